@@ -1,0 +1,80 @@
+"""Pins oracle/psalm_oracle.py against golden vectors produced by the reference code itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances are fp32 round-off level:
+the oracle and the reference run the same arithmetic in different association orders
+(e.g. MSDA gather formula vs grid_sample, fused einsums)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import RNG_SEED_AT_CALL, check_signature, load_case
+from oracle import psalm_oracle as O
+from psalm_amd.config import PsalmConfig
+from psalm_amd.synthetic import make_inputs, make_state_dict
+
+STAGE_RTOL = 2e-4       # stage tensors: max|d| <= 2e-4 * absmax(stage)   (fp32 CPU vs fp32 CPU)
+
+
+def _run(name):
+    case, z = load_case(name)
+    cfg = PsalmConfig(num_layers=case["layers"], seg_task=case["task"])
+    sd = make_state_dict(cfg, seed=case["seed"])
+    inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"])
+    torch.manual_seed(RNG_SEED_AT_CALL)
+    results, st = O.eval_seg(sd, cfg, return_stages=True, **inputs)
+    return case, z, cfg, results, st
+
+
+def _check_stages(z, st):
+    for k in ("res2", "res3", "res4", "res5", "image_tokens", "hidden_states", "mask_features", "pred_masks"):
+        check_signature(z, k, st[k], STAGE_RTOL)
+    for i in range(3):
+        check_signature(z, f"ms{i}", st["multi_scale_features"][i], STAGE_RTOL)
+
+
+@pytest.mark.slow
+def test_region_384():
+    case, z, cfg, results, st = _run("region_384")
+    _check_stages(z, st)
+    got = torch.cat([x.reshape(-1) for x in st["pred_region_logits"]]).numpy()
+    np.testing.assert_allclose(got, z["pred_region_logits"], rtol=0, atol=2e-4 * np.abs(z["pred_region_logits"]).max())
+    np.testing.assert_allclose(st["pred_masks"][:, :, ::4, ::4].numpy(), z["pred_masks_s4"], rtol=0,
+                               atol=2e-4 * np.abs(z["pred_masks_s4"]).max())
+    inst = results[0]["instances"]
+    np.testing.assert_allclose(inst.scores.numpy(), z["inst_scores"], atol=1e-4)
+    area = inst.pred_masks.flatten(1).sum(1).numpy()
+    assert np.abs(area - z["inst_mask_area"]).max() <= 2, "mask areas differ by more than 2 px"
+    check_signature(z, "gt", results[0]["gt"], 1e-5)
+
+
+@pytest.mark.slow
+def test_referring_384_b2():
+    case, z, cfg, results, st = _run("referring_384_b2")
+    _check_stages(z, st)
+    np.testing.assert_allclose(st["pred_SEG_logits"].numpy(), z["pred_SEG_logits"], rtol=0,
+                               atol=2e-4 * np.abs(z["pred_SEG_logits"]).max())
+    inst = results[0]["instances"]
+    # topk(sorted=False) order is unspecified -> compare as multisets
+    np.testing.assert_allclose(np.sort(inst.scores.numpy()), np.sort(z["inst_scores"]), atol=1e-4)
+    assert len(results) == 2                      # the oracle post-processes every image
+
+
+@pytest.mark.slow
+def test_panoptic_512():
+    case, z, cfg, results, st = _run("panoptic_512")
+    _check_stages(z, st)
+    np.testing.assert_allclose(st["pred_class_name_logits"].numpy(), z["pred_class_name_logits"], rtol=0,
+                               atol=2e-4 * np.abs(z["pred_class_name_logits"]).max())
+    r = results[0]
+    am = r["sem_seg"].argmax(0).to(torch.uint8).numpy()
+    agree = (am == z["sem_seg_argmax"]).mean()
+    assert agree >= 1 - 1e-4, f"semantic argmax agreement {agree}"
+    pan, info = r["panoptic_seg"]
+    ginfo = z["panoptic_info"]
+    assert [[s["id"], int(s["isthing"]), s["category_id"]] for s in info] == ginfo.tolist()
+    agree = (pan.to(torch.uint8).numpy() == z["panoptic_ids"]).mean()
+    assert agree >= 1 - 1e-4, f"panoptic id agreement {agree}"
+    inst = r["instances"]
+    order_o = np.lexsort((inst.pred_classes.numpy(), -inst.scores.numpy()))
+    order_g = np.lexsort((z["inst_classes"], -z["inst_scores"]))
+    np.testing.assert_allclose(inst.scores.numpy()[order_o], z["inst_scores"][order_g], atol=1e-4)
+    assert (inst.pred_classes.numpy()[order_o] == z["inst_classes"][order_g]).all()
