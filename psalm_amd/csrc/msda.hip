@@ -1,0 +1,201 @@
+// Multi-scale deformable attention forward (bilinear sample-and-accumulate) for gfx950.
+//
+// Replaces the reference's CUDA op `ms_deformable_im2col_gpu_kernel`
+// (psalm/model/mask_decoder/Mask2Former_Simplify/modeling/pixel_decoder/ops/src/cuda/
+//  ms_deform_im2col_cuda.cuh:242-304, bilinear helper :38-89) -- same arithmetic:
+//     out[b,q,m,:] = sum_{l,p} w[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc[b,q,m,l,p])
+//     h_im = loc_y*H_l - 0.5, w_im = loc_x*W_l - 0.5; a sample contributes only when
+//     -1 < h_im < H_l and -1 < w_im < W_l; out-of-range corners read as 0.
+//
+// This is an HBM/L2 gather, not a GEMM: no MFMA.  Mapping for CDNA4:
+//   * one thread owns VEC=4 consecutive channels of one (b,q,head): a (q,head) pair is D/4 = 8 lanes
+//     that read one 128-byte (fp32) / 64-byte (bf16) contiguous segment per bilinear corner, so a
+//     64-lane wavefront issues 8 fully-used 128 B segments per corner load (16 B per lane);
+//   * consecutive threads walk (head, q) in the order the value/out tensors are laid out, so the
+//     output store is a dense 16 B/lane stream and neighbouring queries (neighbouring pixels) hit
+//     the same L2 lines of `value`; the whole value tensor (22 MB fp32 at 1024^2) is L2/MALL resident;
+//   * the (l,p) loop is fully unrolled for L*P <= 16 so all 4*L*P corner loads of a thread are
+//     independent and in flight together (latency hiding by ILP, ~48 loads/lane).
+//   * FUSED variant (used by the pixel decoder): takes the raw outputs of the fused
+//     [sampling_offsets | attention_weights] projection and computes the softmax over L*P and the
+//     sampling locations in-kernel (ops/modules/ms_deform_attn.py:101-110), so the (B,Lq,M,L,P,2)
+//     location and (B,Lq,M,L,P) weight tensors are never materialised in HBM.
+#include "common.h"
+
+struct alignas(16) f32x4_s { float x, y, z, w; };
+struct alignas(8) bf16x4_s { bf16_t x, y, z, w; };
+
+__device__ __forceinline__ f32x4_s ld4(const float* p) { return *reinterpret_cast<const f32x4_s*>(p); }
+__device__ __forceinline__ f32x4_s ld4(const bf16_t* p) {
+    bf16x4_s v = *reinterpret_cast<const bf16x4_s*>(p);
+    return f32x4_s{bf16_to_f32(v.x), bf16_to_f32(v.y), bf16_to_f32(v.z), bf16_to_f32(v.w)};
+}
+__device__ __forceinline__ void st4(float* p, f32x4_s v) { *reinterpret_cast<f32x4_s*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4_s v) {
+    *reinterpret_cast<bf16x4_s*>(p) = bf16x4_s{f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+}
+
+#define MSDA_MAX_LEVELS 8
+struct MsdaLevels {
+    int H[MSDA_MAX_LEVELS], W[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
+};
+
+template <typename TV>
+__device__ __forceinline__ void msda_sample(const TV* __restrict__ vbase, int Hl, int Wl, int row_stride, float loc_x,
+                                            float loc_y, float wgt, f32x4_s& acc) {
+    const float h_im = loc_y * Hl - 0.5f;
+    const float w_im = loc_x * Wl - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
+        const f32x4_s z{0.f, 0.f, 0.f, 0.f};
+        const TV* p00 = vbase + ((long)h_low * Wl + w_low) * row_stride;
+        f32x4_s v1 = (h0 && w0) ? ld4(p00) : z;
+        f32x4_s v2 = (h0 && w1) ? ld4(p00 + row_stride) : z;
+        f32x4_s v3 = (h1 && w0) ? ld4(p00 + (long)Wl * row_stride) : z;
+        f32x4_s v4 = (h1 && w1) ? ld4(p00 + (long)(Wl + 1) * row_stride) : z;
+        const float w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
+        acc.x += wgt * (w1c * v1.x + w2c * v2.x + w3c * v3.x + w4c * v4.x);
+        acc.y += wgt * (w1c * v1.y + w2c * v2.y + w3c * v3.y + w4c * v4.y);
+        acc.z += wgt * (w1c * v1.z + w2c * v2.z + w3c * v3.z + w4c * v4.z);
+        acc.w += wgt * (w1c * v1.w + w2c * v2.w + w3c * v3.w + w4c * v4.w);
+    }
+}
+
+// Plugin form: explicit sampling locations / attention weights (the reference op's contract).
+template <typename TV, typename TO, int LP_UNROLL>
+__global__ void __launch_bounds__(256) msda_forward_kernel(const TV* __restrict__ value, MsdaLevels lv,
+                                                           const float* __restrict__ loc, const float* __restrict__ attw,
+                                                           TO* __restrict__ out, int B, int S, int M, int D, int L, int Lq,
+                                                           int P) {
+    const int G = D >> 2;  // lanes per (q,head)
+    const long total = (long)B * Lq * M * G;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        long t = idx / G;
+        const int m = (int)(t % M);
+        t /= M;
+        const int q = (int)(t % Lq);
+        const int b = (int)(t / Lq);
+        const long qm = ((long)b * Lq + q) * M + m;
+        const float* lp = loc + qm * L * P * 2;
+        const float* wp = attw + qm * L * P;
+        const int row_stride = M * D;
+        const TV* vb = value + (long)b * S * row_stride + m * D + g * 4;
+        f32x4_s acc{0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) {
+            const TV* vl = vb + (long)lv.start[l] * row_stride;
+#pragma unroll LP_UNROLL
+            for (int p = 0; p < P; ++p) {
+                const int i = l * P + p;
+                msda_sample<TV>(vl, lv.H[l], lv.W[l], row_stride, lp[2 * i], lp[2 * i + 1], wp[i], acc);
+            }
+        }
+        st4(out + qm * D + g * 4, acc);
+    }
+}
+
+// Fused form: raw projection output `ow` (B*Lq, M*L*P*3) = [offsets (M,L,P,2) | logits (M,L*P)],
+// query q is pixel (i,j) of level lq, reference point ((j+.5)/W, (i+.5)/H) (msdeformattn.py:76-87, valid_ratio 1).
+template <typename TV, typename TO, int L, int P>
+__global__ void __launch_bounds__(256) msda_fused_kernel(const TV* __restrict__ value, MsdaLevels lv,
+                                                         const float* __restrict__ ow, TO* __restrict__ out, int B, int S,
+                                                         int M, int D) {
+    const int G = D >> 2;
+    const int Lq = S;
+    const long total = (long)B * Lq * M * G;
+    constexpr int LP = L * P;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        long t = idx / G;
+        const int m = (int)(t % M);
+        t /= M;
+        const int q = (int)(t % Lq);
+        const int b = (int)(t / Lq);
+        int lq = 0;
+#pragma unroll
+        for (int l = 1; l < L; ++l)
+            if (q >= lv.start[l]) lq = l;
+        const int qi = q - lv.start[lq];
+        const float ref_x = ((qi % lv.W[lq]) + 0.5f) / lv.W[lq];
+        const float ref_y = ((qi / lv.W[lq]) + 0.5f) / lv.H[lq];
+        const float* row = ow + ((long)b * Lq + q) * (M * LP * 3);
+        const float* offp = row + m * LP * 2;
+        const float* lgp = row + M * LP * 2 + m * LP;
+        float lg[LP];
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) { lg[i] = lgp[i]; mx = fmaxf(mx, lg[i]); }
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
+        const float inv = 1.f / den;
+        const int row_stride = M * D;
+        const TV* vb = value + (long)b * S * row_stride + m * D + g * 4;
+        f32x4_s acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const TV* vl = vb + (long)lv.start[l] * row_stride;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int i = l * P + p;
+                const float lx = ref_x + offp[2 * i] / lv.W[l];
+                const float ly = ref_y + offp[2 * i + 1] / lv.H[l];
+                msda_sample<TV>(vl, lv.H[l], lv.W[l], row_stride, lx, ly, lg[i] * inv, acc);
+            }
+        }
+        st4(out + (((long)b * Lq + q) * M + m) * D + g * 4, acc);
+    }
+}
+
+static int fill_levels(MsdaLevels& lv, const int64_t* shapes, const int64_t* starts, int L, int S) {
+    if (L > MSDA_MAX_LEVELS) return -1;
+    long tot = 0;
+    for (int l = 0; l < L; ++l) {
+        lv.H[l] = (int)shapes[2 * l];
+        lv.W[l] = (int)shapes[2 * l + 1];
+        lv.start[l] = (int)starts[l];
+        tot += (long)lv.H[l] * lv.W[l];
+    }
+    return tot == S ? 0 : -2;
+}
+
+extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
+                                  const int64_t* level_start_host, const float* sampling_loc, const float* attn_weight,
+                                  void* out, int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream) {
+    PSALM_CHECK_ARG(D % 4 == 0 && D > 0, "psalm_msda_forward: head dim must be a multiple of 4");
+    MsdaLevels lv;
+    int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
+    PSALM_CHECK_ARG(rc != -1, "psalm_msda_forward: too many levels (max 8)");
+    PSALM_CHECK_ARG(rc == 0, "psalm_msda_forward: sum(H_l*W_l) != S");
+    const long total = (long)B * Lq * M * (D / 4);
+    if (total == 0) return 0;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block < 65536 * 8 ? (total + block - 1) / block : 65536 * 8);
+    PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((msda_forward_kernel<TV, TO, 4>), dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           (const TV*)value, lv, sampling_loc, attn_weight, (TO*)out, B, S, M, D, L, Lq, P);
+    }));
+    PSALM_LAUNCH_END("psalm_msda_forward");
+}
+
+extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
+                                const int64_t* level_start_host, const float* offsets_logits, void* out, int out_dtype,
+                                int B, int S, int M, int D, int L, int P, void* stream) {
+    PSALM_CHECK_ARG(D % 4 == 0 && D > 0, "psalm_msda_fused: head dim must be a multiple of 4");
+    PSALM_CHECK_ARG(L == 3 && P == 4, "psalm_msda_fused: specialised for L=3 levels, P=4 points (PSALM pixel decoder)");
+    MsdaLevels lv;
+    int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
+    PSALM_CHECK_ARG(rc == 0, "psalm_msda_fused: bad level table");
+    const long total = (long)B * S * M * (D / 4);
+    if (total == 0) return 0;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block);
+    PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((msda_fused_kernel<TV, TO, 3, 4>), dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);
+    }));
+    PSALM_LAUNCH_END("psalm_msda_fused");
+}

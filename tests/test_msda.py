@@ -1,0 +1,133 @@
+"""MSDA forward: HIP kernel vs the oracle, including the reference's own known-answer test
+(ops/test.py:24-63: seed 3, N,M,D=1,2,2, Lq,L,P=2,2,2, shapes [(6,4),(3,2)], fp32 tol rtol 1e-2 / atol 1e-3)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from ops_backend import ops  # noqa: F401
+from oracle import build_oracle
+from oracle import psalm_oracle as O
+
+
+def _starts(shapes):
+    s = [0]
+    for h, w in shapes[:-1]:
+        s.append(s[-1] + h * w)
+    return s
+
+
+def _c_ref(value, shapes, starts, loc, w, f64=False):
+    libs = build_oracle.build()
+    lib = ctypes.CDLL(libs["libmsda_ref_f64.so" if f64 else "libmsda_ref.so"])
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = torch.empty(B, Lq, M * D)
+    sh = (ctypes.c_int64 * (2 * L))(*[x for hw in shapes for x in hw])
+    st = (ctypes.c_int64 * L)(*starts)
+    lib.msda_forward_ref(ctypes.c_void_p(value.contiguous().data_ptr()), sh, st, ctypes.c_void_p(loc.contiguous().data_ptr()),
+                         ctypes.c_void_p(w.contiguous().data_ptr()), ctypes.c_void_p(out.data_ptr()), B, S, M, D, L, Lq, P)
+    return out
+
+
+def _rand_case(seed, B, M, D, Lq, shapes, P, spread=0.3):
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in shapes)
+    L = len(shapes)
+    value = torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, Lq, M, L, P, 2, generator=g) * (1 + 2 * spread) - spread     # some samples out of bounds
+    w = torch.softmax(torch.randn(B, Lq, M, L * P, generator=g), -1).view(B, Lq, M, L, P)
+    return value, loc, w
+
+
+def test_oracle_known_answer_reference_test_py():
+    """CPU: the reference's own check, oracle-vs-oracle (gather formula and C loops vs grid_sample formula)."""
+    torch.manual_seed(3)
+    N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    for _ in range(2):
+        value = torch.rand(N, S, M, D) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2)
+        w = torch.rand(N, Lq, M, L, P) + 1e-5
+        w /= w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        ref = O.msda_core_grid_sample(value.double(), shapes, loc.double(), w.double()).float()
+        got = O.msda_core(value, shapes, _starts(shapes), loc, w)
+        assert torch.allclose(got, ref, rtol=1e-2, atol=1e-3)          # the reference's fp32 bar
+        assert (got - ref).abs().max() < 1e-7
+        assert (_c_ref(value, shapes, _starts(shapes), loc, w) - ref).abs().max() < 1e-7
+
+
+def test_known_answer_hip(ops):
+    torch.manual_seed(3)
+    N, M, D, Lq, L, P = 1, 2, 4, 2, 2, 2      # D=4: the kernels vectorise 4 channels per lane (PSALM uses D=32)
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    value = torch.rand(N, S, M, D) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    w = torch.rand(N, Lq, M, L, P) + 1e-5
+    w /= w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    ref = O.msda_core_grid_sample(value.double(), shapes, loc.double(), w.double()).float()
+    got = ops.msda_forward(value.to(ops.device), shapes, _starts(shapes), loc.to(ops.device), w.to(ops.device)).cpu()
+    assert torch.allclose(got, ref, rtol=1e-2, atol=1e-3)
+    assert (got - ref).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("B,M,D,Lq,shapes,P", [
+    (1, 8, 32, 70, [(5, 7), (3, 4), (2, 2)], 4),
+    (2, 2, 32, 33, [(9, 6), (4, 3)], 3),
+    (1, 1, 8, 5, [(1, 1)], 1),
+])
+def test_random_vs_oracle(ops, B, M, D, Lq, shapes, P):
+    value, loc, w = _rand_case(0, B, M, D, Lq, shapes, P)
+    st = _starts(shapes)
+    ref64 = _c_ref(value, shapes, st, loc, w, f64=True)
+    ref = O.msda_core(value, shapes, st, loc, w)
+    got = ops.msda_forward(value.to(ops.device), shapes, st, loc.to(ops.device), w.to(ops.device)).cpu()
+    tol = 2e-6 * value.abs().max().item() * 4
+    assert (got - ref64).abs().max() <= tol, (got - ref64).abs().max()
+    assert (ref - ref64).abs().max() <= tol
+    # bf16 value / bf16 out variant: error bounded by bf16 quantisation of value and output
+    gotb = ops.msda_forward(value.bfloat16().to(ops.device), shapes, st, loc.to(ops.device), w.to(ops.device)).cpu().float()
+    refb = _c_ref(value.bfloat16().float(), shapes, st, loc, w, f64=True)
+    assert (gotb - refb).abs().max() <= 2 ** -8 * refb.abs().max() + 1e-6
+
+
+def test_border_semantics(ops):
+    """Locations exactly on the validity limits: h_im in {-1, -0.5, 0, H-1, H-0.5, H}."""
+    shapes = [(4, 5)]
+    H, W = shapes[0]
+    vals = [(-1.0 + 0.5) / H, (-0.999 + 0.5) / H, 0.5 / H, (H - 1 + 0.5) / H, (H - 0.5 + 0.5) / H, (H + 0.5) / H, 0.37]
+    pts = [(x * H / W if False else x, y) for y in vals for x in [0.5 / W, (W - 0.01 + 0.5) / W, (W + 0.5) / W, -0.5 / W]]
+    Lq = len(pts)
+    value = torch.arange(H * W * 4, dtype=torch.float32).view(1, H * W, 1, 4) / 7.0
+    loc = torch.tensor(pts, dtype=torch.float32).view(1, Lq, 1, 1, 1, 2)
+    w = torch.ones(1, Lq, 1, 1, 1)
+    ref = _c_ref(value, shapes, [0], loc, w)
+    got = ops.msda_forward(value.to(ops.device), shapes, [0], loc.to(ops.device), w.to(ops.device)).cpu()
+    assert torch.equal(got, ref) or (got - ref).abs().max() < 1e-5
+
+
+def test_fused_matches_explicit(ops):
+    """Fused kernel (softmax + location arithmetic in-kernel) == ms_deform_attn.py:101-110 done in torch + explicit op."""
+    B, M, D, P = 2, 8, 32, 4
+    shapes = [(4, 4), (8, 8), (16, 16)]
+    L = 3
+    S = sum(h * w for h, w in shapes)
+    st = _starts(shapes)
+    g = torch.Generator().manual_seed(5)
+    value = torch.randn(B, S, M * D, generator=g)
+    ow = torch.randn(B, S, M * L * P * 3, generator=g) * 2.0
+    off = ow[..., : M * L * P * 2].reshape(B, S, M, L, P, 2)
+    aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, S, M, L * P), -1).view(B, S, M, L, P)
+    refs = []
+    for (H_, W_) in shapes:
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing="ij")
+        refs.append(torch.stack((rx.reshape(-1) / W_, ry.reshape(-1) / H_), -1))
+    ref_pts = torch.cat(refs, 0)[None, :, None, None, None, :]
+    norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)[None, None, None, :, None, :]
+    loc = ref_pts + off / norm
+    want = O.msda_core(value.view(B, S, M, D), shapes, st, loc, aw)
+    got = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
+    assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
