@@ -1,0 +1,347 @@
+// Attention kernels of the PSALM inference path (first generation: fp32 VALU math, LDS-staged K/V tiles,
+// wave-parallel online softmax).  All softmax statistics and accumulators are fp32; inputs may be f32 or bf16.
+//
+//   psalm_window_attention  Swin (shifted-)window attention, 12x12 windows, head_dim 32
+//                           (swin_trans.py:117-149 + the shift mask of :369-387 computed in-kernel)
+//   psalm_causal_attention  Phi prefill attention with partial RoPE fused into the Q/K loads
+//                           (modeling_phi.py:189-245, :137-160, :92-122)
+//   psalm_mha_attention     nn.MultiheadAttention core for the predictor: 100 queries x (HW | 100) keys, optional
+//                           boolean mask with the "all-masked row => unmasked" rule
+//                           (mask2former_transformer_decoder.py:645-666, :647)
+//   psalm_attn_mask         bilinear resize of mask logits + (sigmoid < 0.5) -> u8 mask + all-masked row flags
+//                           (mask2former_transformer_decoder.py:754-759)
+#include "common.h"
+
+// ============================================================================================ Swin window attention
+// qkv (B*nW*N, 3C) rows ordered like window_partition (swin_trans.py:37-49); head h uses columns
+// [h*32, h*32+32) of each of the q | k | v thirds.  One block = one (window, head): K, V and the head's
+// relative-position-bias column are staged in LDS; thread t < N owns query row t (q in registers) and streams
+// the N keys with an online softmax, 4 keys per rescale.
+template <typename T, int HD>
+__global__ void __launch_bounds__(192) window_attention_kernel(const T* __restrict__ qkv, const float* __restrict__ bias_table,
+                                                               T* __restrict__ out, int nWh, int nWw, int C, int heads, int ws,
+                                                               int shift) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int N = ws * ws;
+    float* Ks = smem;                       // [N][HD+1]
+    float* Vs = Ks + N * (HD + 1);          // [N][HD+1]
+    float* Bs = Vs + N * (HD + 1);          // [(2ws-1)^2]
+    const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int nbias = (2 * ws - 1) * (2 * ws - 1);
+    const long row0 = (long)win * N;
+    for (int e = tid; e < N * HD; e += blockDim.x) {
+        const int r = e / HD, c = e % HD;
+        const T* p = qkv + (row0 + r) * 3 * C + h * HD + c;
+        Ks[r * (HD + 1) + c] = ldf(p + C);
+        Vs[r * (HD + 1) + c] = ldf(p + 2 * C);
+    }
+    for (int e = tid; e < nbias; e += blockDim.x) Bs[e] = bias_table[(long)e * heads + h];
+    __syncthreads();
+    if (tid >= N) return;
+    const float scale = rsqrtf((float)HD);
+    float q[HD], o[HD];
+    {
+        const T* p = qkv + (row0 + tid) * 3 * C + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { q[c] = ldf(p + c) * scale; o[c] = 0.f; }
+    }
+    const int yi = tid / ws, xi = tid % ws;
+    // shift-mask region label of a token (swin_trans.py:371-387): slices (0,-ws), (-ws,-shift), (-shift,None)
+    const int wwin = win % (nWh * nWw);
+    const int wh = wwin / nWw, ww = wwin % nWw;
+    const int Hp = nWh * ws, Wp = nWw * ws;
+    auto label = [&](int yy, int xx) -> int {
+        const int gy = wh * ws + yy, gx = ww * ws + xx;
+        const int ly = gy < Hp - ws ? 0 : (gy < Hp - shift ? 1 : 2);
+        const int lx = gx < Wp - ws ? 0 : (gx < Wp - shift ? 1 : 2);
+        return ly * 3 + lx;
+    };
+    const int my_label = shift > 0 ? label(yi, xi) : 0;
+    float m = -3.0e38f, l = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 4) {
+        float s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            if (j < N) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) acc += q[c] * Ks[j * (HD + 1) + c];
+                const int yj = j / ws, xj = j % ws;
+                acc += Bs[(yi - yj + ws - 1) * (2 * ws - 1) + (xi - xj + ws - 1)];
+                if (shift > 0 && label(yj, xj) != my_label) acc += -100.0f;
+                s[u] = acc;
+            } else s[u] = -3.0e38f;
+        }
+        const float mc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(m - mn);
+        l *= alpha;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            if (j < N) {
+                const float p = __expf(s[u] - mn);
+                l += p;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) o[c] += p * Vs[j * (HD + 1) + c];
+            }
+        }
+        m = mn;
+    }
+    const float inv = 1.f / l;
+    T* op = out + (row0 + tid) * C + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) stf(op + c, o[c] * inv);
+}
+
+extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw,
+                                      int C, int heads, int ws, int shift, void* stream) {
+    PSALM_CHECK_ARG(C == heads * 32, "psalm_window_attention: head_dim must be 32");
+    PSALM_CHECK_ARG(ws * ws <= 192, "psalm_window_attention: window too large (ws*ws <= 192)");
+    const int nwin = B * nWh * nWw;
+    if (nwin == 0) return 0;
+    const int N = ws * ws;
+    const size_t shmem = (size_t)(2 * N * 33 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
+    PSALM_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((window_attention_kernel<T, 32>), dim3(nwin, heads), dim3(192), shmem, (hipStream_t)stream,
+                           (const T*)qkv, bias_table, (T*)out, nWh, nWw, C, heads, ws, shift);
+    });
+    PSALM_LAUNCH_END("psalm_window_attention");
+}
+
+// ============================================================================================ Phi causal attention
+// q/k/v are column blocks of one row-strided buffer (ld elements per token): q at col q_off + h*64, etc.
+// Partial RoPE on the first `rot` dims of each head (modeling_phi.py:218-231): x*cos + rotate_half(x)*sin with
+// rotate_half(x) = cat(-x[rot/2:], x[:rot/2]); cos/sin tables (Lmax, rot) fp32 are computed on the host exactly as the
+// reference does (emb = cat(freqs, freqs)).  allowed(i,j) = j <= i && key_mask[b,j]  (causal + padding).
+// Block = 128 threads = 128 consecutive queries of one (batch, head); K/V tiles of 64 keys are staged in LDS
+// (RoPE applied while staging); each thread owns one query row (q, o in registers), 4 keys per softmax rescale.
+template <typename T, int HD, int ROT, int QT>
+__global__ void __launch_bounds__(QT) causal_attention_kernel(const T* __restrict__ base, long ld, int q_off, int k_off,
+                                                               int v_off, T* out, long ldo, int o_off,
+                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                               const unsigned char* __restrict__ key_mask, int L, int heads,
+                                                               float scale) {
+    constexpr int KT = 64, rot = ROT;
+    __shared__ float Ks[KT][HD + 1];
+    __shared__ float Vs[KT][HD + 1];
+    __shared__ unsigned char Ms[KT];
+    const int tid = threadIdx.x;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qi = qt * QT + tid;
+    const bool active = qi < L;
+    const long tok0 = (long)b * L;
+    constexpr int half = ROT / 2;
+    float q[HD], o[HD];
+    if (active) {
+        const T* p = base + (tok0 + qi) * ld + q_off + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) q[c] = ldf(p + c);
+        // RoPE on q
+#pragma unroll
+        for (int c = 0; c < half; ++c) {
+            const float x1 = q[c], x2 = q[c + half];
+            const float c1 = cosT[(long)qi * rot + c], s1 = sinT[(long)qi * rot + c];
+            const float c2 = cosT[(long)qi * rot + c + half], s2 = sinT[(long)qi * rot + c + half];
+            q[c] = x1 * c1 - x2 * s1;
+            q[c + half] = x2 * c2 + x1 * s2;
+        }
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { q[c] *= scale; o[c] = 0.f; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { q[c] = 0.f; o[c] = 0.f; }
+    }
+    float m = -3.0e38f, l = 0.f;
+    const int last_q = min(L - 1, qt * QT + QT - 1);
+    const int ntiles = last_q / KT + 1;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        for (int e = tid; e < KT * HD; e += QT) {
+            const int r = e / HD, c = e % HD;
+            const int kj = kt * KT + r;
+            float kv = 0.f, vv = 0.f;
+            if (kj < L) {
+                const T* p = base + (tok0 + kj) * ld;
+                kv = ldf(p + k_off + h * HD + c);
+                vv = ldf(p + v_off + h * HD + c);
+                if (c < rot) {
+                    const float other = ldf(p + k_off + h * HD + (c < half ? c + half : c - half));
+                    const float cs = cosT[(long)kj * rot + c], sn = sinT[(long)kj * rot + c];
+                    kv = kv * cs + (c < half ? -other : other) * sn;
+                }
+            }
+            Ks[r][c] = kv;
+            Vs[r][c] = vv;
+        }
+        for (int e = tid; e < KT; e += QT) { const int kj = kt * KT + e; Ms[e] = (kj < L) ? key_mask[(long)b * L + kj] : 0; }
+        __syncthreads();
+        if (active && kt * KT <= qi) {
+            for (int j0 = 0; j0 < KT; j0 += 4) {
+                float s[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u, kj = kt * KT + j;
+                    ok[u] = (kj <= qi) && Ms[j];
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) acc += q[c] * Ks[j][c];
+                    s[u] = ok[u] ? acc : -3.0e38f;
+                }
+                const float mc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+                if (mc > -1.0e38f) {
+                    const float mn = fmaxf(m, mc);
+                    const float alpha = __expf(m - mn);
+                    l *= alpha;
+#pragma unroll
+                    for (int c = 0; c < HD; ++c) o[c] *= alpha;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok[u]) {
+                            const float p = __expf(s[u] - mn);
+                            l += p;
+#pragma unroll
+                            for (int c = 0; c < HD; ++c) o[c] += p * Vs[j0 + u][c];
+                        }
+                    }
+                    m = mn;
+                }
+            }
+        }
+    }
+    if (active) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        T* op = out + (tok0 + qi) * ldo + o_off + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) stf(op + c, o[c] * inv);
+    }
+}
+
+extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,
+                                      int o_off, const float* cos_table, const float* sin_table,
+                                      const unsigned char* key_mask, int B, int L, int heads, int head_dim, int rot,
+                                      void* stream) {
+    PSALM_CHECK_ARG(head_dim == 64, "psalm_causal_attention: head_dim must be 64 (Phi-1.5)");
+    PSALM_CHECK_ARG(rot == 32, "psalm_causal_attention: rotary dim must be 32 (Phi-1.5: 0.5 * 64)");
+    if (B == 0 || L == 0) return 0;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    PSALM_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((causal_attention_kernel<T, 64, 32, 128>), dim3(cdiv(L, 128), heads, B), dim3(128), 0,
+                           (hipStream_t)stream, (const T*)qkv, ld, q_off, k_off, v_off, (T*)out, ldo, o_off, cos_table,
+                           sin_table, key_mask, L, heads, scale);
+    });
+    PSALM_LAUNCH_END("psalm_causal_attention");
+}
+
+// ============================================================================================ generic MHA (predictor)
+// q (B,Lq,*) row stride ldq, k/v (B,Lk,*) row strides ldk/ldv; head h uses columns [h*32, h*32+32).
+// mask (B,Lq,Lk) u8, 1 = NOT allowed; row_all_masked (B,Lq) u8: 1 -> ignore the mask for that row (TD:647).
+// One wave per (b, h, q): lanes split the keys (64 per step), each lane keeps a private online-softmax state
+// (m, l, o[32]); the 64 states are merged with a butterfly at the end.
+template <typename T, int HD>
+__global__ void __launch_bounds__(256) mha_attention_kernel(const T* __restrict__ Q, long ldq, const T* __restrict__ K, long ldk,
+                                                            const T* __restrict__ V, long ldv, T* __restrict__ O, long ldo,
+                                                            const unsigned char* __restrict__ mask,
+                                                            const unsigned char* __restrict__ row_all_masked, int B, int Lq,
+                                                            int Lk, int heads, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)B * heads * Lq;
+    if (w >= total) return;
+    const int qi = (int)(w % Lq);
+    const int h = (int)((w / Lq) % heads);
+    const int b = (int)(w / ((long)Lq * heads));
+    float q[HD], o[HD];
+    {
+        const T* p = Q + ((long)b * Lq + qi) * ldq + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) { q[c] = ldf(p + c) * scale; o[c] = 0.f; }
+    }
+    const unsigned char* mrow = nullptr;
+    if (mask && !(row_all_masked && row_all_masked[(long)b * Lq + qi])) mrow = mask + ((long)b * Lq + qi) * Lk;
+    float m = -3.0e38f, l = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+        if (mrow && mrow[j]) continue;
+        const T* kp = K + ((long)b * Lk + j) * ldk + h * HD;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s += q[c] * ldf(kp + c);
+        const float mn = fmaxf(m, s);
+        const float alpha = __expf(m - mn), p = __expf(s - mn);
+        l = l * alpha + p;
+        const T* vp = V + ((long)b * Lk + j) * ldv + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = o[c] * alpha + p * ldf(vp + c);
+        m = mn;
+    }
+    const float mall = wave_max(m);
+    const float f = (m > -1.0e38f) ? __expf(m - mall) : 0.f;
+    const float lall = wave_sum(l * f);
+    const float inv = lall > 0.f ? 1.f / lall : 0.f;
+    T* op = O + ((long)b * Lq + qi) * ldo + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+        const float v = wave_sum(o[c] * f);
+        if (lane == (c & 63)) stf(op + c, v * inv);
+    }
+}
+
+extern "C" int psalm_mha_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out, long ldo,
+                                   int dtype, const unsigned char* mask, const unsigned char* row_all_masked, int B, int Lq,
+                                   int Lk, int heads, int head_dim, void* stream) {
+    PSALM_CHECK_ARG(head_dim == 32, "psalm_mha_attention: head_dim must be 32");
+    const long total = (long)B * heads * Lq;
+    if (total == 0 || Lk == 0) return 0;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    PSALM_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((mha_attention_kernel<T, 32>), dim3(cdiv(total, 4)), dim3(256), 0, (hipStream_t)stream, (const T*)q,
+                           ldq, (const T*)k, ldk, (const T*)v, ldv, (T*)out, ldo, mask, row_all_masked, B, Lq, Lk, heads, scale);
+    });
+    PSALM_LAUNCH_END("psalm_mha_attention");
+}
+
+// ============================================================================================ attention-mask generation
+// masks (B*Q, h, w) f32 logits -> bilinear (align_corners=False, PyTorch index rule) to (Ht,Wt) -> mask = logit < 0
+// (== sigmoid < 0.5) -> u8 (B*Q, Ht*Wt); row_all_masked[bq] = 1 when every key is masked.
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ src, int h, int w, float sy, float sx) {
+    sy = fmaxf(sy, 0.f);
+    sx = fmaxf(sx, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * src[(long)y0 * w + x0] + lx * src[(long)y0 * w + x1]) +
+           ly * (hx * src[(long)y1 * w + x0] + lx * src[(long)y1 * w + x1]);
+}
+
+__global__ void __launch_bounds__(256) attn_mask_kernel(const float* __restrict__ masks, unsigned char* __restrict__ out,
+                                                        unsigned char* __restrict__ row_all_masked, int h, int w, int Ht,
+                                                        int Wt) {
+    __shared__ int cnt[4];
+    const int bq = blockIdx.x, tid = threadIdx.x;
+    const float* src = masks + (long)bq * h * w;
+    const float sh = (float)h / Ht, sw = (float)w / Wt;
+    int unmasked = 0;
+    for (int i = tid; i < Ht * Wt; i += 256) {
+        const int y = i / Wt, x = i % Wt;
+        const float v = bilinear_at(src, h, w, sh * (y + 0.5f) - 0.5f, sw * (x + 0.5f) - 0.5f);
+        const unsigned char mk = v < 0.f ? 1 : 0;
+        out[(long)bq * Ht * Wt + i] = mk;
+        unmasked += !mk;
+    }
+    const float tot = wave_sum((float)unmasked);
+    if ((tid & 63) == 0) cnt[tid >> 6] = (int)tot;
+    __syncthreads();
+    if (tid == 0) row_all_masked[bq] = (cnt[0] + cnt[1] + cnt[2] + cnt[3]) == 0 ? 1 : 0;
+}
+
+extern "C" int psalm_attn_mask(const float* masks, unsigned char* out, unsigned char* row_all_masked, int BQ, int h, int w,
+                               int Ht, int Wt, void* stream) {
+    if (BQ == 0) return 0;
+    hipLaunchKernelGGL(attn_mask_kernel, dim3(BQ), dim3(256), 0, (hipStream_t)stream, masks, out, row_all_masked, h, w, Ht, Wt);
+    PSALM_LAUNCH_END("psalm_attn_mask");
+}

@@ -1,0 +1,232 @@
+// Data-layout kernels around the GEMMs: im2col for the patch-embed / projector / FPN convolutions, bilinear
+// resampling (PyTorch align_corners=False index rule), sine position embedding.  Activations are NHWC
+// ("tokens x channels") everywhere so 1x1 convolutions are plain GEMMs and 3x3 / strided ones are im2col + GEMM.
+#include "common.h"
+
+// ---------------------------------------------------------------- PatchEmbed im2col from the NCHW fp32 image
+// swin_trans.py:427-436: Conv2d(3, E, k=ps, stride=ps) after right/bottom zero padding to a multiple of ps.
+// out (B*Hp*Wp, Kpad) with K order (c, ky, kx) == the flattened conv weight (E, 3, ps, ps); columns >= 3*ps*ps are 0.
+template <typename TO>
+__global__ void __launch_bounds__(256) patch_im2col_kernel(const float* __restrict__ img, TO* __restrict__ out, int B, int Cin,
+                                                           int H, int W, int ps, int Hp, int Wp, int Kpad) {
+    const long total = (long)B * Hp * Wp * Kpad;
+    const int K = Cin * ps * ps;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kpad);
+        long t = i / Kpad;
+        const int px = (int)(t % Wp);
+        t /= Wp;
+        const int py = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / (ps * ps), ky = (k / ps) % ps, kx = k % ps;
+            const int y = py * ps + ky, x = px * ps + kx;
+            if (y < H && x < W) v = img[(((long)b * Cin + c) * H + y) * W + x];
+        }
+        stf(out + i, v);
+    }
+}
+
+extern "C" int psalm_patch_im2col(const float* img, void* out, int out_dtype, int B, int Cin, int H, int W, int ps, int Kpad,
+                                  void* stream) {
+    const int Hp = (H + ps - 1) / ps, Wp = (W + ps - 1) / ps;
+    const long total = (long)B * Hp * Wp * Kpad;
+    if (total == 0) return 0;
+    PSALM_CHECK_ARG(Kpad >= Cin * ps * ps, "psalm_patch_im2col: Kpad too small");
+    const int grid = (int)((total + 2047) / 2048);
+    PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((patch_im2col_kernel<TO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (TO*)out, B, Cin, H, W,
+                           ps, Hp, Wp, Kpad);
+    });
+    PSALM_LAUNCH_END("psalm_patch_im2col");
+}
+
+// ---------------------------------------------------------------- generic NHWC im2col, K order (ky, kx, c)
+// x (B,H,W,C) -> out (B*Ho*Wo, k*k*C); weights are pre-permuted on the host to (Cout, ky, kx, Cin).
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+                                                          int k, int stride, int pad, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo * k * k * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int kx = (int)(t % k);
+        t /= k;
+        const int ky = (int)(t % k);
+        t /= k;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int y = oy * stride - pad + ky, xx = ox * stride - pad + kx;
+        T v = 0;
+        if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((long)b * H + y) * W + xx) * C + c];
+        out[i] = v;
+    }
+}
+
+extern "C" int psalm_im2col_nhwc(const void* x, void* out, int dtype, int B, int H, int W, int C, int k, int stride, int pad,
+                                 void* stream) {
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long total = (long)B * Ho * Wo * k * k * C;
+    if (total == 0) return 0;
+    long g = (total + 2047) / 2048;
+    const int grid = (int)(g > 1048576 ? 1048576 : g);
+    PSALM_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((im2col_nhwc_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, H, W, C,
+                           k, stride, pad, Ho, Wo);
+    });
+    PSALM_LAUNCH_END("psalm_im2col_nhwc");
+}
+
+// ---------------------------------------------------------------- bilinear resize, PyTorch align_corners=False rule
+// src index = scale*(dst+0.5)-0.5 clamped at 0, scale = in/out (float); neighbour +1 clamped at the border.
+struct BilinIdx { int i0, i1; float l0, l1; };
+__device__ __forceinline__ BilinIdx bilin_idx(int d, float scale, int in_size) {
+    float s = scale * (d + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    BilinIdx r;
+    r.i0 = (int)s;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l1 = s - r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+// planes: in (N, h, w) -> out (N, H, W), with an optional crop of the input to (hc, wc) first
+// (sem_seg_postprocess = crop + resize, llava_phi.py:1427-1429)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) resize_planes_kernel(const TI* __restrict__ in, TO* __restrict__ out, long N, int h, int w,
+                                                            int hc, int wc, int H, int W) {
+    const long total = N * H * W;
+    const float sh = (float)hc / H, sw = (float)wc / W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const long n = i / ((long)W * H);
+        const BilinIdx iy = bilin_idx(y, sh, hc), ix = bilin_idx(x, sw, wc);
+        const TI* p = in + n * h * w;
+        const float v = iy.l0 * (ix.l0 * ldf(p + (long)iy.i0 * w + ix.i0) + ix.l1 * ldf(p + (long)iy.i0 * w + ix.i1)) +
+                        iy.l1 * (ix.l0 * ldf(p + (long)iy.i1 * w + ix.i0) + ix.l1 * ldf(p + (long)iy.i1 * w + ix.i1));
+        stf(out + i, v);
+    }
+}
+
+extern "C" int psalm_resize_planes(const void* in, int in_dtype, void* out, int out_dtype, long N, int h, int w, int hc, int wc,
+                                   int H, int W, void* stream) {
+    const long total = N * H * W;
+    if (total == 0) return 0;
+    PSALM_CHECK_ARG(hc <= h && wc <= w && hc > 0 && wc > 0, "psalm_resize_planes: bad crop");
+    long g = (total + 1023) / 1024;
+    const int grid = (int)(g > 1048576 ? 1048576 : g);
+    PSALM_DISPATCH(in_dtype, TI, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((resize_planes_kernel<TI, TO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out, N,
+                           h, w, hc, wc, H, W);
+    }));
+    PSALM_LAUNCH_END("psalm_resize_planes");
+}
+
+// NHWC: out (B,H,W,C) = lateral (B,H,W,C) + bilinear_up(small (B,h,w,C))   -- FPN top-down step, msdeformattn.py:306
+// (the reference upsamples in fp32: `.float()` then cast back)
+template <typename TL, typename TS, typename TO>
+__global__ void __launch_bounds__(256) upsample_add_nhwc_kernel(const TL* __restrict__ lat, const TS* __restrict__ small,
+                                                                TO* __restrict__ out, int B, int h, int w, int H, int W, int C) {
+    const long total = (long)B * H * W * C;
+    const float sh = (float)h / H, sw = (float)w / W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const BilinIdx iy = bilin_idx(y, sh, h), ix = bilin_idx(x, sw, w);
+        const TS* p = small + (long)b * h * w * C + c;
+        const float v = iy.l0 * (ix.l0 * ldf(p + ((long)iy.i0 * w + ix.i0) * C) + ix.l1 * ldf(p + ((long)iy.i0 * w + ix.i1) * C)) +
+                        iy.l1 * (ix.l0 * ldf(p + ((long)iy.i1 * w + ix.i0) * C) + ix.l1 * ldf(p + ((long)iy.i1 * w + ix.i1) * C));
+        stf(out + i, ldf(lat + i) + v);
+    }
+}
+
+extern "C" int psalm_upsample_add_nhwc(const void* lateral, int lat_dtype, const void* small, int small_dtype, void* out,
+                                       int out_dtype, int B, int h, int w, int H, int W, int C, void* stream) {
+    const long total = (long)B * H * W * C;
+    if (total == 0) return 0;
+    long g = (total + 2047) / 2048;
+    const int grid = (int)(g > 1048576 ? 1048576 : g);
+    PSALM_DISPATCH(lat_dtype, TL, PSALM_DISPATCH(small_dtype, TS, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((upsample_add_nhwc_kernel<TL, TS, TO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const TL*)lateral,
+                           (const TS*)small, (TO*)out, B, h, w, H, W, C);
+    })));
+    PSALM_LAUNCH_END("psalm_upsample_add_nhwc");
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC and back (API boundary only)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) permute_nchw_nhwc_kernel(const TI* __restrict__ in, TO* __restrict__ out, int B, int C,
+                                                                long HW, int to_nhwc) {
+    const long total = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // i indexes the OUTPUT
+        if (to_nhwc) {
+            const int c = (int)(i % C);
+            const long p = (i / C) % HW;
+            const long b = i / ((long)C * HW);
+            stf(out + i, ldf(in + (b * C + c) * HW + p));
+        } else {
+            const long p = i % HW;
+            const int c = (int)((i / HW) % C);
+            const long b = i / ((long)C * HW);
+            stf(out + i, ldf(in + (b * HW + p) * C + c));
+        }
+    }
+}
+
+extern "C" int psalm_permute_layout(const void* in, int in_dtype, void* out, int out_dtype, int B, int C, long HW, int to_nhwc,
+                                    void* stream) {
+    const long total = (long)B * C * HW;
+    if (total == 0) return 0;
+    long g = (total + 2047) / 2048;
+    const int grid = (int)(g > 1048576 ? 1048576 : g);
+    PSALM_DISPATCH(in_dtype, TI, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((permute_nchw_nhwc_kernel<TI, TO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out,
+                           B, C, HW, to_nhwc);
+    }));
+    PSALM_LAUNCH_END("psalm_permute_layout");
+}
+
+// ---------------------------------------------------------------- region pooling (visual prompts)
+// context_cluster.py:333-400: per region, bilinear-sample (grid_sample, align_corners=True, zero padding) the image's
+// projector tokens viewed as an (h, w, C) map at n points (y,x in [0,1)), then average over the points.
+// tokens (B*h*w, C) f32; img_of_region (R) int32; pts (R, n, 2) f32 (y, x); out (R, C) f32.  One block per region.
+__global__ void __launch_bounds__(256) region_pool_kernel(const float* __restrict__ tokens, const int* __restrict__ img_of_region,
+                                                          const float* __restrict__ pts, float* __restrict__ out, int h, int w,
+                                                          int C, int n) {
+    const int r = blockIdx.x;
+    const float* fmap = tokens + (long)img_of_region[r] * h * w * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int p = 0; p < n; ++p) {
+            const float gy = 2.0f * pts[((long)r * n + p) * 2 + 0] - 1.0f, gx = 2.0f * pts[((long)r * n + p) * 2 + 1] - 1.0f;
+            const float iy = (gy + 1.f) * 0.5f * (h - 1), ix = (gx + 1.f) * 0.5f * (w - 1);
+            const float fy = floorf(iy), fx = floorf(ix);
+            const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+            const float wy1 = iy - fy, wx1 = ix - fx, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+            float v = 0.f;
+            if (y0 >= 0 && y0 < h && x0 >= 0 && x0 < w) v += wy0 * wx0 * fmap[((long)y0 * w + x0) * C + c];
+            if (y0 >= 0 && y0 < h && x1 >= 0 && x1 < w) v += wy0 * wx1 * fmap[((long)y0 * w + x1) * C + c];
+            if (y1 >= 0 && y1 < h && x0 >= 0 && x0 < w) v += wy1 * wx0 * fmap[((long)y1 * w + x0) * C + c];
+            if (y1 >= 0 && y1 < h && x1 >= 0 && x1 < w) v += wy1 * wx1 * fmap[((long)y1 * w + x1) * C + c];
+            acc += v;
+        }
+        out[(long)r * C + c] = acc / n;
+    }
+}
+
+extern "C" int psalm_region_pool(const float* tokens, const int* img_of_region, const float* pts, float* out, int R, int h, int w,
+                                 int C, int n, void* stream) {
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(region_pool_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, tokens, img_of_region, pts, out, h, w, C, n);
+    PSALM_LAUNCH_END("psalm_region_pool");
+}

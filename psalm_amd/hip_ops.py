@@ -21,6 +21,7 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libpsalm_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_NEW = 0, 1, 2, 3
+ACT_POST_RESIDUAL = 16
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
@@ -67,6 +68,14 @@ class Ops:
             raise PsalmHipError("psalm_amd kernels need GPU tensors (no CPU fallback)")
         return c_void_p(t.data_ptr())
 
+    def _pv(self, t: Optional[torch.Tensor]):
+        """pointer of a possibly row-strided view (caller passes the stride)."""
+        if t is None:
+            return c_void_p(0)
+        if self.is_emu != (t.device.type == "cpu"):
+            raise PsalmHipError("tensor on the wrong device for this backend (no CPU fallback)")
+        return c_void_p(t.data_ptr())
+
     def _check(self, rc: int, name: str):
         if rc != 0:
             raise PsalmHipError(f"{name} failed (rc={rc}): {self.lib.psalm_last_error().decode()}")
@@ -76,6 +85,202 @@ class Ops:
 
     def zeros(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, a, w, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=None):
+        """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  `a`, `out`, `residual` may be row-strided 2-D views
+        (last dim contiguous).  w.dtype selects the arithmetic: bfloat16 -> bf16 MFMA / fp32 accumulate,
+        float32 -> exact fp32 MFMA."""
+        if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1]:
+            raise PsalmHipError(f"gemm shape mismatch {tuple(a.shape)} x {tuple(w.shape)}")
+        M, K = a.shape
+        N = w.shape[0]
+        if out is None:
+            out = self.empty(M, N, dtype=out_dtype or (torch.float32 if w.dtype == torch.float32 else a.dtype))
+        for t in (a, w, out) + ((residual,) if residual is not None else ()):
+            if t.stride(-1) != 1:
+                raise PsalmHipError("gemm operands need a contiguous last dimension")
+        if residual is not None and (residual.dtype != out.dtype or residual.shape != out.shape):
+            raise PsalmHipError("gemm residual must match the output's dtype and shape")
+        if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+            raise PsalmHipError("gemm bias must be float32 (N,)")
+        rc = self.lib.psalm_gemm(self._pv(a), _dt(a), c_long(a.stride(0)), self._pv(w), _dt(w), c_long(w.stride(0)),
+                                 self._pv(bias), self._pv(residual), c_long(residual.stride(0) if residual is not None else 0),
+                                 self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start, self._stream())
+        self._check(rc, "psalm_gemm")
+        return out
+
+    # ------------------------------------------------------------------ row ops
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None):
+        """LayerNorm over the last dim of a 2-D (row-strided) view."""
+        rows, C = x.shape
+        if out is None:
+            out = self.empty(rows, C, dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_layernorm(self._pv(x), _dt(x), c_long(x.stride(0)), self._pv(out), _dt(out), c_long(out.stride(0)),
+                                      self._p(gamma), self._p(beta), rows, C, c_float(eps), self._stream())
+        self._check(rc, "psalm_layernorm")
+        return out
+
+    def swin_window_gather(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5, out_dtype=None):
+        """x (B*H*W, C) -> LN + pad + roll(-shift) + window partition -> (B*nW*ws*ws, C)."""
+        C = x.shape[-1]
+        nWh, nWw = (H + ws - 1) // ws, (W + ws - 1) // ws
+        out = self.empty(B * nWh * nWw * ws * ws, C, dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_swin_window_gather(self._p(x), _dt(x), self._p(out), _dt(out), self._p(gamma), self._p(beta), B, H, W,
+                                               C, ws, shift, c_float(eps), self._stream())
+        self._check(rc, "psalm_swin_window_gather")
+        return out
+
+    def swin_window_merge(self, win, shortcut, B, H, W, ws, shift, out=None):
+        """out (B*H*W, C) = shortcut + window_reverse/roll(+shift)/crop(win)."""
+        C = shortcut.shape[-1]
+        if out is None:
+            out = torch.empty_like(shortcut)
+        rc = self.lib.psalm_swin_window_merge(self._p(win), _dt(win), self._p(shortcut), self._p(out), _dt(shortcut), B, H, W, C,
+                                              ws, shift, self._stream())
+        self._check(rc, "psalm_swin_window_merge")
+        return out
+
+    def patch_merge_ln(self, x, gamma, beta, B, H, W, eps=1e-5, out_dtype=None):
+        C = x.shape[-1]
+        out = self.empty(B * ((H + 1) // 2) * ((W + 1) // 2), 4 * C, dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_patch_merge_ln(self._p(x), _dt(x), self._p(out), _dt(out), self._p(gamma), self._p(beta), B, H, W, C,
+                                           c_float(eps), self._stream())
+        self._check(rc, "psalm_patch_merge_ln")
+        return out
+
+    def groupnorm_nhwc(self, x, gamma, beta, B, HW, groups, eps=1e-5, relu=False, out_dtype=None, out=None):
+        """x (B*HW, C) NHWC -> GroupNorm(groups) [+ReLU]."""
+        C = x.shape[-1]
+        if out is None:
+            out = self.empty(B * HW, C, dtype=out_dtype or x.dtype)
+        ws = self.empty(B * ((HW + 63) // 64) * groups * 2, dtype=torch.float32)
+        rc = self.lib.psalm_groupnorm_nhwc(self._p(x), _dt(x), self._p(out), _dt(out), self._p(gamma), self._p(beta), self._p(ws),
+                                           B, HW, C, groups, c_float(eps), int(relu), self._stream())
+        self._check(rc, "psalm_groupnorm_nhwc")
+        return out
+
+    def add_bcast(self, a, b, out_dtype=None):
+        """out[r] = a[r] + b[r % b_rows]   (a (rows,C), b (b_rows,C))."""
+        rows, C = a.shape
+        out = self.empty(rows, C, dtype=out_dtype or a.dtype)
+        rc = self.lib.psalm_add_bcast(self._p(a), _dt(a), self._p(b), _dt(b), self._p(out), _dt(out), c_long(rows), C,
+                                      c_long(b.shape[0]), self._stream())
+        self._check(rc, "psalm_add_bcast")
+        return out
+
+    def gather_rows(self, srcs, src_id, src_row, C, out_dtype=torch.float32):
+        """dst[r] = srcs[src_id[r]][src_row[r]]; src_id < 0 -> zero row.  src_id/src_row int32 device tensors."""
+        srcs = list(srcs) + [None] * (4 - len(srcs))
+        rows = src_id.numel()
+        out = self.empty(rows, C, dtype=out_dtype)
+        args = []
+        for t in srcs:
+            args += [self._p(t), _dt(t) if t is not None else 0]
+        rc = self.lib.psalm_gather_rows(*args, self._p(src_id), self._p(src_row), self._p(out), _dt(out), c_long(rows), C,
+                                        self._stream())
+        self._check(rc, "psalm_gather_rows")
+        return out
+
+    def segment_mean(self, x, seg_offsets, seg_rows, out_dtype=None):
+        """out[s] = mean of x[seg_rows[seg_offsets[s]:seg_offsets[s+1]]]."""
+        nseg = seg_offsets.numel() - 1
+        C = x.shape[-1]
+        out = self.empty(nseg, C, dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_segment_mean(self._pv(x), _dt(x), c_long(x.stride(0)), self._p(seg_offsets), self._p(seg_rows),
+                                         self._p(out), _dt(out), nseg, C, self._stream())
+        self._check(rc, "psalm_segment_mean")
+        return out
+
+    # ------------------------------------------------------------------ attention
+    def window_attention(self, qkv, bias_table, B, nWh, nWw, heads, ws, shift):
+        C = qkv.shape[-1] // 3
+        out = self.empty(qkv.shape[0], C, dtype=qkv.dtype)
+        rc = self.lib.psalm_window_attention(self._p(qkv), self._p(bias_table), self._p(out), _dt(qkv), B, nWh, nWw, C, heads, ws,
+                                             shift, self._stream())
+        self._check(rc, "psalm_window_attention")
+        return out
+
+    def causal_attention(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot):
+        """buf (B*L, ld) holds q|k|v column blocks; out (B*L, ldo) receives the attention output at column o_off."""
+        if buf.dtype != out.dtype:
+            raise PsalmHipError("causal_attention: buf/out dtype mismatch")
+        rc = self.lib.psalm_causal_attention(self._pv(buf), _dt(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out),
+                                             c_long(out.stride(0)), o_off, self._p(cos), self._p(sin), self._p(key_mask), B, L,
+                                             heads, head_dim, rot, self._stream())
+        self._check(rc, "psalm_causal_attention")
+        return out
+
+    def mha_attention(self, q, k, v, B, Lq, Lk, heads, mask=None, row_all_masked=None):
+        """q (B*Lq, D) / k, v (B*Lk, D) row-strided views, head_dim 32; mask (B,Lq,Lk) u8 1 = blocked."""
+        D = heads * 32
+        out = self.empty(B * Lq, D, dtype=q.dtype)
+        rc = self.lib.psalm_mha_attention(self._pv(q), c_long(q.stride(0)), self._pv(k), c_long(k.stride(0)), self._pv(v),
+                                          c_long(v.stride(0)), self._p(out), c_long(D), _dt(q), self._p(mask),
+                                          self._p(row_all_masked), B, Lq, Lk, heads, 32, self._stream())
+        self._check(rc, "psalm_mha_attention")
+        return out
+
+    def attn_mask(self, masks, Ht, Wt):
+        """masks (B,Q,h,w) f32 logits -> (u8 (B,Q,Ht*Wt) 1 = blocked, u8 (B,Q) all-masked flags)."""
+        B, Q, h, w = masks.shape
+        out = self.empty(B, Q, Ht * Wt, dtype=torch.uint8)
+        flags = self.empty(B, Q, dtype=torch.uint8)
+        rc = self.lib.psalm_attn_mask(self._p(masks), self._p(out), self._p(flags), B * Q, h, w, Ht, Wt, self._stream())
+        self._check(rc, "psalm_attn_mask")
+        return out, flags
+
+    # ------------------------------------------------------------------ image / layout ops
+    def patch_im2col(self, img, ps, Kpad, out_dtype=torch.float32):
+        B, Cin, H, W = img.shape
+        Hp, Wp = (H + ps - 1) // ps, (W + ps - 1) // ps
+        out = self.empty(B * Hp * Wp, Kpad, dtype=out_dtype)
+        rc = self.lib.psalm_patch_im2col(self._p(img), self._p(out), _dt(out), B, Cin, H, W, ps, Kpad, self._stream())
+        self._check(rc, "psalm_patch_im2col")
+        return out
+
+    def im2col_nhwc(self, x, B, H, W, k, stride, pad):
+        C = x.shape[-1]
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = self.empty(B * Ho * Wo, k * k * C, dtype=x.dtype)
+        rc = self.lib.psalm_im2col_nhwc(self._p(x), self._p(out), _dt(x), B, H, W, C, k, stride, pad, self._stream())
+        self._check(rc, "psalm_im2col_nhwc")
+        return out
+
+    def resize_planes(self, x, H, W, crop=None, out_dtype=None):
+        """x (N,h,w) -> bilinear (align_corners=False) -> (N,H,W); optional crop (hc,wc) of the input first."""
+        N, h, w = x.shape
+        hc, wc = crop if crop is not None else (h, w)
+        out = self.empty(N, H, W, dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_resize_planes(self._p(x), _dt(x), self._p(out), _dt(out), c_long(N), h, w, hc, wc, H, W, self._stream())
+        self._check(rc, "psalm_resize_planes")
+        return out
+
+    def upsample_add_nhwc(self, lateral, small, B, h, w, H, W, out_dtype=None):
+        C = lateral.shape[-1]
+        out = self.empty(B * H * W, C, dtype=out_dtype or lateral.dtype)
+        rc = self.lib.psalm_upsample_add_nhwc(self._p(lateral), _dt(lateral), self._p(small), _dt(small), self._p(out), _dt(out), B, h,
+                                              w, H, W, C, self._stream())
+        self._check(rc, "psalm_upsample_add_nhwc")
+        return out
+
+    def region_pool(self, tokens, img_of_region, pts, h, w, n_img):
+        """tokens (B*h*w, C) f32; img_of_region (R,) i32; pts (R,n,2) f32 (y,x) -> (R, C) f32."""
+        R, n = pts.shape[0], pts.shape[1]
+        C = tokens.shape[-1]
+        out = self.empty(R, C, dtype=torch.float32)
+        if tokens.dtype != torch.float32:
+            raise PsalmHipError("region_pool expects fp32 image tokens")
+        rc = self.lib.psalm_region_pool(self._p(tokens), self._p(img_of_region), self._p(pts), self._p(out), R, h, w, C, n,
+                                        self._stream())
+        self._check(rc, "psalm_region_pool")
+        return out
+
+    def permute_layout(self, x, B, C, HW, to_nhwc, out_dtype=None):
+        out = self.empty((B * HW, C) if to_nhwc else (B, C, HW), dtype=out_dtype or x.dtype)
+        rc = self.lib.psalm_permute_layout(self._p(x), _dt(x), self._p(out), _dt(out), B, C, c_long(HW), int(to_nhwc), self._stream())
+        self._check(rc, "psalm_permute_layout")
+        return out
 
     # ------------------------------------------------------------------ MSDA
     def msda_forward(self, value, spatial_shapes: Sequence[Sequence[int]], level_start: Sequence[int], loc, attw,

@@ -1,0 +1,613 @@
+"""PSALM segmentation inference (`eval_seg`) on hand-written gfx950 kernels.
+
+Host-side mirror of the reference's model API for this path:
+    psalm/model/language_model/llava_phi.py:146-1472  (class PSALM: eval_seg and everything it calls)
+Same call signature and result dicts as `PSALM.eval_seg` (LP:1317-1336 -> LP:1424-1466), same checkpoint layout
+(`state_dict` names of the reference, see psalm_amd/synthetic.py), but every tensor operation is a kernel from
+libpsalm_hip.so called through psalm_amd.hip_ops (ctypes; torch = device memory + stream only).  There is no
+torch / CPU fallback: without the HIP library and a GPU, construction raises.
+
+Precision modes
+    "bf16": weights bf16, GEMMs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; GEMM-feeding activations bf16;
+            residual streams, LayerNorm/GroupNorm/softmax statistics, sampling offsets, mask and class logits fp32.
+    "fp32": weights and activations fp32, GEMMs on the exact fp32 MFMA -- structural parity mode against the fp32
+            CPU reference (differences are summation-order round-off only).
+
+Layout: activations are token-major (rows = pixels/tokens, cols = channels; NHWC for feature maps), so 1x1
+convolutions are GEMMs, 3x3 / strided convolutions are im2col + GEMM, and LayerNorm/softmax rows are contiguous.
+
+Deliberate, value-preserving departures from the reference's control flow (SURVEY.md §7 "quirks"):
+  * the Swin tower runs once per image, not twice (LP:787 and LP:1369 feed it the same pixels);
+  * every image of the batch is post-processed (LP:1472 returns inside the loop after image 0);
+  * the prediction heads' class/SEG/region logits are evaluated only after the last decoder layer (the nine
+    earlier evaluations are auxiliary training outputs, TD:672-690); the mask logits are needed every layer
+    because they define the next layer's attention mask;
+  * BatchNorm (eval) is folded into the projector convolutions; q/k/v/fc1 and dense/fc2 of each Phi layer are fused
+    into two GEMMs (the parallel-residual layer makes attention and MLP share their input and their sum).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip_ops as H
+from .config import (CLS_TOKEN_INDEX, IMAGE_TOKEN_INDEX, REFER_TOKEN_INDEX, REGION_TOKEN_INDEX, SEG_TOKEN_INDEX,
+                     PsalmConfig)
+
+
+class Instances:
+    """Result container with the attribute surface the reference's evaluators read from detectron2 `Instances`
+    (LP:317-323, LP:435-447): image_size, pred_masks, scores, pred_classes, pred_boxes."""
+
+    def __init__(self, image_size, **fields):
+        self.image_size = tuple(image_size)
+        self._fields = dict(fields)
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def has(self, name):
+        return name in self._fields
+
+    def get_fields(self):
+        return self._fields
+
+    def to(self, device):
+        return Instances(self.image_size, **{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self._fields.items()})
+
+    def __len__(self):
+        return int(self.pred_masks.shape[0])
+
+
+def default_region_point_sampler(nonzero: torch.Tensor, n: int) -> torch.Tensor:
+    """Row indices into `nonzero` (context_cluster.py:31-40 rand_sample_repeat; global torch CPU RNG, same call order)."""
+    m = nonzero.shape[0]
+    if m < n:
+        return torch.cat((torch.arange(m), torch.randint(0, m, (n - m,))))
+    if m == n:
+        return torch.arange(m)
+    return torch.randperm(m)[:n]
+
+
+class PSALM:
+    def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
+                 precision: str = "bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.cfg = cfg
+        self.ops = ops if ops is not None else H.get_ops()        # raises without GPU + libpsalm_hip.so
+        self.precision = precision
+        self.wdt = torch.bfloat16 if precision == "bf16" else torch.float32   # weight / GEMM-operand dtype
+        self.adt = self.wdt                                                     # GEMM-feeding activation dtype
+        self.device = self.ops.device
+        self.seg_task = cfg.seg_task
+        self.is_thing_list = None
+        self._cache: Dict = {}
+        self.w: Dict[str, torch.Tensor] = {}
+        self._prepare_weights(state_dict)
+
+    # ======================================================================================= weights
+    def _W(self, t):                      # GEMM weight
+        return t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device)
+
+    def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
+        return t.detach().to(torch.float32).contiguous().to(self.device)
+
+    def _prepare_weights(self, sd):
+        cfg, w = self.cfg, self.w
+        W, Fp = self._W, self._F
+
+        def lin(dst, src, bias=True):
+            w[dst + ".w"] = W(sd[src + ".weight"])
+            if bias and (src + ".bias") in sd:
+                w[dst + ".b"] = Fp(sd[src + ".bias"])
+
+        def norm(dst, src):
+            w[dst + ".g"] = Fp(sd[src + ".weight"])
+            w[dst + ".b"] = Fp(sd[src + ".bias"])
+
+        # ---- Phi decoder.  Fused GEMM 1 rows: [k | v | q | fc1]  (attention output later overwrites the q columns, so
+        # [attn | gelu(fc1)] is one contiguous K panel for fused GEMM 2 = [dense | fc2] with the two biases summed).
+        w["embed"] = Fp(sd["model.embed_tokens.weight"]) if self.precision == "fp32" else \
+            sd["model.embed_tokens.weight"].detach().to(torch.bfloat16).to(self.device)
+        w["seg_query"] = Fp(sd["seg_query"])
+        for i in range(cfg.num_layers):
+            p = f"model.layers.{i}."
+            a = p + "self_attn."
+            w[f"llm{i}.w1"] = W(torch.cat([sd[a + "k_proj.weight"], sd[a + "v_proj.weight"], sd[a + "q_proj.weight"],
+                                           sd[p + "mlp.fc1.weight"]], 0))
+            w[f"llm{i}.b1"] = Fp(torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"],
+                                            sd[p + "mlp.fc1.bias"]], 0))
+            w[f"llm{i}.w2"] = W(torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1))
+            w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"] + sd[p + "mlp.fc2.bias"])
+            norm(f"llm{i}.ln", p + "input_layernorm")
+        norm("llm.final", "model.final_layernorm")
+
+        # ---- Swin
+        vt = "model.vision_tower."
+        E, ps = cfg.swin_embed_dim, cfg.swin_patch
+        pe = sd[vt + "patch_embed.proj.weight"].reshape(E, -1)                 # (E, 3*ps*ps), K order (c,ky,kx)
+        self.pe_kpad = (pe.shape[1] + 7) // 8 * 8
+        w["swin.pe.w"] = W(torch.nn.functional.pad(pe, (0, self.pe_kpad - pe.shape[1])))
+        w["swin.pe.b"] = Fp(sd[vt + "patch_embed.proj.bias"])
+        norm("swin.pe.ln", vt + "patch_embed.norm")
+        for s, depth in enumerate(cfg.swin_depths):
+            for b in range(depth):
+                p, q = f"{vt}layers.{s}.blocks.{b}.", f"swin{s}.{b}."
+                norm(q + "n1", p + "norm1")
+                norm(q + "n2", p + "norm2")
+                lin(q + "qkv", p + "attn.qkv")
+                lin(q + "proj", p + "attn.proj")
+                lin(q + "fc1", p + "mlp.fc1")
+                lin(q + "fc2", p + "mlp.fc2")
+                w[q + "rpb"] = Fp(sd[p + "attn.relative_position_bias_table"])
+            if s < len(cfg.swin_depths) - 1:
+                norm(f"swin{s}.ds.ln", f"{vt}layers.{s}.downsample.norm")
+                lin(f"swin{s}.ds.red", f"{vt}layers.{s}.downsample.reduction", bias=False)
+            norm(f"swin.out{s}", f"{vt}norm{s}")
+
+        # ---- projector (BasicBlock with eval BatchNorm folded; conv weights to (Cout, ky, kx, Cin))
+        pj = "model.mm_projector.layer1.0."
+
+        def bn_fold(conv_w, bn):
+            scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+            shift = sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale
+            return conv_w * scale.view(-1, 1, 1, 1), shift
+
+        def conv_mat(cw):
+            return cw.permute(0, 2, 3, 1).reshape(cw.shape[0], -1)
+        c1, b1 = bn_fold(sd[pj + "conv1.weight"], pj + "bn1")
+        w["proj.c1.w"], w["proj.c1.b"] = W(conv_mat(c1)), Fp(b1)
+        w["proj.c2.w"] = W(conv_mat(sd[pj + "conv2.weight"]))
+        c2, b2 = bn_fold(sd[pj + "conv2.weight"], pj + "bn2")
+        w["proj.c2f.w"], w["proj.c2f.b"] = W(conv_mat(c2)), Fp(b2)
+        cd, bd = bn_fold(sd[pj + "downsample.0.weight"], pj + "downsample.1")
+        w["proj.ds.w"], w["proj.ds.b"] = W(conv_mat(cd)), Fp(bd)
+        lin("proj.fc", "model.mm_projector.fc")
+
+        # ---- LLM -> decoder projectors
+        for n in ("seg_query_projector", "SEG_token_projector", "class_name_projector", "region_projector"):
+            lin(n, n)
+
+        # ---- pixel decoder
+        pd = "pixel_decoder."
+        for i in range(3):
+            w[f"pd.ip{i}.w"] = W(sd[f"{pd}input_proj.{i}.0.weight"].flatten(1))
+            w[f"pd.ip{i}.b"] = Fp(sd[f"{pd}input_proj.{i}.0.bias"])
+            norm(f"pd.ip{i}.gn", f"{pd}input_proj.{i}.1")
+        w["pd.level_embed"] = Fp(sd[pd + "transformer.level_embed"])
+        for i in range(cfg.md_enc_layers):
+            p, q = f"{pd}transformer.encoder.layers.{i}.", f"pd.enc{i}."
+            w[q + "ow.w"] = W(torch.cat([sd[p + "self_attn.sampling_offsets.weight"], sd[p + "self_attn.attention_weights.weight"]], 0))
+            w[q + "ow.b"] = Fp(torch.cat([sd[p + "self_attn.sampling_offsets.bias"], sd[p + "self_attn.attention_weights.bias"]], 0))
+            lin(q + "value", p + "self_attn.value_proj")
+            lin(q + "out", p + "self_attn.output_proj")
+            norm(q + "n1", p + "norm1")
+            lin(q + "l1", p + "linear1")
+            lin(q + "l2", p + "linear2")
+            norm(q + "n2", p + "norm2")
+        w["pd.adapter.w"] = W(sd[pd + "adapter_1.0.weight"].flatten(1))
+        w["pd.adapter.b"] = Fp(sd[pd + "adapter_1.0.bias"])
+        norm("pd.adapter.gn", pd + "adapter_1.1")
+        w["pd.layer.w"] = W(conv_mat(sd[pd + "layer_1.0.weight"]))
+        w["pd.layer.b"] = Fp(sd[pd + "layer_1.0.bias"])
+        norm("pd.layer.gn", pd + "layer_1.1")
+        w["pd.mf.w"] = W(sd[pd + "mask_features.weight"].flatten(1))
+        w["pd.mf.b"] = Fp(sd[pd + "mask_features.bias"])
+
+        # ---- predictor
+        pr = "predictor."
+        D = cfg.md_hidden
+        nl, nlev = cfg.md_dec_layers, cfg.md_levels
+        for i in range(nl):
+            c = f"{pr}transformer_cross_attention_layers.{i}."
+            Wi, bi = sd[c + "multihead_attn.in_proj_weight"], sd[c + "multihead_attn.in_proj_bias"]
+            w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"] = W(Wi[:D]), Fp(bi[:D])
+            lin(f"pr{i}.co", c + "multihead_attn.out_proj")
+            norm(f"pr{i}.cn", c + "norm")
+            s_ = f"{pr}transformer_self_attention_layers.{i}."
+            Ws, bs = sd[s_ + "self_attn.in_proj_weight"], sd[s_ + "self_attn.in_proj_bias"]
+            w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"] = W(Ws[:2 * D]), Fp(bs[:2 * D])
+            w[f"pr{i}.sv.w"], w[f"pr{i}.sv.b"] = W(Ws[2 * D:]), Fp(bs[2 * D:])
+            lin(f"pr{i}.so", s_ + "self_attn.out_proj")
+            norm(f"pr{i}.sn", s_ + "norm")
+            f_ = f"{pr}transformer_ffn_layers.{i}."
+            lin(f"pr{i}.f1", f_ + "linear1")
+            lin(f"pr{i}.f2", f_ + "linear2")
+            norm(f"pr{i}.fn", f_ + "norm")
+        # cross-attention K / V projections of all layers that read level l, stacked: one GEMM per level
+        for l in range(nlev):
+            layers = [i for i in range(nl) if i % nlev == l]
+            ks, vs, kb, vb = [], [], [], []
+            for i in layers:
+                c = f"{pr}transformer_cross_attention_layers.{i}."
+                Wi, bi = sd[c + "multihead_attn.in_proj_weight"], sd[c + "multihead_attn.in_proj_bias"]
+                ks.append(Wi[D:2 * D]); kb.append(bi[D:2 * D]); vs.append(Wi[2 * D:]); vb.append(bi[2 * D:])
+            w[f"pr.lvl{l}.k.w"], w[f"pr.lvl{l}.k.b"] = W(torch.cat(ks, 0)), Fp(torch.cat(kb, 0))
+            w[f"pr.lvl{l}.v.w"], w[f"pr.lvl{l}.v.b"] = W(torch.cat(vs, 0)), Fp(torch.cat(vb, 0))
+        norm("pr.dn", pr + "decoder_norm")
+        w["pr.query_embed"] = Fp(sd[pr + "query_embed.weight"])
+        w["pr.level_embed"] = Fp(sd[pr + "level_embed.weight"])
+        for name, n in (("mask_embed", 3), ("SEG_proj", 2), ("CLASS_proj", 2), ("REGION_proj", 2)):
+            for j in range(n):
+                lin(f"pr.{name}{j}", f"{pr}{name}.layers.{j}")
+
+    # ======================================================================================= small host tables
+    def _pos_embed(self, Hh, Ww):
+        """PositionEmbeddingSine(normalize=True) as an (H*W, D) fp32 token table (position_encoding.py:29-52).
+        Input-independent, so computed once per resolution on the host with the reference's formula."""
+        key = ("pos", Hh, Ww)
+        if key not in self._cache:
+            npf = self.cfg.md_hidden // 2
+            y = torch.arange(1, Hh + 1, dtype=torch.float32)[:, None].expand(Hh, Ww)
+            x = torch.arange(1, Ww + 1, dtype=torch.float32)[None, :].expand(Hh, Ww)
+            eps, scale = 1e-6, 2 * math.pi
+            y = y / (y[-1:, :] + eps) * scale
+            x = x / (x[:, -1:] + eps) * scale
+            dim_t = torch.arange(npf, dtype=torch.float32)
+            dim_t = 10000.0 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+            px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+            px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+            py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+            self._cache[key] = torch.cat((py, px), dim=2).reshape(Hh * Ww, 2 * npf).contiguous().to(self.device)
+        return self._cache[key]
+
+    def _rope(self, L):
+        """cos/sin (L, rot) fp32, computed as modeling_phi.py:75-88 does (emb = cat(freqs, freqs))."""
+        key = ("rope", L)
+        if key not in self._cache:
+            rd = self.cfg.rotary_dim
+            inv = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, rd, 2, dtype=torch.float32) / rd))
+            fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+            emb = torch.cat((fr, fr), -1)
+            self._cache[key] = (emb.cos().contiguous().to(self.device), emb.sin().contiguous().to(self.device))
+        return self._cache[key]
+
+    # ======================================================================================= Swin + projector
+    def swin(self, images):
+        """swin_trans.py:608-633.  images (B,3,H,W) fp32 on device -> [(tokens (B*h*w, C) adt, h, w)] x 4 (post norm_i)."""
+        o, w, cfg = self.ops, self.w, self.cfg
+        B, _, Hi, Wi = images.shape
+        ps, ws = cfg.swin_patch, cfg.swin_window
+        cols = o.patch_im2col(images, ps, self.pe_kpad, out_dtype=torch.float32)
+        Hc, Wc = (Hi + ps - 1) // ps, (Wi + ps - 1) // ps
+        x = o.gemm(cols, w["swin.pe.w"], w["swin.pe.b"], out_dtype=torch.float32)
+        x = o.layernorm(x, w["swin.pe.ln.g"], w["swin.pe.ln.b"])
+        outs = []
+        for s, (depth, heads) in enumerate(zip(cfg.swin_depths, cfg.swin_heads)):
+            nWh, nWw = (Hc + ws - 1) // ws, (Wc + ws - 1) // ws
+            for b in range(depth):
+                q = f"swin{s}.{b}."
+                shift = 0 if b % 2 == 0 else ws // 2
+                xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
+                qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
+                aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
+                pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)
+                x = o.swin_window_merge(pw, x, B, Hc, Wc, ws, shift)
+                h = o.layernorm(x, w[q + "n2.g"], w[q + "n2.b"], out_dtype=self.adt)
+                h = o.gemm(h, w[q + "fc1.w"], w[q + "fc1.b"], act=H.ACT_GELU, out_dtype=self.adt)
+                x = o.gemm(h, w[q + "fc2.w"], w[q + "fc2.b"], residual=x, out_dtype=torch.float32)
+            outs.append((o.layernorm(x, w[f"swin.out{s}.g"], w[f"swin.out{s}.b"], out_dtype=self.adt), Hc, Wc))
+            if s < len(cfg.swin_depths) - 1:
+                xm = o.patch_merge_ln(x, w[f"swin{s}.ds.ln.g"], w[f"swin{s}.ds.ln.b"], B, Hc, Wc, out_dtype=self.adt)
+                x = o.gemm(xm, w[f"swin{s}.ds.red.w"], out_dtype=torch.float32)
+                Hc, Wc = (Hc + 1) // 2, (Wc + 1) // 2
+        return outs
+
+    def projector(self, res5, B, h, w_):
+        """multimodal_projector/builder.py:365-375 (+ BasicBlock :85-111, conv2 applied twice). -> (B*n, hidden) fp32."""
+        o, w = self.ops, self.w
+        c1 = o.im2col_nhwc(res5, B, h, w_, 3, 2, 1)
+        y = o.gemm(c1, w["proj.c1.w"], w["proj.c1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+        ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+        y = o.gemm(o.im2col_nhwc(y, B, ho, wo, 3, 1, 1), w["proj.c2.w"], out_dtype=self.adt)
+        ds = o.gemm(o.im2col_nhwc(res5, B, h, w_, 1, 2, 0), w["proj.ds.w"], w["proj.ds.b"], out_dtype=self.adt)
+        y = o.gemm(o.im2col_nhwc(y, B, ho, wo, 3, 1, 1), w["proj.c2f.w"], w["proj.c2f.b"], residual=ds,
+                   act=H.ACT_RELU | H.ACT_POST_RESIDUAL, out_dtype=self.adt)
+        return o.gemm(y, w["proj.fc.w"], w["proj.fc.b"], out_dtype=torch.float32), ho * wo
+
+    # ======================================================================================= token splicing (host ints)
+    def _splice_plan(self, input_ids, attention_mask, n_img, class_name_ids, cls_indices, token_refer_id, n_regions,
+                     want_cls, want_refer):
+        """llava_phi.py:767-971 on host integers: where every row of inputs_embeds comes from, plus the row sets used
+        after the LLM (seg queries LP:1299-1316, class-name groups LP:552-565, refer span LP:972-978, regions LP:302-307).
+        source ids: 0 = embed_tokens row, 1 = image token, 2 = seg_query row, 3 = region feature row."""
+        ids_all = input_ids.tolist()
+        am_all = attention_mask.to(torch.bool).tolist()
+        B, T = len(ids_all), len(ids_all[0])
+        NQ = self.cfg.md_queries
+        per = []
+        reg_base = 0
+        for b in range(B):
+            sid: List[int] = []
+            srow: List[int] = []
+            seg_rows: List[int] = []
+            cls_groups: List[List[int]] = []
+            refer_rows: List[int] = []
+            region_rows: List[int] = []
+            class_tok = None
+            if class_name_ids is not None:
+                ci = cls_indices[b].tolist()
+                cn = class_name_ids[b].tolist()
+                class_tok = []
+                prev = None
+                for idx, tok in zip(ci, cn):                    # unique_consecutive groups with idx >= 0 (LP:566-574)
+                    if idx < 0:
+                        prev = None
+                        continue
+                    if idx != prev:
+                        class_tok.append([])
+                        prev = idx
+                    class_tok[-1].append(tok)
+            refer_tok = token_refer_id[b].tolist() if token_refer_id is not None else None
+            cls_i = reg_i = 0
+            for t in ids_all[b]:
+                pos = len(sid)
+                if t >= 0:
+                    sid.append(0); srow.append(t)
+                elif t == IMAGE_TOKEN_INDEX:
+                    sid += [1] * n_img; srow += list(range(b * n_img, (b + 1) * n_img))
+                elif t == SEG_TOKEN_INDEX:
+                    sid += [2] * NQ; srow += list(range(NQ)); seg_rows += list(range(pos, pos + NQ))
+                elif t == CLS_TOKEN_INDEX:
+                    toks = class_tok[cls_i]
+                    cls_i += 1
+                    sid += [0] * len(toks); srow += toks; cls_groups.append(list(range(pos, pos + len(toks))))
+                elif t == REGION_TOKEN_INDEX:
+                    sid.append(3); srow.append(reg_base + reg_i); region_rows.append(pos)
+                    reg_i += 1
+                elif t == REFER_TOKEN_INDEX:
+                    sid += [0] * len(refer_tok); srow += refer_tok; refer_rows += list(range(pos, pos + len(refer_tok)))
+                else:
+                    raise ValueError(f"unknown sentinel token id {t}")
+            if n_regions is not None:
+                assert reg_i == n_regions[b], "the number of <region> tokens and regions needs to be same"   # LP:592-594
+                reg_base += n_regions[b]
+            if class_tok is not None:
+                assert cls_i == len(class_tok), "the number of <cls> tokens and class_embed needs to be same"  # LP:590-591
+            per.append((sid, srow, seg_rows, cls_groups, refer_rows, region_rows))
+        lens = [len(p[0]) for p in per]
+        L = max(lens)
+        sid = np.full((B, L), -1, np.int32)
+        srow = np.zeros((B, L), np.int32)
+        kmask = np.zeros((B, L), np.uint8)
+        for b, p in enumerate(per):
+            Lb = lens[b]
+            sid[b, :Lb] = p[0]
+            srow[b, :Lb] = p[1]
+            kmask[b, : Lb - T] = 1                                # LP:939-946 / LP:965-968
+            kmask[b, Lb - T: Lb] = am_all[b]
+        plan = {"L": L, "lens": lens, "sid": sid, "srow": srow, "kmask": kmask}
+        # row sets as CSR over rows of the flattened (B*L, H) hidden-state matrix
+        def csr(groups_per_b):
+            off, rows = [0], []
+            for b, groups in enumerate(groups_per_b):
+                for gr in groups:
+                    rows += [b * L + r for r in gr]
+                    off.append(len(rows))
+            return np.asarray(off, np.int32), np.asarray(rows, np.int32)
+        plan["seg"] = csr([[[r] for r in p[2]] for p in per])
+        plan["cls"] = csr([p[3] for p in per]) if want_cls else None
+        plan["n_cls"] = [len(p[3]) for p in per]
+        plan["refer"] = csr([[p[4]] for p in per]) if want_refer else None
+        plan["region"] = csr([[[r] for r in p[5]] for p in per]) if n_regions is not None else None
+        return plan
+
+    def _dev_i32(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    # ======================================================================================= region pooling
+    def region_points(self, region_masks_list, sampler):
+        """context_cluster.py:345-356: per region mask, nonzero()/[H,W] then random repeat/subsample to n points.
+        Host side (RNG + tiny index work); returns (total_regions, n, 2) fp32 (y,x) in [0,1) and regions per image."""
+        pts, counts = [], []
+        n = self.cfg.region_points
+        for masks in region_masks_list:
+            masks = masks.cpu()
+            counts.append(int(masks.shape[0]))
+            for m in masks:
+                nz = m.nonzero()
+                wh = torch.tensor([m.shape[0], m.shape[1]])[None]
+                pts.append((nz / wh)[sampler(nz, n)].float())
+        return (torch.stack(pts) if pts else torch.zeros(0, n, 2)), counts
+
+    # ======================================================================================= Phi decoder
+    def llm(self, embeds, key_mask, B, L):
+        """PhiModel.forward (modeling_phi.py:343-396) on inputs_embeds (B*L, hidden) fp32; key_mask (B,L) u8."""
+        o, w, cfg = self.ops, self.w, self.cfg
+        Hd, I = cfg.hidden_size, cfg.intermediate_size
+        cos, sin = self._rope(L)
+        x = embeds
+        big = o.empty(B * L, 3 * Hd + I, dtype=self.adt)
+        for i in range(cfg.num_layers):
+            h = o.layernorm(x, w[f"llm{i}.ln.g"], w[f"llm{i}.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
+            o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
+            # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place
+            o.causal_attention(big, 2 * Hd, 0, Hd, big, 2 * Hd, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
+                               cfg.rotary_dim)
+            x = o.gemm(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+        return o.layernorm(x, w["llm.final.g"], w["llm.final.b"], cfg.layer_norm_eps, out_dtype=torch.float32)
+
+    # ======================================================================================= pixel decoder (one image)
+    def pixel_decoder(self, feats):
+        """msdeformattn.py:268-315 for ONE image.  feats = [(tokens (h*w, C), h, w)] res2..res5.
+        Returns mask_features (H2*W2, mask_dim) in the GEMM-weight dtype, [level tokens (h*w, D) fp32] x 3, sizes."""
+        o, w, cfg = self.ops, self.w, self.cfg
+        D, G, M = cfg.md_hidden, cfg.md_gn_groups, cfg.md_heads
+        levels = [feats[3], feats[2], feats[1]]
+        shapes = [(h, w_) for _, h, w_ in levels]
+        starts = [0]
+        for h, w_ in shapes[:-1]:
+            starts.append(starts[-1] + h * w_)
+        S = starts[-1] + shapes[-1][0] * shapes[-1][1]
+        src = o.empty(S, D, dtype=torch.float32)
+        for i, (tok, h, w_) in enumerate(levels):
+            t = o.gemm(tok, w[f"pd.ip{i}.w"], w[f"pd.ip{i}.b"], out_dtype=self.adt)
+            # GroupNorm writes straight into this level's rows of the level-concatenated token buffer
+            o.groupnorm_nhwc(t, w[f"pd.ip{i}.gn.g"], w[f"pd.ip{i}.gn.b"], 1, h * w_, G, out=src[starts[i]: starts[i] + h * w_])
+        key = ("lvlpos", tuple(shapes))
+        if key not in self._cache:
+            self._cache[key] = torch.cat([self._pos_embed(h, w_) + w["pd.level_embed"][l][None] for l, (h, w_) in enumerate(shapes)], 0).contiguous()
+        lvl_pos = self._cache[key]
+        for i in range(cfg.md_enc_layers):
+            q_ = f"pd.enc{i}."
+            qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
+            value = o.gemm(src, w[q_ + "value.w"], w[q_ + "value.b"], out_dtype=self.adt)
+            ow = o.gemm(qin, w[q_ + "ow.w"], w[q_ + "ow.b"], out_dtype=torch.float32)
+            att = o.msda_fused(value.view(1, S, D), shapes, starts, ow.view(1, S, -1), M, out_dtype=self.adt).view(S, D)
+            src = o.layernorm(o.gemm(att, w[q_ + "out.w"], w[q_ + "out.b"], residual=src, out_dtype=torch.float32),
+                              w[q_ + "n1.g"], w[q_ + "n1.b"])
+            hdd = o.gemm(src, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+            src = o.layernorm(o.gemm(hdd, w[q_ + "l2.w"], w[q_ + "l2.b"], residual=src, out_dtype=torch.float32),
+                              w[q_ + "n2.g"], w[q_ + "n2.b"])
+        ms = [src[starts[l]: starts[l] + h * w_] for l, (h, w_) in enumerate(shapes)]
+        tok2, H2, W2 = feats[0]
+        lat = o.gemm(tok2, w["pd.adapter.w"], w["pd.adapter.b"], out_dtype=self.adt)
+        lat = o.groupnorm_nhwc(lat, w["pd.adapter.gn.g"], w["pd.adapter.gn.b"], 1, H2 * W2, G, relu=True, out_dtype=torch.float32)
+        hs, ws_ = shapes[-1]
+        y = o.upsample_add_nhwc(lat, ms[-1], 1, hs, ws_, H2, W2, out_dtype=self.adt)
+        y = o.gemm(o.im2col_nhwc(y, 1, H2, W2, 3, 1, 1), w["pd.layer.w"], w["pd.layer.b"], out_dtype=self.adt)
+        y = o.groupnorm_nhwc(y, w["pd.layer.gn.g"], w["pd.layer.gn.b"], 1, H2 * W2, G, relu=True, out_dtype=self.adt)
+        mf = o.gemm(y, w["pd.mf.w"], w["pd.mf.b"], out_dtype=self.wdt)
+        return mf, ms, shapes, (H2, W2)
+
+    # ======================================================================================= predictor (one image)
+    def predictor(self, ms, shapes, mf, mf_size, seg_query, SEG_emb=None, class_emb=None, region_emb=None):
+        """mask2former_transformer_decoder.py:596-693 (+ heads :695-762) for ONE image.
+        seg_query (Q, D) fp32; *_emb (n, D) in the GEMM-weight dtype."""
+        o, w, cfg = self.ops, self.w, self.cfg
+        D, nh, Q = cfg.md_hidden, cfg.md_heads, cfg.md_queries
+        nl, nlev = cfg.md_dec_layers, cfg.md_levels
+        H2, W2 = mf_size
+        qe = w["pr.query_embed"]
+        Kl, Vl = [], []
+        for l in range(nlev):
+            h, w_ = shapes[l]
+            key = ("prpos", l, h, w_)
+            if key not in self._cache:
+                self._cache[key] = (self._pos_embed(h, w_) + w["pr.level_embed"][l][None]).contiguous()
+            kin = o.add_bcast(ms[l], self._cache[key], out_dtype=self.adt)
+            vin = o.add_bcast(ms[l], w["pr.level_embed"][l:l + 1], out_dtype=self.adt)
+            Kl.append(o.gemm(kin, w[f"pr.lvl{l}.k.w"], w[f"pr.lvl{l}.k.b"], out_dtype=self.adt))
+            Vl.append(o.gemm(vin, w[f"pr.lvl{l}.v.w"], w[f"pr.lvl{l}.v.b"], out_dtype=self.adt))
+
+        def mlp(x, name, n, out_dtype):
+            for j in range(n):
+                last = j == n - 1
+                x = o.gemm(x, w[f"pr.{name}{j}.w"], w[f"pr.{name}{j}.b"], act=H.ACT_NONE if last else H.ACT_RELU,
+                           out_dtype=out_dtype if last else self.adt)
+            return x
+
+        def mask_head(out):
+            dec = o.layernorm(out, w["pr.dn.g"], w["pr.dn.b"], out_dtype=self.adt)
+            me = mlp(dec, "mask_embed", 3, self.adt)
+            return dec, o.gemm(me, mf, out_dtype=torch.float32)     # (Q, H2*W2) fp32 mask logits
+
+        out = seg_query
+        dec, masks = mask_head(out)
+        for i in range(nl):
+            l = i % nlev
+            h, w_ = shapes[l]
+            amask, flags = o.attn_mask(masks.view(1, Q, H2, W2), h, w_)
+            j = i // nlev
+            qp = o.gemm(o.add_bcast(out, qe, out_dtype=self.adt), w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"], out_dtype=self.adt)
+            a = o.mha_attention(qp, Kl[l][:, j * D:(j + 1) * D], Vl[l][:, j * D:(j + 1) * D], 1, Q, h * w_, nh, amask, flags)
+            out = o.layernorm(o.gemm(a, w[f"pr{i}.co.w"], w[f"pr{i}.co.b"], residual=out, out_dtype=torch.float32),
+                              w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"])
+            qk = o.gemm(o.add_bcast(out, qe, out_dtype=self.adt), w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"], out_dtype=self.adt)
+            v = o.gemm(out, w[f"pr{i}.sv.w"], w[f"pr{i}.sv.b"], out_dtype=self.adt)
+            a = o.mha_attention(qk[:, :D], qk[:, D:], v, 1, Q, Q, nh)
+            out = o.layernorm(o.gemm(a, w[f"pr{i}.so.w"], w[f"pr{i}.so.b"], residual=out, out_dtype=torch.float32),
+                              w[f"pr{i}.sn.g"], w[f"pr{i}.sn.b"])
+            hdd = o.gemm(out, w[f"pr{i}.f1.w"], w[f"pr{i}.f1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+            out = o.layernorm(o.gemm(hdd, w[f"pr{i}.f2.w"], w[f"pr{i}.f2.b"], residual=out, out_dtype=torch.float32),
+                              w[f"pr{i}.fn.g"], w[f"pr{i}.fn.b"])
+            dec, masks = mask_head(out)
+        res = {"pred_masks": masks.view(Q, H2, W2), "pred_class_name_logits": None, "pred_SEG_logits": None,
+               "pred_region_logits": None}
+        if class_emb is not None:
+            res["pred_class_name_logits"] = o.gemm(mlp(dec, "CLASS_proj", 2, self.adt), class_emb, out_dtype=torch.float32)
+        if SEG_emb is not None:
+            res["pred_SEG_logits"] = o.gemm(mlp(dec, "SEG_proj", 2, self.adt), SEG_emb, out_dtype=torch.float32)
+        if region_emb is not None:     # einsum 'kd,ld->kl' (TD:744): (k, Q)
+            res["pred_region_logits"] = o.gemm(region_emb.to(self.adt) if region_emb.dtype != self.adt else region_emb,
+                                               mlp(dec, "REGION_proj", 2, self.wdt), out_dtype=torch.float32)
+        return res
+
+    # ======================================================================================= forward to logits
+    def forward_logits(self, input_ids, attention_mask, images, seg_info=None, class_name_ids=None,
+                       class_name_embedding_indices=None, cls_indices=None, token_refer_id=None,
+                       refer_embedding_indices=None, labels=None, region_point_sampler: Callable = default_region_point_sampler,
+                       stages: Optional[dict] = None):
+        """Everything of eval_seg up to the predictor outputs (LP:1350-1398).  Returns a list (one per image) of
+        dicts with pred_masks (Q,h,w) fp32, pred_class_name_logits (Q,C+1) / pred_SEG_logits (Q,1) / pred_region_logits (k,Q)."""
+        o, w, cfg = self.ops, self.w, self.cfg
+        images = images.to(self.device, torch.float32).contiguous()
+        B = images.shape[0]
+        feats = self.swin(images)
+        res5, h5, w5 = feats[3]
+        img_tok, n_img = self.projector(res5, B, h5, w5)
+        if stages is not None:
+            stages.update(feats=feats, image_tokens=img_tok)
+        # ---- region pooling (LP:791-797)
+        region_feats, n_regions = None, None
+        if bool((input_ids == REGION_TOKEN_INDEX).any()):
+            pts, n_regions = self.region_points([s["instances"].region_masks.tensor for s in seg_info], region_point_sampler)
+            side = int(math.sqrt(n_img))
+            img_of_region = [b for b, k in enumerate(n_regions) for _ in range(k)]
+            region_feats = o.region_pool(img_tok, self._dev_i32(np.asarray(img_of_region, np.int32)),
+                                         pts.to(self.device).contiguous(), side, side, n_img)
+        # ---- splice + LLM
+        plan = self._splice_plan(input_ids, attention_mask, n_img, class_name_ids, cls_indices, token_refer_id, n_regions,
+                                 class_name_embedding_indices is not None, refer_embedding_indices is not None)
+        L = plan["L"]
+        embeds = o.gather_rows([w["embed"], img_tok, w["seg_query"], region_feats], self._dev_i32(plan["sid"].reshape(-1)),
+                               self._dev_i32(plan["srow"].reshape(-1)), cfg.hidden_size, out_dtype=torch.float32)
+        hidden = self.llm(embeds, torch.from_numpy(plan["kmask"]).to(self.device), B, L)
+        if stages is not None:
+            stages.update(inputs_embeds=embeds.view(B, L, -1), hidden_states=hidden.view(B, L, -1), lengths=plan["lens"])
+        # ---- LLM states -> decoder embeddings (LP:1366-1390)
+        Q = cfg.md_queries
+        off, rows = plan["seg"]
+        seg_q = o.gemm(o.segment_mean(hidden, self._dev_i32(off), self._dev_i32(rows)), w["seg_query_projector.w"],
+                       w["seg_query_projector.b"], out_dtype=torch.float32)
+        cls_emb = seg_emb = reg_emb = None
+        if plan["cls"] is not None:
+            off, rows = plan["cls"]
+            cls_emb = o.gemm(o.segment_mean(hidden, self._dev_i32(off), self._dev_i32(rows)), w["class_name_projector.w"],
+                             w["class_name_projector.b"], out_dtype=self.wdt)
+        if plan["refer"] is not None:
+            off, rows = plan["refer"]
+            seg_emb = o.gemm(o.segment_mean(hidden, self._dev_i32(off), self._dev_i32(rows)), w["SEG_token_projector.w"],
+                             w["SEG_token_projector.b"], out_dtype=self.wdt)
+        if plan["region"] is not None:
+            off, rows = plan["region"]
+            reg_emb = o.gemm(o.segment_mean(hidden, self._dev_i32(off), self._dev_i32(rows)), w["region_projector.w"],
+                             w["region_projector.b"], out_dtype=self.adt)
+        if stages is not None:
+            stages.update(seg_query=seg_q.view(B, Q, -1), class_name_embedding=cls_emb, SEG_embedding=seg_emb,
+                          region_embedding=reg_emb)
+        # ---- per image: pixel decoder + predictor
+        outs = []
+        c0 = r0 = 0
+        for b in range(B):
+            fb = []
+            for tok, h, w_ in feats:
+                fb.append((tok[b * h * w_:(b + 1) * h * w_], h, w_))
+            mf, ms, shapes, mf_size = self.pixel_decoder(fb)
+            nc = plan["n_cls"][b]
+            ce = cls_emb[c0:c0 + nc] if cls_emb is not None else None
+            c0 += nc
+            se = seg_emb[b:b + 1] if seg_emb is not None else None
+            re = None
+            if reg_emb is not None:
+                re = reg_emb[r0:r0 + n_regions[b]]
+                r0 += n_regions[b]
+            r = self.predictor(ms, shapes, mf, mf_size, seg_q[b * Q:(b + 1) * Q], se, ce, re)
+            if stages is not None:
+                stages.setdefault("mask_features", []).append(mf)
+                stages.setdefault("multi_scale_features", []).append(ms)
+            outs.append(r)
+        return outs

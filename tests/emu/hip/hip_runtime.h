@@ -18,6 +18,7 @@
 #pragma once
 #include <ucontext.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -188,6 +189,8 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, F fn) {
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
 
+using std::max;
+using std::min;
 inline void __syncthreads() { emu::syncthreads(); }
 
 template <class T>

@@ -1,0 +1,64 @@
+"""GEMM kernels (bf16 MFMA and exact-fp32 MFMA) vs a float64 torch matmul of the same (rounded) operands."""
+import pytest
+import torch
+
+from ops_backend import ops  # noqa: F401
+from psalm_amd import hip_ops as H
+
+
+def _ref(a, w, bias, res, act, act_col_start):
+    y = a.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if act:
+        f = {H.ACT_RELU: torch.relu, H.ACT_GELU: torch.nn.functional.gelu,
+             H.ACT_GELU_NEW: lambda v: torch.nn.functional.gelu(v, approximate="tanh")}[act]
+        y = torch.cat([y[:, :act_col_start], f(y[:, act_col_start:])], 1)
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+CASES = [
+    # M, N, K, a_dtype, w_dtype, c_dtype, bias, res, act, act_col_start
+    (128, 128, 64, "f32", "bf16", "f32", True, True, H.ACT_NONE, 0),
+    (100, 200, 48, "bf16", "bf16", "bf16", True, False, H.ACT_GELU, 0),
+    (130, 300, 96, "f32", "bf16", "bf16", False, False, H.ACT_GELU_NEW, 128),
+    (257, 130, 40, "bf16", "bf16", "f32", True, True, H.ACT_RELU, 0),
+    (64, 136, 32, "f32", "f32", "f32", True, True, H.ACT_GELU, 0),
+    (150, 129, 24, "f32", "f32", "f32", False, False, H.ACT_NONE, 0),
+    (1, 8, 8, "f32", "f32", "bf16", True, False, H.ACT_RELU, 0),
+]
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+@pytest.mark.parametrize("M,N,K,ad,wd,cd,has_bias,has_res,act,acs", CASES)
+def test_gemm(ops, M, N, K, ad, wd, cd, has_bias, has_res, act, acs):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    # asymmetric operands (a transposed-output or swapped-fragment bug cannot hide)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).to(DT[ad])
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).to(DT[wd])
+    bias = torch.randn(N, generator=g) if has_bias else None
+    res = torch.randn(M, N, generator=g).to(DT[cd]) if has_res else None
+    a_eff = a.float().bfloat16().float() if wd == "bf16" else a.float()       # bf16 mode rounds A to bf16 when staging
+    want = _ref(a_eff, w.float(), bias, res.float() if has_res else None, act, acs)
+    d = ops.device
+    got = ops.gemm(a.to(d), w.to(d), bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, acs,
+                   out_dtype=DT[cd]).cpu().double()
+    scale = want.abs().max().item()
+    tol = (2 ** -8 if cd == "bf16" else 2e-6) * scale + 1e-6
+    err = (got - want).abs().max().item()
+    assert err <= tol, f"max err {err} > {tol}"
+
+
+def test_gemm_strided_views(ops):
+    """A and C as column slices of wider buffers (how the fused [q|k|v|fc1] / [attn|mlp] buffers are used)."""
+    g = torch.Generator().manual_seed(0)
+    d = ops.device
+    big_a = torch.randn(70, 96, generator=g).to(d)
+    w = torch.randn(40, 32, generator=g).bfloat16().to(d)
+    big_c = torch.zeros(70, 100, device=d)
+    ops.gemm(big_a[:, 64:96], w, out=big_c[:, 8:48])
+    want = big_a[:, 64:96].cpu().bfloat16().double() @ w.cpu().double().t()
+    assert (big_c[:, 8:48].cpu().double() - want).abs().max() < 1e-4
+    assert big_c[:, :8].abs().max() == 0 and big_c[:, 48:].abs().max() == 0

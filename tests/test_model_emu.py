@@ -1,0 +1,53 @@
+"""End-to-end host orchestration (psalm_amd.model.PSALM) on a TINY architecture, kernels running in the host
+emulation, against the CPU oracle on the same seeded weights/inputs.  Validates layouts, weight fusion/folding,
+token splicing and the stage wiring without a GPU.  (The full-size model is checked on the GPU: test_e2e_gpu.py.)"""
+import pytest
+import torch
+
+from ops_backend import make_ops
+from oracle import psalm_oracle as O
+from psalm_amd.config import PsalmConfig
+from psalm_amd.model import PSALM
+from psalm_amd.synthetic import make_inputs, make_state_dict
+
+
+def _rel(a, b):
+    return ((a.float().cpu() - b.float()).abs().max() / b.float().abs().max().clamp(min=1e-6)).item()
+
+
+@pytest.mark.parametrize("task,batch,size", [("panoptic", 1, 96), ("referring", 2, 96), ("region", 2, 96)])
+def test_tiny_forward_logits_fp32(task, batch, size):
+    cfg = PsalmConfig.tiny(task)
+    sd = make_state_dict(cfg, seed=11)
+    inputs = make_inputs(cfg, task, size=size, batch=batch, seed=3, num_classes=9)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
+    torch.manual_seed(77)
+    _, st = O.eval_seg(sd, cfg, return_stages=True, postprocess=False, **inputs)
+    torch.manual_seed(77)
+    stages = {}
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    outs = model.forward_logits(stages=stages, **kw)
+    B = batch
+    for i, name in enumerate(("res2", "res3", "res4", "res5")):
+        tok, h, w = stages["feats"][i]
+        want = st[name].permute(0, 2, 3, 1).reshape(-1, st[name].shape[1])
+        assert _rel(tok, want) < 2e-4, name
+    assert _rel(stages["image_tokens"].view(B, -1, cfg.hidden_size), st["image_tokens"]) < 2e-4
+    assert _rel(stages["inputs_embeds"], st["inputs_embeds"]) < 1e-5
+    for b in range(B):
+        Lb = st["lengths"][b]
+        assert _rel(stages["hidden_states"][b, :Lb], st["hidden_states"][b, :Lb]) < 5e-4
+    assert _rel(stages["seg_query"], st["seg_query"]) < 5e-4
+    for b in range(B):
+        mfw = st["mask_features"][b].permute(1, 2, 0).reshape(-1, cfg.md_mask_dim)
+        assert _rel(stages["mask_features"][b], mfw) < 5e-4
+        for l in range(3):
+            want = st["multi_scale_features"][l][b].permute(1, 2, 0).reshape(-1, cfg.md_hidden)
+            assert _rel(stages["multi_scale_features"][b][l], want) < 5e-4
+        assert _rel(outs[b]["pred_masks"], st["pred_masks"][b]) < 2e-3
+        if task == "panoptic":
+            assert _rel(outs[b]["pred_class_name_logits"], st["pred_class_name_logits"][b]) < 2e-3
+        if task == "referring":
+            assert _rel(outs[b]["pred_SEG_logits"], st["pred_SEG_logits"][b]) < 2e-3
+        if task == "region":
+            assert _rel(outs[b]["pred_region_logits"], st["pred_region_logits"][b]) < 2e-3

@@ -1,0 +1,245 @@
+"""Op-level parity: every HIP kernel vs the same arithmetic written with plain torch fp32/fp64 on CPU
+(the formulas are the reference's, taken from oracle/psalm_oracle.py where one exists).
+Runs on the host emulation of the kernels here and on the real GPU under `-m gpu`."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ops_backend import ops  # noqa: F401
+from oracle import psalm_oracle as O
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    return (3e-5 if dtype == torch.float32 else 2 ** -7) * scale
+
+
+def dev(ops, *ts):
+    return [t.to(ops.device) if t is not None else None for t in ts]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,C", [(5, 128), (9, 200), (3, 2048)])
+def test_layernorm(ops, dtype, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dtype)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    want = F.layer_norm(x.float(), (C,), ga, be, 1e-5)
+    got = ops.layernorm(*dev(ops, x, ga, be)).cpu().float()
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+    # strided output into a wider buffer
+    big = torch.zeros(rows, C + 16, dtype=dtype, device=ops.device)
+    ops.layernorm(*dev(ops, x, ga, be), out=big[:, 8:8 + C])
+    assert (big[:, 8:8 + C].cpu().float() - want).abs().max() <= tol(dtype, want.abs().max())
+    assert big[:, :8].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,C,ws,shift", [(1, 12, 12, 32, 12, 0), (2, 17, 14, 32, 12, 6), (1, 24, 30, 64, 12, 6)])
+def test_swin_window_gather_and_merge(ops, dtype, B, H, W, C, ws, shift):
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H * W, C, generator=g).to(dtype)
+    ga, be = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xn = F.layer_norm(x.float(), (C,), ga, be, 1e-5).view(B, H, W, C)
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    xp = F.pad(xn, (0, 0, 0, pr, 0, pb))
+    Hp, Wp = xp.shape[1], xp.shape[2]
+    if shift:
+        xp = torch.roll(xp, (-shift, -shift), (1, 2))
+    want = O._window_partition(xp, ws).view(-1, C)
+    got = ops.swin_window_gather(*dev(ops, x.view(-1, C), ga, be), B, H, W, ws, shift).cpu().float()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+    # merge: inverse data movement + residual
+    win = torch.randn(want.shape, generator=g).to(dtype)
+    sc = torch.randn(B * H * W, C, generator=g)
+    y = O._window_reverse(win.float().view(-1, ws, ws, C), ws, Hp, Wp)
+    if shift:
+        y = torch.roll(y, (shift, shift), (1, 2))
+    wantm = sc + y[:, :H, :W].reshape(B * H * W, C)
+    gotm = ops.swin_window_merge(*dev(ops, win, sc), B, H, W, ws, shift).cpu()
+    assert (gotm - wantm).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,C", [(1, 8, 8, 32), (2, 7, 5, 64)])
+def test_patch_merge_ln(ops, dtype, B, H, W, C):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype)
+    ga, be = 1 + 0.1 * torch.randn(4 * C, generator=g), 0.1 * torch.randn(4 * C, generator=g)
+    xx = x.float()
+    if H % 2 or W % 2:
+        xx = F.pad(xx, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xx[:, 0::2, 0::2], xx[:, 1::2, 0::2], xx[:, 0::2, 1::2], xx[:, 1::2, 1::2]], -1)
+    want = F.layer_norm(cat.reshape(-1, 4 * C), (4 * C,), ga, be, 1e-5)
+    got = ops.patch_merge_ln(*dev(ops, x.view(-1, C), ga, be), B, H, W).cpu().float()
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,HW,C,G,relu", [(1, 100, 64, 8, False), (2, 150, 256, 32, True)])
+def test_groupnorm(ops, dtype, B, HW, C, G, relu):
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(B, HW, C, generator=g) * 1.5 + 0.3).to(dtype)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    want = F.group_norm(x.float().transpose(1, 2).reshape(B, C, HW, 1), G, ga, be, 1e-5).reshape(B, C, HW).transpose(1, 2)
+    if relu:
+        want = F.relu(want)
+    got = ops.groupnorm_nhwc(*dev(ops, x.reshape(-1, C), ga, be), B, HW, G, relu=relu).cpu().float().view(B, HW, C)
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+
+
+def test_add_gather_segment(ops):
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(12, 40, generator=g)
+    b = torch.randn(4, 40, generator=g)
+    got = ops.add_bcast(*dev(ops, a, b)).cpu()
+    assert torch.equal(got, a + b.repeat(3, 1))
+    t0, t1 = torch.randn(7, 40, generator=g), torch.randn(5, 40, generator=g).bfloat16()
+    sid = torch.tensor([0, 1, -1, 1, 0, 0], dtype=torch.int32)
+    srow = torch.tensor([6, 4, 0, 0, 1, 6], dtype=torch.int32)
+    got = ops.gather_rows(dev(ops, t0, t1), *dev(ops, sid, srow), 40).cpu()
+    want = torch.stack([t0[6], t1[4].float(), torch.zeros(40), t1[0].float(), t0[1], t0[6]])
+    assert torch.equal(got, want)
+    x = torch.randn(20, 40, generator=g)
+    off = torch.tensor([0, 3, 4, 9], dtype=torch.int32)
+    rows = torch.tensor([1, 5, 7, 2, 10, 11, 12, 19, 0], dtype=torch.int32)
+    got = ops.segment_mean(*dev(ops, x, off, rows)).cpu()
+    want = torch.stack([x[[1, 5, 7]].mean(0), x[[2]].mean(0), x[[10, 11, 12, 19, 0]].mean(0)])
+    assert (got - want).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,nWh,nWw,heads,shift", [(1, 1, 1, 2, 0), (1, 2, 3, 1, 6), (2, 2, 2, 2, 6)])
+def test_window_attention(ops, dtype, B, nWh, nWw, heads, shift):
+    ws, hd = 12, 32
+    C = heads * hd
+    N = ws * ws
+    g = torch.Generator().manual_seed(6 + heads)
+    nW = nWh * nWw
+    qkv = (torch.randn(B * nW * N, 3 * C, generator=g) * 0.7).to(dtype)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    from psalm_amd.synthetic import relative_position_index
+    idx = relative_position_index(ws).view(-1)
+    q_, k_, v_ = qkv.float().view(B * nW, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = (q_ * hd ** -0.5) @ k_.transpose(-2, -1) + table[idx].view(N, N, heads).permute(2, 0, 1)[None]
+    if shift:
+        am = O.swin_shift_mask(nWh * ws, nWw * ws, ws, shift)
+        attn = (attn.view(B, nW, heads, N, N) + am[None, :, None]).view(-1, heads, N, N)
+    want = (attn.softmax(-1) @ v_).transpose(1, 2).reshape(B * nW * N, C)
+    got = ops.window_attention(*dev(ops, qkv, table), B, nWh, nWw, heads, ws, shift).cpu().float()
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+
+
+def _rope_tables(L, rot, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat((fr, fr), -1)
+    return emb.cos().contiguous(), emb.sin().contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1)])
+def test_causal_attention(ops, dtype, B, L, heads):
+    hd, rot = 64, 32
+    H = heads * hd
+    g = torch.Generator().manual_seed(7)
+    ld = 3 * H + 16
+    buf = (torch.randn(B * L, ld, generator=g) * 0.8).to(dtype)
+    key_mask = torch.ones(B, L, dtype=torch.uint8)
+    if B > 1:
+        key_mask[1, L - 20:] = 0                                  # right padding of the 2nd sample
+    cos, sin = _rope_tables(L, rot)
+    q = buf[:, 0:H].float().view(B, L, heads, hd).transpose(1, 2)
+    k = buf[:, H + 8:2 * H + 8].float().view(B, L, heads, hd).transpose(1, 2)
+    v = buf[:, 2 * H + 16:3 * H + 16].float().view(B, L, heads, hd).transpose(1, 2)
+
+    def rope(x):
+        xr = x[..., :rot]
+        rh = torch.cat((-xr[..., rot // 2:], xr[..., : rot // 2]), -1)
+        return torch.cat((xr * cos + rh * sin, x[..., rot:]), -1)
+    w = rope(q) @ rope(k).transpose(2, 3) * hd ** -0.5
+    allow = torch.tril(torch.ones(L, L, dtype=torch.bool))[None, None] & key_mask[:, None, None, :].bool()
+    w = w.masked_fill(~allow, torch.finfo(torch.float32).min).softmax(-1)
+    want = (w @ v).transpose(1, 2).reshape(B * L, H)
+    out = torch.zeros(B * L, H + 32, dtype=dtype, device=ops.device)
+    ops.causal_attention(buf.to(ops.device), 0, H + 8, 2 * H + 16, out, 32, *dev(ops, cos, sin, key_mask), B, L, heads, hd, rot)
+    got = out[:, 32:].cpu().float()
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+    assert out[:, :32].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_mha_attention_and_mask(ops, dtype):
+    B, Lq, heads, hd = 2, 10, 2, 32
+    D = heads * hd
+    h = w = 16
+    Ht = Wt = 6
+    Lk = Ht * Wt
+    g = torch.Generator().manual_seed(8)
+    masks = torch.randn(B, Lq, h, w, generator=g)
+    masks[0, 3] = -1.0                                             # an all-masked row -> must attend everywhere (TD:647)
+    am = F.interpolate(masks, size=(Ht, Wt), mode="bilinear", align_corners=False)
+    want_mask = (am.sigmoid().flatten(2) < 0.5)
+    got_mask, flags = ops.attn_mask(masks.to(ops.device), Ht, Wt)
+    assert torch.equal(got_mask.cpu().bool(), want_mask)
+    assert flags.cpu()[0, 3] == 1 and flags.cpu().sum() == want_mask.all(-1).sum()
+    q = torch.randn(B * Lq, D + 8, generator=g).to(dtype)
+    kv = torch.randn(B * Lk, 2 * D, generator=g).to(dtype)
+    qq = q[:, 4:4 + D]
+    kk, vv = kv[:, :D], kv[:, D:]
+    wm = want_mask.clone()
+    wm[wm.all(-1)] = False
+    a = (qq.float().view(B, Lq, heads, hd).transpose(1, 2) * hd ** -0.5) @ kk.float().view(B, Lk, heads, hd).transpose(1, 2).transpose(-2, -1)
+    a = a.masked_fill(wm[:, None], float("-inf")).softmax(-1)
+    want = (a @ vv.float().view(B, Lk, heads, hd).transpose(1, 2)).transpose(1, 2).reshape(B * Lq, D)
+    qd, kvd = q.to(ops.device), kv.to(ops.device)
+    got = ops.mha_attention(qd[:, 4:4 + D], kvd[:, :D], kvd[:, D:], B, Lq, Lk, heads, got_mask, flags).cpu().float()
+    assert (got - want).abs().max() <= tol(dtype, want.abs().max())
+    # unmasked self-attention form
+    a2 = ((qq.float().view(B, Lq, heads, hd).transpose(1, 2) * hd ** -0.5) @ qq.float().view(B, Lq, heads, hd).transpose(1, 2).transpose(-2, -1)).softmax(-1)
+    want2 = (a2 @ qq.float().view(B, Lq, heads, hd).transpose(1, 2)).transpose(1, 2).reshape(B * Lq, D)
+    got2 = ops.mha_attention(qd[:, 4:4 + D], qd[:, 4:4 + D], qd[:, 4:4 + D], B, Lq, Lq, heads).cpu().float()
+    assert (got2 - want2).abs().max() <= tol(dtype, want2.abs().max())
+
+
+def test_im2col_and_convs(ops):
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(2, 3, 18, 13, generator=g)
+    wgt = torch.randn(16, 3, 4, 4, generator=g)
+    cols = ops.patch_im2col(img.to(ops.device), 4, 48).cpu()
+    want = F.conv2d(F.pad(img, (0, 3, 0, 2)), wgt, stride=4)       # pad to multiples of 4 (swin_trans.py:431-434)
+    got = (cols @ wgt.view(16, 48).t()).view(2, 5, 4, 16).permute(0, 3, 1, 2)
+    assert (got - want).abs().max() < 1e-4
+    x = torch.randn(2, 9, 7, 8, generator=g)                       # NHWC
+    for k, s, p in ((3, 1, 1), (3, 2, 1), (1, 2, 0)):
+        w2 = torch.randn(5, 8, k, k, generator=g)
+        cols = ops.im2col_nhwc(x.view(-1, 8).to(ops.device), 2, 9, 7, k, s, p).cpu()
+        want = F.conv2d(x.permute(0, 3, 1, 2), w2, stride=s, padding=p)
+        got = (cols @ w2.permute(0, 2, 3, 1).reshape(5, -1).t()).view(2, want.shape[2], want.shape[3], 5).permute(0, 3, 1, 2)
+        assert (got - want).abs().max() < 1e-4
+
+
+def test_resize_and_layout(ops):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(3, 16, 16, generator=g)
+    for (H, W) in ((64, 64), (5, 7), (16, 16), (33, 20)):
+        want = F.interpolate(x[None], size=(H, W), mode="bilinear", align_corners=False)[0]
+        got = ops.resize_planes(x.to(ops.device), H, W).cpu()
+        assert (got - want).abs().max() < 1e-5
+    want = F.interpolate(x[None, :, :12, :10], size=(20, 24), mode="bilinear", align_corners=False)[0]
+    got = ops.resize_planes(x.to(ops.device), 20, 24, crop=(12, 10)).cpu()
+    assert (got - want).abs().max() < 1e-5
+    small = torch.randn(2, 4, 4, 8, generator=g)
+    lat = torch.randn(2, 8, 8, 8, generator=g)
+    want = lat + F.interpolate(small.permute(0, 3, 1, 2), size=(8, 8), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    got = ops.upsample_add_nhwc(lat.view(-1, 8).to(ops.device), small.view(-1, 8).to(ops.device), 2, 4, 4, 8, 8).cpu().view(2, 8, 8, 8)
+    assert (got - want).abs().max() < 1e-5
+    t = torch.randn(2, 6, 5, generator=g)
+    nhwc = ops.permute_layout(t.to(ops.device), 2, 6, 5, True).cpu()
+    assert torch.equal(nhwc.view(2, 5, 6), t.transpose(1, 2))
+    back = ops.permute_layout(nhwc.to(ops.device), 2, 6, 5, False).cpu()
+    assert torch.equal(back, t)
