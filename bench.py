@@ -1,0 +1,156 @@
+"""Headline benchmark: images/sec of PSALM panoptic inference at 1024x1024 on N MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full `eval_seg` on one synthetic 1024x1024 COCO-panoptic-shaped image per GPU: Swin-B -> projector ->
+24-layer Phi-1.5 over image + 134 class-name groups + 100 seg queries -> MSDeformAttn pixel decoder -> 9-layer masked
+decoder -> semantic / instance / panoptic post-processing at full resolution.  Random-init weights of the reference
+architecture (seeded), bf16 MFMA GEMMs with fp32 accumulation.  Images are independent, so N GPUs = N replicas of the
+weights (one RCCL broadcast at start-up) each processing its own image: weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel family (the bf16 MFMA GEMM) measured with HIP
+events around every launch in extra, instrumented steps after the timed region; `cpu_baseline` is the oracle
+(CPU restatement of the reference, fp32) timed on this host for one image of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.dist import broadcast_weights
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+
+    cfg = PsalmConfig(seg_task="panoptic")
+    sd = make_state_dict(cfg, seed=0)
+    model = PSALM(cfg, sd, precision=args.precision)
+    if world > 1:
+        nbytes, secs = broadcast_weights(model, src=0)          # RCCL over xGMI, one-off
+    inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
+    inputs["images"] = inputs["images"].cuda()                  # inputs resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.eval_seg(**inputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.eval_seg(**inputs)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- instrumented steps (not part of `value`): per-kernel HIP-event timing
+    roof = None
+    if rank == 0:
+        recs = []
+        model.ops.lib.records = recs
+        nprof = 2
+        for _ in range(nprof):
+            model.eval_seg(**inputs)
+        torch.cuda.synchronize()
+        model.ops.lib.records = None
+        agg = {}
+        gemm_flops = gemm_ms = 0.0
+        gemm_n = 0
+        for name, a, e0, e1 in recs:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(name, [0, 0.0])
+            d[0] += 1
+            d[1] += ms
+            if name == "psalm_gemm" and a[4] == 1:            # w_dtype == bf16
+                M, N, K = a[12], a[13], a[14]
+                gemm_flops += 2.0 * M * N * K
+                gemm_ms += ms
+                gemm_n += 1
+        breakdown = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if gemm_ms > 0:
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (psalm_gemm, bf16 weights)", "achieved": round(ach, 1),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": gemm_n / nprof, "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2),
+                    "algorithmic_gflop_per_step": round(gemm_flops / nprof / 1e9, 1)}
+        if args.breakdown:
+            os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
+            with open(args.breakdown, "w") as f:
+                json.dump(breakdown, f, indent=1)
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle, one image of the same workload
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import psalm_oracle as O
+        cores = min(os.cpu_count() or 1, 64)
+        torch.set_num_threads(cores)
+        cin = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
+        t1 = time.perf_counter()
+        want = O.eval_seg(sd, cfg, **cin)
+        tc = time.perf_counter() - t1
+        cpu = {"value": round(1.0 / tc, 4), "unit": "images/s", "cores": cores, "kind": "port",
+               "sample": f"1 image, {args.size}x{args.size} panoptic, full model, fp32, single cold run ({tc:.1f} s)"}
+        g, w_ = out[0], want[0]
+        gm, wm = g["mask_pred"].cpu() > 0, w_["mask_pred"] > 0
+        inter = (gm & wm).flatten(1).sum(1).float()
+        union = (gm | wm).flatten(1).sum(1).float()
+        iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
+        parity = {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
+                  "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
+                  "semantic_argmax_agreement": round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6),
+                  "panoptic_id_agreement": round(float((g["panoptic_seg"][0].cpu() == w_["panoptic_seg"][0]).float().mean()), 6),
+                  "panoptic_segments": [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]}
+
+    if rank == 0:
+        L = None
+        line = {
+            "metric": "images/sec at 1024x1024 COCO-panoptic inference", "value": round(world * args.steps / dt, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
+                                   "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
+                       "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)"},
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

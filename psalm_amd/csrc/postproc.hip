@@ -1,0 +1,323 @@
+// Post-processing of the predictor outputs into the evaluator-facing results
+// (llava_phi.py:1401-1466: semantic LP:402-406, instance LP:407-447, panoptic LP:325-386, referring LP:308-324,
+//  region LP:387-400).  HBM-bound streaming kernels over the (Q, H, W) full-resolution mask logits plus a few
+// single-block kernels for the small sequential pieces (top-k, segment merging).
+#include "common.h"
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ---------------------------------------------------------------- class softmax: probs, transposed/padded probs, max score + label
+// cls (Q, C1) fp32 logits (C1 = classes + void).  One wave per query.
+// probs (Q, C1); probsT (C1-1, Kpad) zero-padded beyond Q (A operand of the semantic GEMM, void column dropped,
+// LP:403); score[q] = max_c softmax, label[q] = argmax_c (first index on ties, like torch.max).
+__global__ void __launch_bounds__(256) class_softmax_kernel(const float* __restrict__ cls, float* __restrict__ probs,
+                                                            float* __restrict__ probsT, float* __restrict__ score,
+                                                            int* __restrict__ label, int Q, int C1, int Kpad) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float* row = cls + (long)q * C1;
+    float mx = -3.0e38f;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < C1; c += 64) {
+        const float v = row[c];
+        if (v > mx) { mx = v; mi = c; }
+    }
+    const float gmx = wave_max(mx);
+    int cand = (mx == gmx) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+    float s = 0.f;
+    for (int c = lane; c < C1; c += 64) s += __expf(row[c] - gmx);
+    const float inv = 1.f / wave_sum(s);
+    for (int c = lane; c < C1; c += 64) {
+        const float p = __expf(row[c] - gmx) * inv;
+        probs[(long)q * C1 + c] = p;
+        if (c < C1 - 1) probsT[(long)c * Kpad + q] = p;
+    }
+    if (lane == 0) { score[q] = inv; label[q] = cand; }     // exp(0) * inv
+}
+
+extern "C" int psalm_class_softmax(const float* cls, float* probs, float* probsT, float* score, int* label, int Q, int C1, int Kpad,
+                                   void* stream) {
+    if (Q == 0) return 0;
+    hipLaunchKernelGGL(class_softmax_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, cls, probs, probsT, score, label,
+                       Q, C1, Kpad);
+    PSALM_LAUNCH_END("psalm_class_softmax");
+}
+
+// ---------------------------------------------------------------- sigT[p, q] = sigmoid(mask[q, p]), zero-padded to Kpad columns
+// (W operand of the semantic GEMM: sem[c, p] = sum_q probs[q, c] * sigmoid(mask[q, p]), LP:402-406)
+template <typename TO>
+__global__ void __launch_bounds__(256) sigmoid_transpose_kernel(const float* __restrict__ mask, TO* __restrict__ out, int Q, long HW,
+                                                                int Kpad) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int q0 = 0; q0 < Kpad; q0 += 64) {
+        for (int r = ty; r < 64; r += 4) {
+            const int q = q0 + r;
+            const long p = p0 + tx;
+            tile[r][tx] = (q < Q && p < HW) ? sigmoidf_(mask[(long)q * HW + p]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            const long p = p0 + r;
+            const int q = q0 + tx;
+            if (p < HW && q < Kpad) stf(out + p * Kpad + q, tile[tx][r]);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, long HW, int Kpad, void* stream) {
+    if (HW == 0) return 0;
+    PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((sigmoid_transpose_kernel<TO>), dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, (hipStream_t)stream, mask,
+                           (TO*)out, Q, HW, Kpad);
+    });
+    PSALM_LAUNCH_END("psalm_sigmoid_transpose");
+}
+
+// ---------------------------------------------------------------- per-query mask score  (LP:443-444)
+// score[q] = sum(sigmoid(m) * [m>0]) / (sum([m>0]) + 1e-6).  Deterministic two-stage reduction.
+__global__ void __launch_bounds__(256) mask_score_partial_kernel(const float* __restrict__ mask, float* __restrict__ partial, long HW,
+                                                                 int nchunks) {
+    __shared__ float sn[4], sd[4];
+    const int q = blockIdx.y, chunk = blockIdx.x;
+    const long per = (HW + nchunks - 1) / nchunks;
+    const long p0 = chunk * per, p1 = min(HW, p0 + per);
+    float num = 0.f, den = 0.f;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float m = mask[(long)q * HW + p];
+        if (m > 0.f) { num += sigmoidf_(m); den += 1.f; }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { sn[threadIdx.x >> 6] = num; sd[threadIdx.x >> 6] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((long)q * nchunks + chunk) * 2 + 0] = sn[0] + sn[1] + sn[2] + sn[3];
+        partial[((long)q * nchunks + chunk) * 2 + 1] = sd[0] + sd[1] + sd[2] + sd[3];
+    }
+}
+__global__ void mask_score_final_kernel(const float* __restrict__ partial, float* __restrict__ score, int Q, int nchunks) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < nchunks; ++k) { num += partial[((long)q * nchunks + k) * 2]; den += partial[((long)q * nchunks + k) * 2 + 1]; }
+    score[q] = (float)(num / (den + 1e-6));
+}
+
+// workspace: Q * 64 * 2 floats
+extern "C" int psalm_mask_scores(const float* mask, float* score, float* workspace, int Q, long HW, void* stream) {
+    if (Q == 0) return 0;
+    const int nchunks = 64;
+    hipLaunchKernelGGL(mask_score_partial_kernel, dim3(nchunks, Q), dim3(256), 0, (hipStream_t)stream, mask, workspace, HW, nchunks);
+    hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, score, Q, nchunks);
+    PSALM_LAUNCH_END("psalm_mask_scores");
+}
+
+// ---------------------------------------------------------------- top-k + instance selection (single block)
+// vals (n) = row-major (Q, stride) matrix restricted to the first C columns; picks the k largest (ties: lowest flat
+// index), in descending order.  Then the reference's filtering (LP:417-446):
+//   label = idx % C, query = idx / C; keep only is_thing[label] (if is_thing != NULL);
+//   out_score = value * mask_score[query]; compacted in pick order.  count[0] = number kept.
+__global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ vals, int Q, int C, int stride, int k,
+                                                           const int* __restrict__ is_thing, const float* __restrict__ mask_score,
+                                                           float* __restrict__ out_score, int* __restrict__ out_class,
+                                                           int* __restrict__ out_query, int* __restrict__ count, int apply_sigmoid) {
+    __shared__ float wv[16];
+    __shared__ int wi[16];
+    __shared__ int picked_idx;
+    __shared__ float picked_val;
+    __shared__ int nkept;
+    constexpr int PER = 16;                       // up to 16384 candidates
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = Q * C;
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 1024;
+        float x = -3.0e38f;
+        if (i < n) {
+            x = vals[(long)(i / C) * stride + (i % C)];
+            if (apply_sigmoid) x = sigmoidf_(x);
+        }
+        v[j] = x;
+    }
+    if (tid == 0) nkept = 0;
+    __syncthreads();
+    for (int r = 0; r < k && r < n; ++r) {
+        float best = -3.0e38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * 1024;
+            if (v[j] > best) { best = v[j]; bi = i; }       // ascending i within a thread: first max kept
+        }
+        const float wbest = wave_max(best);
+        int cand = (best == wbest && best > -3.0e38f) ? bi : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+        if (lane == 0) { wv[wave] = wbest; wi[wave] = cand; }
+        __syncthreads();
+        if (tid == 0) {
+            float b = -3.0e38f;
+            int bidx = 0x7fffffff;
+            for (int w = 0; w < 16; ++w)
+                if (wv[w] > b || (wv[w] == b && wi[w] < bidx)) { b = wv[w]; bidx = wi[w]; }
+            picked_idx = bidx;
+            picked_val = b;
+            const int lab = bidx % C, qq = bidx / C;
+            if (!is_thing || is_thing[lab]) {
+                out_score[nkept] = b * (mask_score ? mask_score[qq] : 1.f);
+                out_class[nkept] = lab;
+                out_query[nkept] = qq;
+                nkept++;
+            }
+        }
+        __syncthreads();
+        const int pi = picked_idx;
+        if ((pi & 1023) == tid) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (j == (pi >> 10)) v[j] = -3.0e38f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) count[0] = nkept;
+}
+
+extern "C" int psalm_topk_select(const float* vals, int Q, int C, int stride, int k, const int* is_thing, const float* mask_score,
+                                 float* out_score, int* out_class, int* out_query, int* count, int apply_sigmoid, void* stream) {
+    PSALM_CHECK_ARG((long)Q * C <= 16384, "psalm_topk_select: at most 16384 candidates");
+    hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vals, Q, C, stride, k, is_thing, mask_score,
+                       out_score, out_class, out_query, count, apply_sigmoid);
+    PSALM_LAUNCH_END("psalm_topk_select");
+}
+
+// ---------------------------------------------------------------- out[i] = (mask[query[i]] > 0) as float, i < count (LP:437)
+__global__ void __launch_bounds__(256) binarize_gather_kernel(const float* __restrict__ mask, const int* __restrict__ query,
+                                                              const int* __restrict__ count, float* __restrict__ out, long HW) {
+    const int i = blockIdx.y;
+    if (count && i >= count[0]) return;
+    const int q = query ? query[i] : i;
+    const float* src = mask + (long)q * HW;
+    float* dst = out + (long)i * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) dst[p] = src[p] > 0.f ? 1.f : 0.f;
+}
+
+extern "C" int psalm_binarize_gather(const float* mask, const int* query, const int* count, float* out, int n, long HW, void* stream) {
+    if (n == 0 || HW == 0) return 0;
+    long gx = (HW + 1023) / 1024;
+    hipLaunchKernelGGL(binarize_gather_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx), n), dim3(256), 0, (hipStream_t)stream, mask, query,
+                       count, out, HW);
+    PSALM_LAUNCH_END("psalm_binarize_gather");
+}
+
+// ---------------------------------------------------------------- panoptic (LP:325-386)
+// stage a: per pixel argmax over kept queries (label != void && score > thr) of score * sigmoid(mask); integer area counts.
+//   counts (Q,3) int32 zero-initialised by the caller: [area(argmax==q), area(sigmoid>=0.5), their intersection]
+__global__ void __launch_bounds__(256) panoptic_argmax_kernel(const float* __restrict__ mask, const float* __restrict__ score,
+                                                              const int* __restrict__ label, int* __restrict__ argq,
+                                                              int* __restrict__ counts, int Q, long HW, int void_label, float thr) {
+    HIP_DYNAMIC_SHARED(int, sm)
+    int* lc = sm;                       // (Q,3) block-local counts
+    float* ksc = (float*)(sm + 3 * Q);  // kept score or -1
+    for (int i = threadIdx.x; i < 3 * Q; i += 256) lc[i] = 0;
+    for (int q = threadIdx.x; q < Q; q += 256) ksc[q] = (label[q] != void_label && score[q] > thr) ? score[q] : -1.f;
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        float best = -1.f;
+        int bq = -1;
+        for (int q = 0; q < Q; ++q) {
+            if (ksc[q] < 0.f) continue;
+            const float s = sigmoidf_(mask[(long)q * HW + p]);
+            const float v = ksc[q] * s;
+            if (s >= 0.5f) atomicAdd(&lc[3 * q + 1], 1);
+            if (v > best) { best = v; bq = q; }
+        }
+        argq[p] = bq;
+        if (bq >= 0) {
+            atomicAdd(&lc[3 * bq + 0], 1);
+            if (sigmoidf_(mask[(long)bq * HW + p]) >= 0.5f) atomicAdd(&lc[3 * bq + 2], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * Q; i += 256)
+        if (lc[i]) atomicAdd(&counts[i], lc[i]);
+}
+
+// stage b (one thread): the sequential merge; final_id[q] = segment id or 0; info (n,3) = (id, isthing, category)
+__global__ void panoptic_merge_kernel(const float* __restrict__ score, const int* __restrict__ label, const int* __restrict__ counts,
+                                      const int* __restrict__ is_thing, int* __restrict__ final_id, int* __restrict__ info,
+                                      int* __restrict__ ninfo, int Q, int void_label, float thr, float overlap_thr, int num_classes) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cur = 0, n = 0;
+    // stuff_memory: class -> id, kept in `info`-independent scratch at the tail of final_id (size num_classes)
+    int* stuff = final_id + Q;
+    for (int c = 0; c < num_classes; ++c) stuff[c] = 0;
+    for (int q = 0; q < Q; ++q) {
+        final_id[q] = 0;
+        if (!(label[q] != void_label && score[q] > thr)) continue;
+        const int area = counts[3 * q], orig = counts[3 * q + 1], inter = counts[3 * q + 2];
+        if (area > 0 && orig > 0 && inter > 0) {
+            if ((float)area / (float)orig < overlap_thr) continue;
+            const int pc = label[q];
+            const int thing = is_thing[pc];
+            if (!thing) {
+                if (stuff[pc] != 0) { final_id[q] = stuff[pc]; continue; }
+                stuff[pc] = cur + 1;
+            }
+            cur += 1;
+            final_id[q] = cur;
+            info[3 * n] = cur; info[3 * n + 1] = thing ? 1 : 0; info[3 * n + 2] = pc;
+            n++;
+        }
+    }
+    ninfo[0] = n;
+}
+
+// stage c: pan[p] = final_id[argq[p]] where sigmoid(mask[argq[p], p]) >= 0.5, else 0
+__global__ void __launch_bounds__(256) panoptic_write_kernel(const float* __restrict__ mask, const int* __restrict__ argq,
+                                                             const int* __restrict__ final_id, int* __restrict__ pan, long HW) {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int q = argq[p];
+        int id = 0;
+        if (q >= 0 && sigmoidf_(mask[(long)q * HW + p]) >= 0.5f) id = final_id[q];
+        pan[p] = id;
+    }
+}
+
+// argq (HW) i32 scratch; counts (Q*3) i32 scratch; final_id (Q + num_classes) i32 scratch; pan (HW) i32; info (Q*3) i32; ninfo (1) i32
+extern "C" int psalm_panoptic(const float* mask, const float* score, const int* label, const int* is_thing, int* argq, int* counts,
+                              int* final_id, int* pan, int* info, int* ninfo, int Q, long HW, int num_classes, float obj_thr,
+                              float overlap_thr, void* stream) {
+    if (HW == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int) * 3 * Q, s) != hipSuccess) { psalm_set_error("psalm_panoptic: memset failed"); return -2; }
+    long gx = (HW + 255) / 256;
+    const int grid = (int)(gx > 4096 ? 4096 : gx);
+    const size_t shmem = (size_t)(3 * Q) * sizeof(int) + (size_t)Q * sizeof(float);
+    hipLaunchKernelGGL(panoptic_argmax_kernel, dim3(grid), dim3(256), shmem, s, mask, score, label, argq, counts, Q, HW, num_classes,
+                       obj_thr);
+    hipLaunchKernelGGL(panoptic_merge_kernel, dim3(1), dim3(64), 0, s, score, label, counts, is_thing, final_id, info, ninfo, Q,
+                       num_classes, obj_thr, overlap_thr, num_classes);
+    hipLaunchKernelGGL(panoptic_write_kernel, dim3(grid), dim3(256), 0, s, mask, argq, final_id, pan, HW);
+    PSALM_LAUNCH_END("psalm_panoptic");
+}
+
+// ---------------------------------------------------------------- region scores (LP:390-399): out[q, k] = sigmoid(logits[k, q]) * mask_score[q]
+__global__ void region_scores_kernel(const float* __restrict__ logits, const float* __restrict__ mask_score, float* __restrict__ out,
+                                     int K, int Q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * Q) return;
+    const int q = i / K, k = i % K;
+    out[i] = sigmoidf_(logits[(long)k * Q + q]) * mask_score[q];
+}
+extern "C" int psalm_region_scores(const float* logits, const float* mask_score, float* out, int K, int Q, void* stream) {
+    if (K * Q == 0) return 0;
+    hipLaunchKernelGGL(region_scores_kernel, dim3(cdiv(K * Q, 256)), dim3(256), 0, (hipStream_t)stream, logits, mask_score, out, K, Q);
+    PSALM_LAUNCH_END("psalm_region_scores");
+}

@@ -1,0 +1,63 @@
+"""Multi-GPU support for the image-sharded inference path.
+
+Images are independent, so the only communication is ONE broadcast of the prepared weight arena from rank 0
+(RCCL over xGMI when the process group backend is "nccl"; "gloo" in the CPU tests), then zero steady-state traffic.
+`shard_indices` is the round-robin image -> rank assignment used by drivers that own a list of images.
+"""
+from __future__ import annotations
+
+import time
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    return list(range(rank, n_items, world))
+
+
+def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple[int, float]:
+    """Broadcast every prepared weight tensor of `model.w` from `src`, packed per dtype into flat buckets of up to
+    `bucket_bytes` (few, large messages: xGMI links are per-link bound, so bucket size >> latency*bandwidth).
+    Returns (bytes moved, seconds)."""
+    t0 = time.perf_counter()
+    total = 0
+    by_dtype = {}
+    for k in sorted(model.w):
+        by_dtype.setdefault(model.w[k].dtype, []).append(k)
+    for dt, keys in by_dtype.items():
+        bucket, size = [], 0
+        esz = torch.empty((), dtype=dt).element_size()
+
+        def flush():
+            nonlocal bucket, size, total
+            if not bucket:
+                return
+            flat = torch.cat([model.w[k].reshape(-1) for k in bucket])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for k in bucket:
+                n = model.w[k].numel()
+                model.w[k].copy_(flat[off:off + n].view_as(model.w[k]))
+                off += n
+            total += flat.numel() * esz
+            bucket, size = [], 0
+        for k in keys:
+            n = model.w[k].numel() * esz
+            if size + n > bucket_bytes and bucket:
+                flush()
+            bucket.append(k)
+            size += n
+        flush()
+    if model.w and next(iter(model.w.values())).is_cuda:
+        torch.cuda.synchronize()
+    return total, time.perf_counter() - t0
+
+
+def reduce_metrics(values: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce of a small fp32 vector, e.g. [intersection, union, count] -- the role of AverageMeter.all_reduce in
+    the reference's eval scripts (psalm/eval/referring_segmentation.py:58-79)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+    return values

@@ -36,15 +36,48 @@ def _dt(t: torch.Tensor) -> int:
         raise PsalmHipError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
 
 
+class _ProfiledLib:
+    """Transparent proxy over the CDLL: when `records` is a list, every psalm_* launch is bracketed by a pair of
+    HIP events on the launch stream (torch's current stream) so bench.py can attribute time per kernel family."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "records", None)
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version"):
+            return fn
+
+        def call(*args):
+            rec = self.records
+            if rec is None:
+                return fn(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            rec.append((name, tuple(a.value if hasattr(a, "value") else a for a in args), e0, e1))
+            return rc
+        return call
+
+    def __setattr__(self, k, v):
+        if k == "records":
+            object.__setattr__(self, k, v)
+        else:
+            setattr(self._cdll, k, v)
+
+
 class Ops:
     def __init__(self, lib_path: str = DEFAULT_LIB):
         if not os.path.exists(lib_path):
             raise PsalmHipError(
                 f"{lib_path} not found: build the HIP kernels first (python -m psalm_amd.build). "
                 "psalm_amd has no CPU / PyTorch fallback by design.")
-        self.lib = ctypes.CDLL(lib_path)
-        self.lib.psalm_last_error.restype = c_char_p
-        self.lib.psalm_backend.restype = c_char_p
+        cdll = ctypes.CDLL(lib_path)
+        cdll.psalm_last_error.restype = c_char_p
+        cdll.psalm_backend.restype = c_char_p
+        self.lib = _ProfiledLib(cdll)
         self.backend = self.lib.psalm_backend().decode()
         self.is_emu = self.backend == "emu"
         self.device = torch.device("cpu") if self.is_emu else torch.device("cuda", torch.cuda.current_device())
@@ -280,6 +313,81 @@ class Ops:
         out = self.empty((B * HW, C) if to_nhwc else (B, C, HW), dtype=out_dtype or x.dtype)
         rc = self.lib.psalm_permute_layout(self._p(x), _dt(x), self._p(out), _dt(out), B, C, c_long(HW), int(to_nhwc), self._stream())
         self._check(rc, "psalm_permute_layout")
+        return out
+
+    # ------------------------------------------------------------------ post-processing
+    def class_softmax(self, cls, Kpad):
+        """cls (Q,C1) f32 -> probs (Q,C1), probsT (C1-1,Kpad) zero padded, score (Q), label (Q) i32."""
+        Q, C1 = cls.shape
+        probs = self.empty(Q, C1)
+        probsT = self.zeros(C1 - 1, Kpad)
+        score = self.empty(Q)
+        label = self.empty(Q, dtype=torch.int32)
+        rc = self.lib.psalm_class_softmax(self._p(cls), self._p(probs), self._p(probsT), self._p(score), self._p(label), Q, C1, Kpad,
+                                          self._stream())
+        self._check(rc, "psalm_class_softmax")
+        return probs, probsT, score, label
+
+    def sigmoid_transpose(self, mask, Kpad, out_dtype):
+        """mask (Q,HW) f32 -> (HW,Kpad) sigmoid, zero padded."""
+        Q, HW = mask.shape
+        out = self.empty(HW, Kpad, dtype=out_dtype)
+        rc = self.lib.psalm_sigmoid_transpose(self._p(mask), self._p(out), _dt(out), Q, c_long(HW), Kpad, self._stream())
+        self._check(rc, "psalm_sigmoid_transpose")
+        return out
+
+    def mask_scores(self, mask):
+        """mask (Q,HW) f32 -> (Q) f32: sum(sigmoid*[m>0]) / (sum([m>0]) + 1e-6)."""
+        Q, HW = mask.shape
+        score = self.empty(Q)
+        ws = self.empty(Q * 64 * 2)
+        rc = self.lib.psalm_mask_scores(self._p(mask), self._p(score), self._p(ws), Q, c_long(HW), self._stream())
+        self._check(rc, "psalm_mask_scores")
+        return score
+
+    def topk_select(self, vals, C, k, is_thing=None, mask_score=None, apply_sigmoid=False):
+        """vals (Q,stride) f32, first C columns are candidates.  Returns (score (k), class (k) i32, query (k) i32, count (1) i32),
+        entries [0,count) valid, in descending candidate order."""
+        Q, stride = vals.shape
+        sc = self.zeros(k)
+        cl = self.zeros(k, dtype=torch.int32)
+        qq = self.zeros(k, dtype=torch.int32)
+        cnt = self.zeros(1, dtype=torch.int32)
+        rc = self.lib.psalm_topk_select(self._p(vals), Q, C, stride, k, self._p(is_thing), self._p(mask_score), self._p(sc), self._p(cl),
+                                        self._p(qq), self._p(cnt), int(apply_sigmoid), self._stream())
+        self._check(rc, "psalm_topk_select")
+        return sc, cl, qq, cnt
+
+    def binarize_gather(self, mask, n, query=None, count=None):
+        """out[i] = (mask[query[i]] > 0).float() for i < count (rows >= count untouched); mask (Q,H,W)."""
+        Q, Hh, Ww = mask.shape
+        out = self.empty(n, Hh, Ww)
+        rc = self.lib.psalm_binarize_gather(self._p(mask), self._p(query), self._p(count), self._p(out), n, c_long(Hh * Ww), self._stream())
+        self._check(rc, "psalm_binarize_gather")
+        return out
+
+    def panoptic(self, mask, score, label, is_thing, num_classes, obj_thr, overlap_thr):
+        """mask (Q,H,W) f32 logits; returns (pan (H,W) i32, info (Q,3) i32, ninfo (1) i32)."""
+        Q, Hh, Ww = mask.shape
+        HW = Hh * Ww
+        argq = self.empty(HW, dtype=torch.int32)
+        counts = self.empty(Q * 3, dtype=torch.int32)
+        final_id = self.empty(Q + num_classes + 1, dtype=torch.int32)
+        pan = self.empty(Hh, Ww, dtype=torch.int32)
+        info = self.zeros(Q, 3, dtype=torch.int32)
+        ninfo = self.zeros(1, dtype=torch.int32)
+        rc = self.lib.psalm_panoptic(self._p(mask), self._p(score), self._p(label), self._p(is_thing), self._p(argq), self._p(counts),
+                                     self._p(final_id), self._p(pan), self._p(info), self._p(ninfo), Q, c_long(HW), num_classes,
+                                     c_float(obj_thr), c_float(overlap_thr), self._stream())
+        self._check(rc, "psalm_panoptic")
+        return pan, info, ninfo
+
+    def region_scores(self, logits, mask_score):
+        """logits (K,Q) f32 -> (Q,K) sigmoid(logits).T * mask_score[:,None]."""
+        K, Q = logits.shape
+        out = self.empty(Q, K)
+        rc = self.lib.psalm_region_scores(self._p(logits), self._p(mask_score), self._p(out), K, Q, self._stream())
+        self._check(rc, "psalm_region_scores")
         return out
 
     # ------------------------------------------------------------------ MSDA

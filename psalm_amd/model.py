@@ -611,3 +611,100 @@ class PSALM:
                 stages.setdefault("multi_scale_features", []).append(ms)
             outs.append(r)
         return outs
+
+    # ======================================================================================= post-processing + eval_seg
+    def _postprocess(self, r, info, img_hw):
+        """llava_phi.py:1401-1466 for one image.  r: predictor outputs; info: seg_info entry; img_hw: network input size."""
+        o, cfg = self.ops, self.cfg
+        Q = cfg.md_queries
+        div = cfg.size_divisibility
+        Hpad = (img_hw[0] + div - 1) // div * div                  # ImageList.from_tensors(images, 32), LP:1400
+        Wpad = (img_hw[1] + div - 1) // div * div
+        height = info.get("height", img_hw[0])
+        width = info.get("width", img_hw[1])
+        pm = info.get("padding_mask")
+        nz = np.where(~np.asarray(pm.cpu() if torch.is_tensor(pm) else pm))          # LP:1418-1423
+        oh = int(nz[0].max() - nz[0].min() + 1)
+        ow = int(nz[1].max() - nz[1].min() + 1)
+        mp = o.resize_planes(r["pred_masks"], Hpad, Wpad)                             # LP:1401-1406
+        if (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad):
+            mp = o.resize_planes(mp, height, width, crop=(oh, ow))                    # sem_seg_postprocess, LP:1427-1429
+        HW = height * width
+        mflat = mp.view(Q, HW)
+        res = {}
+        task = self.seg_task
+        if task == "panoptic":
+            cls = r["pred_class_name_logits"]
+            C1 = cls.shape[1]
+            Kpad = (Q + 31) // 32 * 32
+            probs, probsT, score, label = o.class_softmax(cls, Kpad)
+            sigT = o.sigmoid_transpose(mflat, Kpad, self.wdt)
+            res["sem_seg"] = o.gemm(probsT, sigT, out_dtype=torch.float32).view(C1 - 1, height, width)       # LP:402-406
+            mscore = o.mask_scores(mflat)
+            thing = self._thing_dev(C1 - 1)
+            sc, cl, qq, cnt = o.topk_select(probs, C1 - 1, Q, thing, mscore)                                 # LP:407-447
+            inst_masks = o.binarize_gather(mp, Q, qq, cnt)
+            pan, pinfo, ninfo = o.panoptic(mp, score, label, thing, C1 - 1, cfg.object_mask_threshold, cfg.overlap_threshold)
+            res["_pending"] = ("panoptic", sc, cl, qq, cnt, inst_masks, pan, pinfo, ninfo, (height, width))
+        elif task == "referring":
+            mscore = o.mask_scores(mflat)
+            sc, cl, qq, cnt = o.topk_select(r["pred_SEG_logits"], 1, Q, None, mscore, apply_sigmoid=True)    # LP:308-324
+            inst_masks = o.binarize_gather(mp, Q, qq, cnt)
+            res["_pending"] = ("referring", sc, qq, inst_masks, (height, width))
+        elif task == "region":
+            mscore = o.mask_scores(mflat)
+            scores = o.region_scores(r["pred_region_logits"], mscore)                                        # LP:387-400
+            inst_masks = o.binarize_gather(mp, Q)
+            gt = info["instances"].gt_masks
+            gt = gt.tensor if hasattr(gt, "tensor") else gt
+            gt = gt.to(self.device, torch.float32).contiguous()
+            res["gt"] = o.resize_planes(gt, height, width, crop=(oh, ow))                                    # LP:1458-1461
+            res["instances"] = Instances((height, width), pred_masks=inst_masks, scores=scores,
+                                         pred_boxes=torch.zeros(Q, 4, device=self.device))
+        else:
+            raise NotImplementedError(f"seg_task {task}")
+        res["mask_pred"] = mp
+        return res
+
+    def _thing_dev(self, C):
+        key = ("thing", C, tuple(int(bool(x)) for x in self.is_thing_list))
+        if key not in self._cache:
+            t = list(key[2]) + [0] * max(0, C - len(key[2]))
+            self._cache[key] = torch.tensor(t[:C], dtype=torch.int32, device=self.device)
+        return self._cache[key]
+
+    def _finalize(self, res):
+        """One host round trip per image: fetch the data-dependent counts and slice the padded result buffers."""
+        pend = res.pop("_pending", None)
+        if pend is None:
+            return res
+        if pend[0] == "panoptic":
+            _, sc, cl, qq, cnt, inst_masks, pan, pinfo, ninfo, hw = pend
+            n = int(cnt.item())
+            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n].to(torch.int64),
+                                         query_index=qq[:n].to(torch.int64), pred_boxes=torch.zeros(n, 4, device=self.device))
+            ni = int(ninfo.item())
+            rows = pinfo[:ni].cpu().tolist()
+            res["panoptic_seg"] = (pan, [{"id": a, "isthing": bool(b), "category_id": c} for a, b, c in rows])
+        else:
+            _, sc, qq, inst_masks, hw = pend
+            res["instances"] = Instances(hw, pred_masks=inst_masks, scores=sc, query_index=qq.to(torch.int64),
+                                         pred_boxes=torch.zeros(inst_masks.shape[0], 4, device=self.device))
+        return res
+
+    @torch.no_grad()
+    def eval_seg(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
+                 seg_info=None, class_name_ids=None, class_name_embedding_indices=None, cls_indices=None,
+                 token_refer_id=None, refer_embedding_indices=None, is_thing_list=None,
+                 region_point_sampler: Callable = default_region_point_sampler):
+        """Same keyword signature as the reference's PSALM.eval_seg (llava_phi.py:1317-1336).  Returns list[dict] with
+        `sem_seg`, `instances`, `panoptic_seg` (panoptic) / `instances` (referring) / `instances`,`gt` (region), one entry
+        per image (the reference stops after image 0, LP:1472)."""
+        if self.seg_task == "panoptic":
+            assert is_thing_list is not None, "is_thing_list need to be given"        # LP:1337-1339
+            self.is_thing_list = is_thing_list
+        outs = self.forward_logits(input_ids, attention_mask, images, seg_info, class_name_ids, class_name_embedding_indices,
+                                   cls_indices, token_refer_id, refer_embedding_indices, labels, region_point_sampler)
+        results = [self._postprocess(r, seg_info[b], images.shape[-2:]) for b, r in enumerate(outs)]
+        return [self._finalize(r) for r in results]

@@ -51,3 +51,46 @@ def test_tiny_forward_logits_fp32(task, batch, size):
             assert _rel(outs[b]["pred_SEG_logits"], st["pred_SEG_logits"][b]) < 2e-3
         if task == "region":
             assert _rel(outs[b]["pred_region_logits"], st["pred_region_logits"][b]) < 2e-3
+
+
+@pytest.mark.parametrize("task,batch,pad", [("panoptic", 1, 0), ("referring", 2, 32), ("region", 1, 0)])
+def test_tiny_eval_seg_postprocess_fp32(task, batch, pad):
+    """Full eval_seg incl. post-processing kernels vs the oracle's post-processing of the oracle's logits."""
+    cfg = PsalmConfig.tiny(task)
+    size = 96
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, task, size=size, batch=batch, seed=4, num_classes=9, pad=pad)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
+    torch.manual_seed(5)
+    want = O.eval_seg(sd, cfg, **inputs)
+    torch.manual_seed(5)
+    got = model.eval_seg(**inputs)
+    assert len(got) == batch
+    for b in range(batch):
+        g, w = got[b], want[b]
+        assert _rel(g["mask_pred"], w["mask_pred"]) < 2e-3
+        gi, wi = g["instances"], w["instances"]
+        if task == "panoptic":
+            assert (g["sem_seg"].argmax(0).cpu() == w["sem_seg"].argmax(0)).float().mean() > 0.999
+            assert _rel(g["sem_seg"], w["sem_seg"]) < 2e-3
+            gp, ginfo = g["panoptic_seg"]
+            wp, winfo = w["panoptic_seg"]
+            assert ginfo == winfo
+            assert (gp.cpu() == wp).float().mean() > 0.999
+            og = sorted(zip((-gi.scores.cpu()).tolist(), gi.pred_classes.cpu().tolist()))
+            ow = sorted(zip((-wi.scores).tolist(), wi.pred_classes.tolist()))
+            assert len(og) == len(ow)
+            for (a, c1), (b_, c2) in zip(og, ow):
+                assert abs(a - b_) < 1e-4 and c1 == c2
+        elif task == "referring":
+            assert (torch.sort(gi.scores.cpu()).values - torch.sort(wi.scores).values).abs().max() < 1e-4
+            # masks: compare per query through query_index
+            gm = torch.zeros_like(wi.pred_masks)
+            gm[gi.query_index.cpu()] = gi.pred_masks.cpu()
+            wm = torch.zeros_like(wi.pred_masks)
+            wm[wi.query_index] = wi.pred_masks
+            assert (gm != wm).float().mean() < 1e-3
+        else:
+            assert _rel(gi.scores, wi.scores) < 2e-3
+            assert (gi.pred_masks.cpu() != wi.pred_masks).float().mean() < 1e-3
+            assert _rel(g["gt"], w["gt"]) < 1e-5
