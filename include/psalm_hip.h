@@ -44,6 +44,122 @@ int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_
                      const int64_t* level_start_host, const float* offsets_logits, void* out, int out_dtype, int B, int S,
                      int M, int D, int L, int P, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dense contractions (every nn.Linear / 1x1 conv / im2col'd conv / einsum of the path).
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]   (nn.Linear weight layout, W is [out,in]).
+ *   act: 0 none, 1 relu, 2 gelu(erf), 3 gelu_new(tanh); |16 = apply after the residual add (ResNet block);
+ *   activation applies to columns >= act_col_start only (fused [k|v|q|fc1] projection of a Phi layer).
+ *   w_dtype selects the arithmetic: BF16 -> v_mfma_f32_32x32x16_bf16 / fp32 accumulate (A f32 or bf16, converted
+ *   while staging); F32 -> v_mfma_f32_32x32x2_f32 (exact fp32; A must be f32).  lda/ldw/ldr/ldc are row strides in
+ *   elements; K % 8 == 0; rows 16-byte aligned.
+ * Replaces torch.nn.functional.linear / conv2d at: modeling_phi.py:189-260 (q/k/v/dense/fc1/fc2),
+ * swin_trans.py:28-34,109-149,266-296, multimodal_projector/builder.py:85-111,365-375, msdeformattn.py:196-254,
+ * OPS/modules/ms_deform_attn.py:98-123, mask2former_transformer_decoder.py:187-199,709,723,744,749,
+ * llava_phi.py:163,183-185 (projectors), llava_phi.py:402-406 (semantic einsum). */
+int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
+               const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
+               int act_col_start, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row / normalisation kernels (one 64-lane wavefront per row, fp32 statistics). */
+/* nn.LayerNorm over the last dim (swin_trans.py:181,187,548; modeling_phi.py:263-300; msdeformattn.py:37,45;
+ * mask2former_transformer_decoder.py:19,77,143,451).  x (rows,C) row stride ldx; y (rows,C) row stride ldy. */
+int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, const float* gamma,
+                    const float* beta, int rows, int C, float eps, void* stream);
+/* SwinTransformerBlock.forward front half (swin_trans.py:206-225): norm1 -> zero-pad to a multiple of ws ->
+ * roll(-shift) -> window_partition.  x (B*H*W,C) -> out (B*nW*ws*ws, C). */
+int psalm_swin_window_gather(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,
+                             const float* beta, int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
+/* ... and its back half (swin_trans.py:233-250): window_reverse -> roll(+shift) -> crop -> + shortcut. */
+int psalm_swin_window_merge(const void* win, int win_dtype, const void* shortcut, void* out, int x_dtype, int B, int H,
+                            int W, int C, int ws, int shift, void* stream);
+/* PatchMerging.forward up to the reduction GEMM (swin_trans.py:269-296): 2x2 gather-concat + LayerNorm(4C). */
+int psalm_patch_merge_ln(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma, const float* beta,
+                         int B, int H, int W, int C, float eps, void* stream);
+/* nn.GroupNorm(G, C) (+ optional ReLU) on NHWC tokens (msdeformattn.py:199-202,248-254).
+ * workspace: B * ceil(HW/64) * G * 2 floats. */
+int psalm_groupnorm_nhwc(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
+                         float* workspace, int B, int HW, int C, int G, float eps, int relu, void* stream);
+/* out[r,:] = a[r,:] + b[r % b_rows,:]  (positional / level / query embedding adds: msdeformattn.py:51-58,
+ * mask2former_transformer_decoder.py:35-37,93-96). */
+int psalm_add_bcast(const void* a, int a_dtype, const void* b, int b_dtype, void* out, int out_dtype, long rows, int C,
+                    long b_rows, void* stream);
+/* inputs_embeds assembly (llava_phi.py:581-766,874-948): dst[r] = src{src_id[r]}[src_row[r]], src_id < 0 -> zeros. */
+int psalm_gather_rows(const void* src0, int dt0, const void* src1, int dt1, const void* src2, int dt2, const void* src3,
+                      int dt3, const int* src_id, const int* src_row, void* dst, int dst_dtype, long rows, int C,
+                      void* stream);
+/* get_seg_query / get_class_name_embedding / get_SEG_embedding / get_region_embedding (llava_phi.py:1299-1316,
+ * 552-565,972-978,302-307): CSR row-set mean pooling of hidden states. */
+int psalm_segment_mean(const void* x, int x_dtype, long ldx, const int* seg_offsets, const int* seg_rows, void* out,
+                       int out_dtype, int nseg, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Attention. */
+/* WindowAttention.forward core (swin_trans.py:117-149) with the relative-position bias gather (:131-134) and the
+ * shifted-window -100 mask (:369-387) computed in-kernel.  qkv (B*nW*ws*ws, 3C); out (B*nW*ws*ws, C); head_dim 32. */
+int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw, int C,
+                           int heads, int ws, int shift, void* stream);
+/* PhiAttention prefill core (modeling_phi.py:189-245,137-160) with partial RoPE (:92-122) fused into the loads:
+ * q/k/v are column blocks of one row-strided buffer; causal + key padding mask (B,L) u8; fp32 softmax. */
+int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,
+                           int o_off, const float* cos_table, const float* sin_table, const unsigned char* key_mask, int B,
+                           int L, int heads, int head_dim, int rot, void* stream);
+/* nn.MultiheadAttention core of the predictor (mask2former_transformer_decoder.py:35-45,93-105,645-666), head_dim 32;
+ * mask (B,Lq,Lk) u8 1 = blocked; row_all_masked (B,Lq) u8 implements TD:647. */
+int psalm_mha_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out, long ldo,
+                        int dtype, const unsigned char* mask, const unsigned char* row_all_masked, int B, int Lq, int Lk,
+                        int heads, int head_dim, void* stream);
+/* forward_prediction_heads' attention-mask branch (mask2former_transformer_decoder.py:754-760): bilinear resize of the
+ * mask logits to (Ht,Wt), sigmoid < 0.5, plus the all-masked row flags. */
+int psalm_attn_mask(const float* masks, unsigned char* out, unsigned char* row_all_masked, int BQ, int h, int w, int Ht,
+                    int Wt, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Image / layout kernels. */
+/* PatchEmbed im2col (swin_trans.py:427-443): img (B,Cin,H,W) f32 -> (B*Hp*Wp, Kpad), K order (c,ky,kx), zero pad. */
+int psalm_patch_im2col(const float* img, void* out, int out_dtype, int B, int Cin, int H, int W, int ps, int Kpad,
+                       void* stream);
+/* k x k / stride / pad im2col of NHWC tokens (projector convs builder.py:85-111, FPN conv msdeformattn.py:248-254). */
+int psalm_im2col_nhwc(const void* x, void* out, int dtype, int B, int H, int W, int C, int k, int stride, int pad,
+                      void* stream);
+/* F.interpolate(bilinear, align_corners=False) on N planes with optional top-left crop first
+ * (llava_phi.py:1401-1406; detectron2 sem_seg_postprocess at llava_phi.py:1427-1429). */
+int psalm_resize_planes(const void* in, int in_dtype, void* out, int out_dtype, long N, int h, int w, int hc, int wc, int H,
+                        int W, void* stream);
+/* FPN top-down step (msdeformattn.py:300-308): out = lateral + bilinear_up(small), NHWC. */
+int psalm_upsample_add_nhwc(const void* lateral, int lat_dtype, const void* small, int small_dtype, void* out, int out_dtype,
+                            int B, int h, int w, int H, int W, int C, void* stream);
+/* NCHW <-> NHWC. */
+int psalm_permute_layout(const void* in, int in_dtype, void* out, int out_dtype, int B, int C, long HW, int to_nhwc,
+                         void* stream);
+/* region_pooling.forward (visual_prompt_module/context_cluster.py:357-400): grid_sample(align_corners=True) of the
+ * projector tokens at n points per region + mean.  pts (R,n,2) f32 (y,x) in [0,1). */
+int psalm_region_pool(const float* tokens, const int* img_of_region, const float* pts, float* out, int R, int h, int w, int C,
+                      int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Post-processing (llava_phi.py:308-447). */
+/* softmax over C1 class logits; probsT = transpose of the first C1-1 columns padded to Kpad (semantic einsum operand);
+ * per-query max score / label (panoptic, llava_phi.py:328). */
+int psalm_class_softmax(const float* cls, float* probs, float* probsT, float* score, int* label, int Q, int C1, int Kpad,
+                        void* stream);
+/* sigmoid(mask)^T padded to Kpad: second operand of class_name_semantic_inference (llava_phi.py:402-406). */
+int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, long HW, int Kpad, void* stream);
+/* mask score = sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6) (llava_phi.py:318-320,439-441). workspace Q*64*2 floats. */
+int psalm_mask_scores(const float* mask, float* score, float* workspace, int Q, long HW, void* stream);
+/* topk over Q*C candidates + thing filter + score product (llava_phi.py:407-447, 308-324). */
+int psalm_topk_select(const float* vals, int Q, int C, int stride, int k, const int* is_thing, const float* mask_score,
+                      float* out_score, int* out_class, int* out_query, int* count, int apply_sigmoid, void* stream);
+/* pred_masks = (mask[query] > 0).float() (llava_phi.py:316,437). */
+int psalm_binarize_gather(const float* mask, const int* query, const int* count, float* out, int n, long HW, void* stream);
+/* class_name_panoptic_inference (llava_phi.py:325-386) entirely on device: keep / argmax / area tests / stuff merge. */
+int psalm_panoptic(const float* mask, const float* score, const int* label, const int* is_thing, int* argq, int* counts,
+                   int* final_id, int* pan, int* info, int* ninfo, int Q, long HW, int num_classes, float obj_thr,
+                   float overlap_thr, void* stream);
+/* region_inference scores (llava_phi.py:387-400). */
+int psalm_region_scores(const float* logits, const float* mask_score, float* out, int K, int Q, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
