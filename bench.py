@@ -88,6 +88,7 @@ def main():
         torch.cuda.synchronize()
         model.ops.lib.records = None
         agg = {}
+        shapes = {}
         gemm_flops = gemm_ms = 0.0
         gemm_n = 0
         for name, a, e0, e1 in recs:
@@ -100,7 +101,13 @@ def main():
                 gemm_flops += 2.0 * M * N * K
                 gemm_ms += ms
                 gemm_n += 1
+                sh = shapes.setdefault(f"M{M} N{N} K{K} a{'f32' if a[1] == 0 else 'bf16'} c{'f32' if a[10] == 0 else 'bf16'}", [0, 0.0, 2.0 * M * N * K])
+                sh[0] += 1
+                sh[1] += ms
         breakdown = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        breakdown["_gemm_shapes"] = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 4),
+                                         "TFLOPs": round(v[2] * v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None}
+                                     for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
         if gemm_ms > 0:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (psalm_gemm, bf16 weights)", "achieved": round(ach, 1),

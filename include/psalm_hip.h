@@ -52,21 +52,24 @@ int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_
  *   activation applies to columns >= act_col_start only (fused [k|v|q|fc1] projection of a Phi layer).
  *   w_dtype selects the arithmetic: BF16 -> v_mfma_f32_32x32x16_bf16 / fp32 accumulate (A f32 or bf16, converted
  *   while staging); F32 -> v_mfma_f32_32x32x2_f32 (exact fp32; A must be f32).  lda/ldw/ldr/ldc are row strides in
- *   elements; K % 8 == 0; rows 16-byte aligned.
+ *   elements; K % 8 == 0; rows 16-byte aligned.  A and W both bf16 with K % 64 == 0 take the direct-to-LDS
+ *   (global_load_lds_dwordx4, XOR-swizzled LDS image) kernel; `workspace` (workspace_bytes, may be NULL/0) is caller-owned
+ *   scratch for split-K partials, used when the tile grid alone cannot fill the 256 CUs.
  * Replaces torch.nn.functional.linear / conv2d at: modeling_phi.py:189-260 (q/k/v/dense/fc1/fc2),
  * swin_trans.py:28-34,109-149,266-296, multimodal_projector/builder.py:85-111,365-375, msdeformattn.py:196-254,
  * OPS/modules/ms_deform_attn.py:98-123, mask2former_transformer_decoder.py:187-199,709,723,744,749,
  * llava_phi.py:163,183-185 (projectors), llava_phi.py:402-406 (semantic einsum). */
 int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
                const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
-               int act_col_start, void* stream);
+               int act_col_start, void* workspace, long workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Row / normalisation kernels (one 64-lane wavefront per row, fp32 statistics). */
 /* nn.LayerNorm over the last dim (swin_trans.py:181,187,548; modeling_phi.py:263-300; msdeformattn.py:37,45;
- * mask2former_transformer_decoder.py:19,77,143,451).  x (rows,C) row stride ldx; y (rows,C) row stride ldy. */
-int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, const float* gamma,
-                    const float* beta, int rows, int C, float eps, void* stream);
+ * mask2former_transformer_decoder.py:19,77,143,451).  x (rows,C) row stride ldx; y (rows,C) row stride ldy; y2_bf16
+ * (optional) receives a second bf16 copy of the result (the next GEMM's A operand beside a fp32 residual stream). */
+int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
+                    const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 /* SwinTransformerBlock.forward front half (swin_trans.py:206-225): norm1 -> zero-pad to a multiple of ws ->
  * roll(-shift) -> window_partition.  x (B*H*W,C) -> out (B*nW*ws*ws, C). */
 int psalm_swin_window_gather(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,
@@ -78,7 +81,7 @@ int psalm_swin_window_merge(const void* win, int win_dtype, const void* shortcut
 int psalm_patch_merge_ln(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma, const float* beta,
                          int B, int H, int W, int C, float eps, void* stream);
 /* nn.GroupNorm(G, C) (+ optional ReLU) on NHWC tokens (msdeformattn.py:199-202,248-254).
- * workspace: B * ceil(HW/64) * G * 2 floats. */
+ * workspace: B * (ceil(HW/64) + 1) * G * 2 floats.  C % 8 == 0. */
 int psalm_groupnorm_nhwc(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
                          float* workspace, int B, int HW, int C, int G, float eps, int relu, void* stream);
 /* out[r,:] = a[r,:] + b[r % b_rows,:]  (positional / level / query embedding adds: msdeformattn.py:51-58,
@@ -100,11 +103,22 @@ int psalm_segment_mean(const void* x, int x_dtype, long ldx, const int* seg_offs
  * shifted-window -100 mask (:369-387) computed in-kernel.  qkv (B*nW*ws*ws, 3C); out (B*nW*ws*ws, C); head_dim 32. */
 int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw, int C,
                            int heads, int ws, int shift, void* stream);
+/* The same on the matrix cores for bf16 buffers and 12x12 windows (one block per (window, head), K / V^T / bias column
+ * staged in LDS, scores of a whole 144-key row kept in MFMA accumulators). */
+int psalm_window_attention_mfma(const void* qkv, const float* bias_table, void* out, int B, int nWh, int nWw, int C, int heads,
+                                int ws, int shift, void* stream);
 /* PhiAttention prefill core (modeling_phi.py:189-245,137-160) with partial RoPE (:92-122) fused into the loads:
  * q/k/v are column blocks of one row-strided buffer; causal + key padding mask (B,L) u8; fp32 softmax. */
 int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,
                            int o_off, const float* cos_table, const float* sin_table, const unsigned char* key_mask, int B,
                            int L, int heads, int head_dim, int rot, void* stream);
+/* The same operation on the matrix cores for bf16 buffers (v_mfma_f32_32x32x16_bf16, fp32 softmax statistics and
+ * accumulation): RoPE/scale/transpose pre-pass into `workspace`, then one wavefront per 32-query tile.  `out` may alias
+ * the q block of `qkv`.  workspace: psalm_causal_attention_mfma_workspace(B,L,heads) bytes, 16-byte aligned. */
+long psalm_causal_attention_mfma_workspace(int B, int L, int heads);
+int psalm_causal_attention_mfma(const void* qkv, long ld, int q_off, int k_off, int v_off, void* out, long ldo, int o_off,
+                                const float* cos_table, const float* sin_table, const unsigned char* key_mask,
+                                void* workspace, int B, int L, int heads, int head_dim, int rot, void* stream);
 /* nn.MultiheadAttention core of the predictor (mask2former_transformer_decoder.py:35-45,93-105,645-666), head_dim 32;
  * mask (B,Lq,Lk) u8 1 = blocked; row_all_masked (B,Lq) u8 implements TD:647. */
 int psalm_mha_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out, long ldo,
@@ -142,8 +156,8 @@ int psalm_region_pool(const float* tokens, const int* img_of_region, const float
  * Post-processing (llava_phi.py:308-447). */
 /* softmax over C1 class logits; probsT = transpose of the first C1-1 columns padded to Kpad (semantic einsum operand);
  * per-query max score / label (panoptic, llava_phi.py:328). */
-int psalm_class_softmax(const float* cls, float* probs, float* probsT, float* score, int* label, int Q, int C1, int Kpad,
-                        void* stream);
+int psalm_class_softmax(const float* cls, float* probs, void* probsT, int probsT_dtype, float* score, int* label, int Q, int C1,
+                        int Kpad, void* stream);
 /* sigmoid(mask)^T padded to Kpad: second operand of class_name_semantic_inference (llava_phi.py:402-406). */
 int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, long HW, int Kpad, void* stream);
 /* mask score = sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6) (llava_phi.py:318-320,439-441). workspace Q*64*2 floats. */

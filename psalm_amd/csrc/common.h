@@ -24,6 +24,32 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); 
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
+// 8 consecutive elements per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses; p must be 16-byte aligned.
+struct alignas(16) psalm_u32x4 { unsigned x, y, z, w; };
+struct alignas(16) psalm_f32x4 { float x, y, z, w; };
+__device__ __forceinline__ void ld8(const float* p, float* d) {
+    const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], b = reinterpret_cast<const psalm_f32x4*>(p)[1];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float* d) {
+    const psalm_u32x4 a = *reinterpret_cast<const psalm_u32x4*>(p);
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        d[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+    reinterpret_cast<psalm_f32x4*>(p)[0] = psalm_f32x4{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<psalm_f32x4*>(p)[1] = psalm_f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+    *reinterpret_cast<psalm_u32x4*>(p) =
+        psalm_u32x4{(unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16), (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16),
+                    (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16), (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16)};
+}
+
 // 64-lane wavefront reductions (CDNA wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -35,6 +61,18 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): the LDS destination is the WAVE-UNIFORM
+// `lds_wave_base` + lane*16 (hardware adds the lane offset; the base goes through M0), the global source is per lane.
+// Completion is tracked by vmcnt; a following __syncthreads() drains it.
+#ifdef PSALM_EMU_BUILD   // host build of the same kernel sources for the CPU tests (tests/emu): functional stand-in
+__device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base) { emu::global_load_lds(g, lds_wave_base, 16); }
+#else
+__device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
 
 // ----------------------------------------------------------------------------- host side
 extern "C" void psalm_set_error(const char* msg);

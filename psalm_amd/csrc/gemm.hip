@@ -185,6 +185,234 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
             epilogue_store<TC>(g, acc[i][j], bm + wm * (BM / 2) + i * 32, bn + wn * 64 + j * 32 + (lane & 31), lane);
 }
 
+
+// ------------------------------------------------------------------------------------------- bf16 MFMA, direct-to-LDS
+// The fast path (A and W both bf16 in memory, K % 64 == 0): operands go HBM/L2 -> LDS with global_load_lds_dwordx4
+// (no staging registers, no ds_write pass), LDS double-buffered, ONE barrier per 64-deep K step; the next tile's
+// copies are issued before the current tile's MFMAs and drained by the barrier's vmcnt(0).
+// LDS image per operand tile: [rows][64 k] bf16 = 128-byte rows, written 8 rows (1 KiB) per wave instruction.  A
+// linear image would put the 16 rows of a ds_read_b128 lane group on only two 16-byte slots of the 256-byte bank row
+// (8-way conflict); the image is therefore XOR-swizzled: 16-byte slot p of row r holds k-chunk  p ^ ((r >> 1) & 7).
+// global_load_lds writes lane-linearly, so the permutation is applied to the per-lane GLOBAL source address
+// (still one full 128-byte line per 8 lanes) and again on the fragment reads (same involution, guide §5.4 rule 21).
+// Rows beyond M / N are clamped to the last valid row (their products land in C rows / columns that are never stored).
+// Split-K (gridDim.y > 1): each z-slice writes its raw fp32 partial tile to a slab; splitk_reduce_kernel applies the
+// epilogue.  Used when the tile grid alone cannot fill the 256 CUs (small M or N with a long K).
+__device__ __forceinline__ void load8_f32(const float* p, float* d) {
+    const f32x4_g a = reinterpret_cast<const f32x4_g*>(p)[0], b = reinterpret_cast<const f32x4_g*>(p)[1];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+__device__ __forceinline__ void load8_f32(const bf16_t* p, float* d) {
+    const u32x4_s a = *reinterpret_cast<const u32x4_s*>(p);
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        d[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+    reinterpret_cast<f32x4_g*>(p)[0] = f32x4_g{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<f32x4_g*>(p)[1] = f32x4_g{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+    *reinterpret_cast<u32x4_s*>(p) = u32x4_s{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+
+struct GemmFastArgs {
+    GemmArgs g;
+    float* slab;        // split-K partials [splits][M][N] fp32 (nullptr when splits == 1)
+    int k_per_split;    // multiple of 64
+    int vec_store;      // 1: C / residual rows allow 8-element vector accesses (N % 8 == 0, 16-byte aligned rows)
+};
+
+template <typename TC, int BM>
+__global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+    const GemmArgs& g = fa.g;
+    constexpr int BN = 128, BK = 64;
+    constexpr int TM = BM / 64;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32;               // 8-row chunks per wave per tile
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2][(BM + BN) * BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+    const int kbeg = blockIdx.y * fa.k_per_split;
+    const int kend = min(g.K, kbeg + fa.k_per_split);
+    const bf16_t* A = (const bf16_t*)g.A;
+    const bf16_t* W = (const bf16_t*)g.W;
+
+    // per-lane global sources of this wave's chunks (chunk c covers tile rows 8c..8c+7; lane -> row 8c + lane/8, slot lane%8)
+    const bf16_t* asrc[A_CH];
+    const bf16_t* bsrc[B_CH];
+    const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int r = (wave + 4 * i) * 8 + lrow;
+        const int kc = slot ^ ((r >> 1) & 7);
+        asrc[i] = A + (long)min(bm + r, g.M - 1) * g.lda + kbeg + kc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int r = (wave + 4 * i) * 8 + lrow;
+        const int kc = slot ^ ((r >> 1) & 7);
+        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + kbeg + kc * 8;
+    }
+    auto issue = [&](int buf, int koff) {
+        bf16_t* As = smem[buf];
+        bf16_t* Bs = smem[buf] + BM * BK;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + 4 * i) * 8 * BK);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + 4 * i) * 8 * BK);
+    };
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: row (lane&31) of a 32-row sub-tile, k-chunk (2*kk + hi) ^ f,  f = ((lane&31) >> 1) & 7
+    const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> 1) & 7;
+    const int a_row0 = wm * (BM / 2) + n32, b_row0 = wn * 64 + n32;
+
+    const int nk = (kend - kbeg) / BK;
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue(buf ^ 1, (kt + 1) * BK);
+        const bf16_t* As = smem[buf];
+        const bf16_t* Bs = smem[buf] + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((2 * kk + hi) ^ fsw) * 8;
+            bf16x8 af[TM], bfr[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
+    // per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
+    // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, 16 lanes per 128-column row.
+    float* Cs = reinterpret_cast<float*>(&smem[0][0]);           // [BM][BN] fp32 = BM*512 B <= sizeof(smem)
+    static_assert(sizeof(float) * BM * BN <= sizeof(bf16_t) * 2 * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                Cs[row * BN + wn * 64 + j * 32 + n32] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int c8 = (tid & 15) * 8;                               // this thread's 8 columns of the tile
+    const int col0 = bn + c8;
+    if (col0 >= g.N) return;
+    const bool split = fa.slab != nullptr;
+    const int act = g.act & 15;
+    const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
+    float bias8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bias8[c] = (!split && g.bias && col0 + c < g.N) ? g.bias[col0 + c] : 0.f;
+    TC* C = (TC*)g.C;
+    const TC* R = (const TC*)g.res;
+    float* P = split ? fa.slab + (long)blockIdx.y * g.M * g.N : nullptr;
+#pragma unroll 2
+    for (int it = 0; it < BM / 16; ++it) {
+        const int rl = it * 16 + (tid >> 4);
+        const int row = bm + rl;
+        if (row >= g.M) break;
+        const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
+        const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (split) {
+            float* dst = P + (long)row * g.N + col0;
+            if (fa.vec_store) {
+                reinterpret_cast<f32x4_g*>(dst)[0] = v0;
+                reinterpret_cast<f32x4_g*>(dst)[1] = v1;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];
+            }
+            continue;
+        }
+        float rres[8];
+        if (R) {
+            if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
+            else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rres[c] = col0 + c < g.N ? ldf(R + (long)row * g.ldr + col0 + c) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x = v[c] + bias8[c];
+            const bool do_act = act != ACT_NONE && col0 + c >= g.act_col_start;
+            if (do_act && !post) x = apply_act(x, act);
+            if (R) x += rres[c];
+            if (do_act && post) x = apply_act(x, act);
+            v[c] = x;
+        }
+        TC* dst = C + (long)row * g.ldc + col0;
+        if (fa.vec_store) store8(dst, v);
+        else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (col0 + c < g.N) stf(dst + c, v[c]);
+        }
+    }
+}
+
+// C = epilogue(sum_z slab[z]); one thread per 4 consecutive columns.
+template <typename TC>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ slab, int splits) {
+    const long n4 = (g.N + 3) / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)g.M * n4) return;
+    const int row = (int)(idx / n4), c0 = (int)(idx % n4) * 4;
+    const int act = g.act & 15;
+    const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
+    TC* C = (TC*)g.C;
+    const TC* R = (const TC*)g.res;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = (c0 + 3 < g.N) && (g.N % 4 == 0);
+    for (int z = 0; z < splits; ++z) {
+        const float* p = slab + ((long)z * g.M + row) * g.N + c0;
+        if (full) {
+            const f32x4_g t = *reinterpret_cast<const f32x4_g*>(p);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+            for (int i = 0; i < 4; ++i) if (c0 + i < g.N) v[i] += p[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = c0 + i;
+        if (col >= g.N) break;
+        float x = v[i] + (g.bias ? g.bias[col] : 0.f);
+        const bool do_act = act != ACT_NONE && col >= g.act_col_start;
+        if (do_act && !post) x = apply_act(x, act);
+        if (R) x += ldf(R + (long)row * g.ldr + col);
+        if (do_act && post) x = apply_act(x, act);
+        stf(C + (long)row * g.ldc + col, x);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- f32 MFMA (exact)
 template <typename TC, int BM>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
@@ -273,26 +501,71 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // C = act(A . W^T + bias) + residual.   A (M,K) lda, dtype a_dtype;  W (N,K) ldw, dtype w_dtype (selects the
 // arithmetic mode);  bias (N) f32 or NULL;  residual (M,N) ldr, dtype c_dtype, or NULL;  C (M,N) ldc, c_dtype.
 // Constraints: K % 8 == 0; 16-byte aligned row starts (lda*sizeof % 16 == 0 etc.);  w f32 requires a f32.
+// workspace (optional, workspace_bytes): scratch for split-K partials; without it small-grid GEMMs run un-split.
 extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
                           const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
-                          int act_col_start, void* stream) {
+                          int act_col_start, void* workspace, long workspace_bytes, void* stream) {
     if (M == 0 || N == 0) return 0;
     PSALM_CHECK_ARG(K > 0 && K % 8 == 0, "psalm_gemm: K must be a positive multiple of 8");
     const long asz = a_dtype == PSALM_F32 ? 4 : 2, wsz = w_dtype == PSALM_F32 ? 4 : 2;
     PSALM_CHECK_ARG(((uintptr_t)A % 16 == 0) && (lda * asz) % 16 == 0, "psalm_gemm: A rows must be 16-byte aligned");
     PSALM_CHECK_ARG(((uintptr_t)W % 16 == 0) && (ldw * wsz) % 16 == 0, "psalm_gemm: W rows must be 16-byte aligned");
     PSALM_CHECK_ARG(!(w_dtype == PSALM_F32 && a_dtype != PSALM_F32), "psalm_gemm: fp32 weights need fp32 activations");
+    PSALM_CHECK_ARG(c_dtype == PSALM_F32 || c_dtype == PSALM_BF16, "psalm_gemm: bad output dtype");
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.res = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.act = act; g.act_col_start = act_col_start;
     g.tiles_n = cdiv(N, 128);
+    hipStream_t s = (hipStream_t)stream;
+
+    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
+        // ---- direct-to-LDS fast path
+        const int BM = M > 192 ? 128 : 64;
+        g.tiles_m = cdiv(M, BM);
+        const long tiles = (long)g.tiles_m * g.tiles_n;
+        int splits = 1;
+        if (tiles < 200 && K >= 1024 && workspace) {
+            splits = (int)((448 + tiles - 1) / tiles);                       // aim at ~1.75 blocks per CU
+            if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
+            if (splits > 32) splits = 32;
+            const long per = (long)M * N * (long)sizeof(float);
+            if ((long)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+            if (splits < 2) splits = 1;
+        }
+        GemmFastArgs fa;
+        fa.g = g;
+        fa.k_per_split = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
+        if (splits > 1) splits = cdiv(K, fa.k_per_split);
+        fa.slab = splits > 1 ? (float*)workspace : nullptr;
+        const long csz = c_dtype == PSALM_F32 ? 4 : 2;
+        if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
+        else fa.vec_store = (N % 8 == 0 && (uintptr_t)C % 16 == 0 && (ldc * csz) % 16 == 0 &&
+                             (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * csz) % 16 == 0))) ? 1 : 0;
+        const dim3 grid((unsigned)tiles, splits), block(256);
+        // partials are fp32 regardless of TC; with split-K the kernel's TC only selects an (unused) epilogue
+        if (BM == 128) {
+            if (c_dtype == PSALM_F32 || splits > 1) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128>), grid, block, 0, s, fa);
+            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128>), grid, block, 0, s, fa);
+        } else {
+            if (c_dtype == PSALM_F32 || splits > 1) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 64>), grid, block, 0, s, fa);
+            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 64>), grid, block, 0, s, fa);
+        }
+        if (splits > 1) {
+            const long n4 = (N + 3) / 4;
+            const dim3 rgrid((unsigned)(((long)M * n4 + 255) / 256));
+            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, block, 0, s, g, (const float*)workspace, splits);
+            else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, block, 0, s, g, (const float*)workspace, splits);
+        }
+        PSALM_LAUNCH_END("psalm_gemm");
+    }
+
+    // ---- register-staged path (fp32 activations converted on the fly, odd K, or exact fp32 arithmetic)
     // 128-row tiles unless that leaves the 256 CUs under-filled
     const bool small = (long)cdiv(M, 128) * g.tiles_n < 256 || M <= 64;
     const int BM = small ? 64 : 128;
     g.tiles_m = cdiv(M, BM);
     const dim3 grid(g.tiles_m * g.tiles_n), block(256);
-    hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_BF16(TA, TC)                                                                             \
     do {                                                                                                \
         if (BM == 128) hipLaunchKernelGGL((gemm_bf16_kernel<TA, TC, 128>), grid, block, 0, s, g);     \
@@ -308,10 +581,10 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
         if (c_dtype == PSALM_F32) {
             if (BM == 128) hipLaunchKernelGGL((gemm_f32_kernel<float, 128>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_f32_kernel<float, 64>), grid, block, 0, s, g);
-        } else if (c_dtype == PSALM_BF16) {
+        } else {
             if (BM == 128) hipLaunchKernelGGL((gemm_f32_kernel<bf16_t, 128>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_f32_kernel<bf16_t, 64>), grid, block, 0, s, g);
-        } else { psalm_set_error("psalm_gemm: bad dtype"); return -1; }
+        }
     } else { psalm_set_error("psalm_gemm: bad weight dtype"); return -1; }
 #undef LAUNCH_BF16
     PSALM_LAUNCH_END("psalm_gemm");

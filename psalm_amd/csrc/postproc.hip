@@ -10,8 +10,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 // cls (Q, C1) fp32 logits (C1 = classes + void).  One wave per query.
 // probs (Q, C1); probsT (C1-1, Kpad) zero-padded beyond Q (A operand of the semantic GEMM, void column dropped,
 // LP:403); score[q] = max_c softmax, label[q] = argmax_c (first index on ties, like torch.max).
+template <typename TP>
 __global__ void __launch_bounds__(256) class_softmax_kernel(const float* __restrict__ cls, float* __restrict__ probs,
-                                                            float* __restrict__ probsT, float* __restrict__ score,
+                                                            TP* __restrict__ probsT, float* __restrict__ score,
                                                             int* __restrict__ label, int Q, int C1, int Kpad) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -33,16 +34,18 @@ __global__ void __launch_bounds__(256) class_softmax_kernel(const float* __restr
     for (int c = lane; c < C1; c += 64) {
         const float p = __expf(row[c] - gmx) * inv;
         probs[(long)q * C1 + c] = p;
-        if (c < C1 - 1) probsT[(long)c * Kpad + q] = p;
+        if (c < C1 - 1) stf(probsT + (long)c * Kpad + q, p);
     }
     if (lane == 0) { score[q] = inv; label[q] = cand; }     // exp(0) * inv
 }
 
-extern "C" int psalm_class_softmax(const float* cls, float* probs, float* probsT, float* score, int* label, int Q, int C1, int Kpad,
-                                   void* stream) {
+extern "C" int psalm_class_softmax(const float* cls, float* probs, void* probsT, int probsT_dtype, float* score, int* label, int Q,
+                                   int C1, int Kpad, void* stream) {
     if (Q == 0) return 0;
-    hipLaunchKernelGGL(class_softmax_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, cls, probs, probsT, score, label,
-                       Q, C1, Kpad);
+    PSALM_DISPATCH(probsT_dtype, TP, {
+        hipLaunchKernelGGL((class_softmax_kernel<TP>), dim3(cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, cls, probs, (TP*)probsT,
+                           score, label, Q, C1, Kpad);
+    });
     PSALM_LAUNCH_END("psalm_class_softmax");
 }
 

@@ -18,8 +18,8 @@ __device__ __forceinline__ void row_stats(const TI* __restrict__ x, int C, int l
 
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int rows, int C, float eps) {
+                                                        bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -27,15 +27,21 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
     float mean, rstd;
     row_stats(xr, C, lane, eps, mean, rstd);
     TO* yr = y + row * ldy;
-    for (int c = lane; c < C; c += 64) stf(yr + c, (ldf(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+    for (int c = lane; c < C; c += 64) {
+        const float v = (ldf(xr + c) - mean) * rstd * gamma[c] + beta[c];
+        stf(yr + c, v);
+        if (y2) y2[row * ldy2 + c] = f32_to_bf16(v);
+    }
 }
 
-extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, const float* gamma,
-                               const float* beta, int rows, int C, float eps, void* stream) {
+// y2 (optional, bf16, row stride ldy2): a second copy of the result in the GEMM operand dtype, so a fp32 residual
+// stream and the bf16 A operand of the next projection come out of one pass.
+extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
+                               const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
     if (rows == 0) return 0;
     PSALM_DISPATCH(x_dtype, TI, PSALM_DISPATCH(y_dtype, TO, {
         hipLaunchKernelGGL((layernorm_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const TI*)x, ldx, (TO*)y, ldy, gamma, beta, rows, C, eps);
+                           (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
     }));
     PSALM_LAUNCH_END("psalm_layernorm");
 }
@@ -190,54 +196,74 @@ __global__ void __launch_bounds__(256) groupnorm_stats_kernel(const TI* __restri
     }
 }
 
-template <typename TI, typename TO>
-__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const TI* __restrict__ x, TO* __restrict__ y,
-                                                              const float* __restrict__ partial,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              int HW, int C, int G, int nchunks, float eps, int relu) {
-    __shared__ float smean[256], srstd[256];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int cpg = C / G;
-    if (tid < G) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
-            const float* p = partial + (((long)b * nchunks + k) * G + tid) * 2;
-            s += p[0];
-            q += p[1];
-        }
-        const double n = (double)HW * cpg;
+// stage 2: one wavefront per (b, g) folds the chunk partials (double accumulation, fixed order -> deterministic)
+__global__ void __launch_bounds__(64) groupnorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                                int HW, int C, int G, int nchunks, float eps) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        const float* p = partial + (((long)b * nchunks + k) * G + g) * 2;
+        s += p[0];
+        q += p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) {
+        const double n = (double)HW * (C / G);
         const double m = s / n;
         double var = q / n - m * m;
         if (var < 0) var = 0;
-        smean[tid] = (float)m;
-        srstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    const long total = (long)HW * C;
-    for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int g = c / cpg;
-        float v = (ldf(x + (long)b * total + i) - smean[g]) * srstd[g] * gamma[c] + beta[c];
-        if (relu) v = fmaxf(v, 0.f);
-        stf(y + (long)b * total + i, v);
+        stats[((long)b * G + g) * 2] = (float)m;
+        stats[((long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
-// workspace: at least B * nchunks * G * 2 floats with nchunks = ceil(HW / 64)
+// stage 3: normalise, 8 consecutive channels per thread (16-byte bf16 / 2 x 16-byte fp32 accesses)
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const TI* __restrict__ x, TO* __restrict__ y,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int HW, int C, int G, int relu) {
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    const long total8 = (long)HW * C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c0 = (int)(e % C);
+        float v[8];
+        ld8(x + (long)b * HW * C + e, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k, g = c / cpg;
+            const float m = stats[((long)b * G + g) * 2], r = stats[((long)b * G + g) * 2 + 1];
+            float o = (v[k] - m) * r * gamma[c] + beta[c];
+            if (relu) o = fmaxf(o, 0.f);
+            v[k] = o;
+        }
+        st8(y + (long)b * HW * C + e, v);
+    }
+}
+
+// workspace: at least B * (nchunks + 1) * G * 2 floats with nchunks = ceil(HW / 64)
 extern "C" int psalm_groupnorm_nhwc(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
                                     float* workspace, int B, int HW, int C, int G, float eps, int relu, void* stream) {
     if (B == 0 || HW == 0) return 0;
-    PSALM_CHECK_ARG(G <= 256 && C % G == 0, "psalm_groupnorm_nhwc: need G <= 256 and C % G == 0");
+    PSALM_CHECK_ARG(G <= 256 && C % G == 0 && C % 8 == 0, "psalm_groupnorm_nhwc: need G <= 256, C % G == 0, C % 8 == 0");
+    PSALM_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "psalm_groupnorm_nhwc: 16-byte aligned tensors");
     const int rows_per_chunk = 64;
     const int nchunks = cdiv(HW, rows_per_chunk);
+    float* stats = workspace + (long)B * nchunks * G * 2;
+    hipStream_t s = (hipStream_t)stream;
     PSALM_DISPATCH(x_dtype, TI, {
-        hipLaunchKernelGGL((groupnorm_stats_kernel<TI>), dim3(nchunks, B), dim3(256), 0, (hipStream_t)stream, (const TI*)x,
-                           workspace, HW, C, G, rows_per_chunk, nchunks);
+        hipLaunchKernelGGL((groupnorm_stats_kernel<TI>), dim3(nchunks, B), dim3(256), 0, s, (const TI*)x, workspace, HW, C, G,
+                           rows_per_chunk, nchunks);
     });
-    const int gx = (int)(((long)HW * C + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(G, B), dim3(64), 0, s, workspace, stats, HW, C, G, nchunks, eps);
+    long gx = ((long)HW * C / 8 + 255) / 256;
+    if (gx > 8192) gx = 8192;
     PSALM_DISPATCH(x_dtype, TI, PSALM_DISPATCH(y_dtype, TO, {
-        hipLaunchKernelGGL((groupnorm_apply_kernel<TI, TO>), dim3(gx < 1 ? 1 : gx, B), dim3(256), 0, (hipStream_t)stream,
-                           (const TI*)x, (TO*)y, workspace, gamma, beta, HW, C, G, nchunks, eps, relu);
+        hipLaunchKernelGGL((groupnorm_apply_kernel<TI, TO>), dim3((unsigned)(gx < 1 ? 1 : gx), B), dim3(256), 0, s, (const TI*)x,
+                           (TO*)y, stats, gamma, beta, HW, C, G, relu);
     }));
     PSALM_LAUNCH_END("psalm_groupnorm_nhwc");
 }

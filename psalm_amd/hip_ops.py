@@ -46,7 +46,8 @@ class _ProfiledLib:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version"):
+        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version") or \
+                name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -82,6 +83,7 @@ class Ops:
         self.is_emu = self.backend == "emu"
         self.device = torch.device("cpu") if self.is_emu else torch.device("cuda", torch.cuda.current_device())
         self.lib_path = lib_path
+        self._ws = {}                      # cached kernel workspaces (device buffers owned by this binding)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -113,6 +115,15 @@ class Ops:
         if rc != 0:
             raise PsalmHipError(f"{name} failed (rc={rc}): {self.lib.psalm_last_error().decode()}")
 
+    GEMM_WS_BYTES = 96 << 20
+
+    def _gemm_ws(self):
+        """Caller-owned split-K scratch handed to psalm_gemm (one buffer for the life of the binding)."""
+        ws = self._ws.get("gemm")
+        if ws is None:
+            ws = self._ws["gemm"] = torch.empty(self.GEMM_WS_BYTES, dtype=torch.uint8, device=self.device)
+        return ws
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
@@ -139,17 +150,21 @@ class Ops:
             raise PsalmHipError("gemm bias must be float32 (N,)")
         rc = self.lib.psalm_gemm(self._pv(a), _dt(a), c_long(a.stride(0)), self._pv(w), _dt(w), c_long(w.stride(0)),
                                  self._pv(bias), self._pv(residual), c_long(residual.stride(0) if residual is not None else 0),
-                                 self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start, self._stream())
+                                 self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start,
+                                 self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm")
         return out
 
     # ------------------------------------------------------------------ row ops
-    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None):
-        """LayerNorm over the last dim of a 2-D (row-strided) view."""
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None, out2=None):
+        """LayerNorm over the last dim of a 2-D (row-strided) view.  out2: optional bf16 (rows,C) second copy."""
         rows, C = x.shape
         if out is None:
             out = self.empty(rows, C, dtype=out_dtype or x.dtype)
+        if out2 is not None and out2.dtype != torch.bfloat16:
+            raise PsalmHipError("layernorm: out2 must be bfloat16")
         rc = self.lib.psalm_layernorm(self._pv(x), _dt(x), c_long(x.stride(0)), self._pv(out), _dt(out), c_long(out.stride(0)),
+                                      self._pv(out2), c_long(out2.stride(0) if out2 is not None else 0),
                                       self._p(gamma), self._p(beta), rows, C, c_float(eps), self._stream())
         self._check(rc, "psalm_layernorm")
         return out
@@ -187,7 +202,7 @@ class Ops:
         C = x.shape[-1]
         if out is None:
             out = self.empty(B * HW, C, dtype=out_dtype or x.dtype)
-        ws = self.empty(B * ((HW + 63) // 64) * groups * 2, dtype=torch.float32)
+        ws = self.empty(B * ((HW + 63) // 64 + 1) * groups * 2, dtype=torch.float32)
         rc = self.lib.psalm_groupnorm_nhwc(self._p(x), _dt(x), self._p(out), _dt(out), self._p(gamma), self._p(beta), self._p(ws),
                                            B, HW, C, groups, c_float(eps), int(relu), self._stream())
         self._check(rc, "psalm_groupnorm_nhwc")
@@ -229,15 +244,33 @@ class Ops:
     def window_attention(self, qkv, bias_table, B, nWh, nWw, heads, ws, shift):
         C = qkv.shape[-1] // 3
         out = self.empty(qkv.shape[0], C, dtype=qkv.dtype)
+        if qkv.dtype == torch.bfloat16 and ws == 12:          # matrix-core kernel (bf16 mode)
+            rc = self.lib.psalm_window_attention_mfma(self._p(qkv), self._p(bias_table), self._p(out), B, nWh, nWw, C, heads, ws,
+                                                      shift, self._stream())
+            self._check(rc, "psalm_window_attention_mfma")
+            return out
         rc = self.lib.psalm_window_attention(self._p(qkv), self._p(bias_table), self._p(out), _dt(qkv), B, nWh, nWw, C, heads, ws,
                                              shift, self._stream())
         self._check(rc, "psalm_window_attention")
         return out
 
     def causal_attention(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot):
-        """buf (B*L, ld) holds q|k|v column blocks; out (B*L, ldo) receives the attention output at column o_off."""
+        """buf (B*L, ld) holds q|k|v column blocks; out (B*L, ldo) receives the attention output at column o_off.
+        bf16 buffers run on the matrix cores (psalm_causal_attention_mfma); fp32 buffers on the exact fp32 kernel."""
         if buf.dtype != out.dtype:
             raise PsalmHipError("causal_attention: buf/out dtype mismatch")
+        if buf.dtype == torch.bfloat16:
+            self.lib.psalm_causal_attention_mfma_workspace.restype = c_long
+            nbytes = self.lib.psalm_causal_attention_mfma_workspace(B, L, heads)
+            key = ("causal_ws", nbytes)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            rc = self.lib.psalm_causal_attention_mfma(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out),
+                                                      c_long(out.stride(0)), o_off, self._p(cos), self._p(sin), self._p(key_mask),
+                                                      self._p(ws), B, L, heads, head_dim, rot, self._stream())
+            self._check(rc, "psalm_causal_attention_mfma")
+            return out
         rc = self.lib.psalm_causal_attention(self._pv(buf), _dt(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out),
                                              c_long(out.stride(0)), o_off, self._p(cos), self._p(sin), self._p(key_mask), B, L,
                                              heads, head_dim, rot, self._stream())
@@ -316,15 +349,15 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ post-processing
-    def class_softmax(self, cls, Kpad):
+    def class_softmax(self, cls, Kpad, probsT_dtype=torch.float32):
         """cls (Q,C1) f32 -> probs (Q,C1), probsT (C1-1,Kpad) zero padded, score (Q), label (Q) i32."""
         Q, C1 = cls.shape
         probs = self.empty(Q, C1)
-        probsT = self.zeros(C1 - 1, Kpad)
+        probsT = self.zeros(C1 - 1, Kpad, dtype=probsT_dtype)
         score = self.empty(Q)
         label = self.empty(Q, dtype=torch.int32)
-        rc = self.lib.psalm_class_softmax(self._p(cls), self._p(probs), self._p(probsT), self._p(score), self._p(label), Q, C1, Kpad,
-                                          self._stream())
+        rc = self.lib.psalm_class_softmax(self._p(cls), self._p(probs), self._p(probsT), _dt(probsT), self._p(score), self._p(label),
+                                          Q, C1, Kpad, self._stream())
         self._check(rc, "psalm_class_softmax")
         return probs, probsT, score, label
 

@@ -451,17 +451,23 @@ class PSALM:
         if key not in self._cache:
             self._cache[key] = torch.cat([self._pos_embed(h, w_) + w["pd.level_embed"][l][None] for l, (h, w_) in enumerate(shapes)], 0).contiguous()
         lvl_pos = self._cache[key]
+        dual = self.adt == torch.bfloat16        # keep a bf16 copy of the fp32 token stream as the GEMM A operand
+        src_a = src                              # (first layer: fp32 A through the converting GEMM path)
         for i in range(cfg.md_enc_layers):
             q_ = f"pd.enc{i}."
             qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
-            value = o.gemm(src, w[q_ + "value.w"], w[q_ + "value.b"], out_dtype=self.adt)
+            value = o.gemm(src_a, w[q_ + "value.w"], w[q_ + "value.b"], out_dtype=self.adt)
             ow = o.gemm(qin, w[q_ + "ow.w"], w[q_ + "ow.b"], out_dtype=torch.float32)
             att = o.msda_fused(value.view(1, S, D), shapes, starts, ow.view(1, S, -1), M, out_dtype=self.adt).view(S, D)
+            mid_a = o.empty(S, D, dtype=self.adt) if dual else None
             src = o.layernorm(o.gemm(att, w[q_ + "out.w"], w[q_ + "out.b"], residual=src, out_dtype=torch.float32),
-                              w[q_ + "n1.g"], w[q_ + "n1.b"])
-            hdd = o.gemm(src, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+                              w[q_ + "n1.g"], w[q_ + "n1.b"], out2=mid_a)
+            hdd = o.gemm(mid_a if dual else src, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+            src_a = o.empty(S, D, dtype=self.adt) if dual else None
             src = o.layernorm(o.gemm(hdd, w[q_ + "l2.w"], w[q_ + "l2.b"], residual=src, out_dtype=torch.float32),
-                              w[q_ + "n2.g"], w[q_ + "n2.b"])
+                              w[q_ + "n2.g"], w[q_ + "n2.b"], out2=src_a)
+            if not dual:
+                src_a = src
         ms = [src[starts[l]: starts[l] + h * w_] for l, (h, w_) in enumerate(shapes)]
         tok2, H2, W2 = feats[0]
         lat = o.gemm(tok2, w["pd.adapter.w"], w["pd.adapter.b"], out_dtype=self.adt)
@@ -636,8 +642,8 @@ class PSALM:
         if task == "panoptic":
             cls = r["pred_class_name_logits"]
             C1 = cls.shape[1]
-            Kpad = (Q + 31) // 32 * 32
-            probs, probsT, score, label = o.class_softmax(cls, Kpad)
+            Kpad = (Q + 63) // 64 * 64                                   # K of the semantic GEMM (direct-to-LDS path: K % 64 == 0)
+            probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
             sigT = o.sigmoid_transpose(mflat, Kpad, self.wdt)
             res["sem_seg"] = o.gemm(probsT, sigT, out_dtype=torch.float32).view(C1 - 1, height, width)       # LP:402-406
             mscore = o.mask_scores(mflat)

@@ -252,6 +252,27 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float __saturatef(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
 
+// ---------------------------------------------------------------- direct global -> LDS copy (global_load_lds_dwordx4)
+// Hardware semantics (guide §5): LDS destination = WAVE-UNIFORM base (M0) + lane * size; the global source is per lane.
+// The stand-in checks that every live lane passes the same base, then copies `size` bytes for this lane.
+namespace emu {
+inline void global_load_lds(const void* g, void* lds_wave_base, int size) {
+    const void* mine = lds_wave_base;
+    const int lane = cur()->lin % 64;
+    const void* const* all = wave_gather(&mine);
+    Block* b = blk();
+    for (int i = 0; i < 64; ++i) {
+        int lin = (cur()->lin / 64) * 64 + i;
+        if (lin < (int)b->fibers.size() && !b->fibers[lin].done && *(void* const*)all[i] != lds_wave_base) {
+            fprintf(stderr, "[hip-emu] global_load_lds: LDS base is not wave-uniform\n");
+            abort();
+        }
+    }
+    wave_done();
+    memcpy((char*)lds_wave_base + (size_t)lane * size, g, size);
+}
+}  // namespace emu
+
 // ---------------------------------------------------------------- MFMA
 namespace emu {
 typedef float f32x16_t __attribute__((ext_vector_type(16)));

@@ -10,6 +10,11 @@ def _ref(a, w, bias, res, act, act_col_start):
     y = a.double() @ w.double().t()
     if bias is not None:
         y = y + bias.double()
+    post = bool(act & H.ACT_POST_RESIDUAL)
+    act &= 15
+    if post:
+        y = y + res.double()
+        res = None
     if act:
         f = {H.ACT_RELU: torch.relu, H.ACT_GELU: torch.nn.functional.gelu,
              H.ACT_GELU_NEW: lambda v: torch.nn.functional.gelu(v, approximate="tanh")}[act]
@@ -28,6 +33,15 @@ CASES = [
     (64, 136, 32, "f32", "f32", "f32", True, True, H.ACT_GELU, 0),
     (150, 129, 24, "f32", "f32", "f32", False, False, H.ACT_NONE, 0),
     (1, 8, 8, "f32", "f32", "bf16", True, False, H.ACT_RELU, 0),
+    # direct-to-LDS fast path (A, W bf16, K % 64 == 0): 64- and 128-row tiles, ragged M/N edges, fused epilogues
+    (100, 200, 64, "bf16", "bf16", "bf16", True, False, H.ACT_GELU, 0),
+    (300, 130, 128, "bf16", "bf16", "f32", True, True, H.ACT_RELU, 0),
+    (257, 260, 192, "bf16", "bf16", "bf16", True, True, H.ACT_GELU_NEW, 128),
+    (33, 8, 64, "bf16", "bf16", "f32", False, False, H.ACT_NONE, 0),
+    # ... with split-K (small tile grid, long K): partial slabs + reduce-epilogue kernel
+    (70, 130, 1024, "bf16", "bf16", "f32", True, True, H.ACT_NONE, 0),
+    (200, 100, 2048, "bf16", "bf16", "bf16", True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 0),
+    (65, 129, 1088, "bf16", "bf16", "bf16", False, False, H.ACT_GELU, 64),
 ]
 DT = {"f32": torch.float32, "bf16": torch.bfloat16}
 
@@ -62,3 +76,17 @@ def test_gemm_strided_views(ops):
     want = big_a[:, 64:96].cpu().bfloat16().double() @ w.cpu().double().t()
     assert (big_c[:, 8:48].cpu().double() - want).abs().max() < 1e-4
     assert big_c[:, :8].abs().max() == 0 and big_c[:, 48:].abs().max() == 0
+
+
+def test_gemm_fast_path_strided_views(ops):
+    """bf16 A / C as column slices of a wider buffer through the direct-to-LDS kernel (Phi: big[:, 2H:] -> x)."""
+    g = torch.Generator().manual_seed(1)
+    d = ops.device
+    big_a = (torch.randn(90, 200, generator=g)).bfloat16().to(d)
+    w = (torch.randn(72, 128, generator=g) * 0.3).bfloat16().to(d)
+    big_c = torch.zeros(90, 104, dtype=torch.bfloat16, device=d)
+    ops.gemm(big_a[:, 72:200], w, out=big_c[:, 16:88])
+    want = big_a[:, 72:200].cpu().double() @ w.cpu().double().t()
+    err = (big_c[:, 16:88].cpu().double() - want).abs().max()
+    assert err <= 2 ** -8 * want.abs().max()
+    assert big_c[:, :16].abs().max() == 0 and big_c[:, 88:].abs().max() == 0

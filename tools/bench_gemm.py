@@ -1,0 +1,63 @@
+"""Per-shape GEMM timing on the GPU (HIP events on the launch stream): the contractions of one 1024x1024 panoptic image.
+    python tools/bench_gemm.py [--json out.json]"""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from psalm_amd.hip_ops import get_ops  # noqa: E402
+
+SHAPES = [  # name, M, N, K, out dtype
+    ("phi.w1 [k|v|q|fc1]", 901, 14336, 2048, torch.bfloat16),
+    ("phi.w2 [dense|fc2]", 901, 2048, 10240, torch.float32),
+    ("swin0.qkv", 69696, 384, 128, torch.bfloat16),
+    ("swin0.fc1", 65536, 512, 128, torch.bfloat16),
+    ("swin0.fc2", 65536, 128, 512, torch.float32),
+    ("swin1.qkv", 17424, 768, 256, torch.bfloat16),
+    ("swin2.qkv", 5184, 1536, 512, torch.bfloat16),
+    ("swin2.proj", 5184, 512, 512, torch.bfloat16),
+    ("swin2.fc1", 4096, 2048, 512, torch.bfloat16),
+    ("swin2.fc2", 4096, 512, 2048, torch.float32),
+    ("swin3.fc1", 1024, 4096, 1024, torch.bfloat16),
+    ("proj.conv2", 256, 2048, 18432, torch.bfloat16),
+    ("pd.value", 21504, 256, 256, torch.bfloat16),
+    ("pd.l1", 21504, 1024, 256, torch.bfloat16),
+    ("pd.l2", 21504, 256, 1024, torch.float32),
+    ("pd.fpn3x3", 65536, 256, 2304, torch.bfloat16),
+    ("pr.mask_einsum", 100, 65536, 256, torch.float32),
+    ("pr.lvl2.kv", 16384, 768, 256, torch.bfloat16),
+    ("square4096", 4096, 4096, 4096, torch.bfloat16),
+]
+
+
+def main():
+    ops = get_ops()
+    res = []
+    for name, M, N, K, cdt in SHAPES:
+        a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+        w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+        bias = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=cdt)
+        for _ in range(3):
+            ops.gemm(a, w, bias, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.gemm(a, w, bias, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+        gb = (M * K * 2 + N * K * 2 + M * N * out.element_size()) / (us * 1e-6) / 1e9
+        res.append({"name": name, "M": M, "N": N, "K": K, "us": round(us, 1), "TFLOPs": round(tf, 1), "GBps": round(gb, 0)})
+        print(f"{name:22s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:7.1f} TF/s  {gb:7.0f} GB/s")
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
