@@ -49,6 +49,7 @@ int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_
  * Dense contractions (every nn.Linear / 1x1 conv / im2col'd conv / einsum of the path).
  * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]   (nn.Linear weight layout, W is [out,in]).
  *   act: 0 none, 1 relu, 2 gelu(erf), 3 gelu_new(tanh); |16 = apply after the residual add (ResNet block);
+ *   |32 = bias is indexed by the output row (bias[M]) instead of the column -- transposed projections C = W . X^T;
  *   activation applies to columns >= act_col_start only (fused [k|v|q|fc1] projection of a Phi layer).
  *   w_dtype selects the arithmetic: BF16 -> v_mfma_f32_32x32x16_bf16 / fp32 accumulate (A f32 or bf16, converted
  *   while staging); F32 -> v_mfma_f32_32x32x2_f32 (exact fp32; A must be f32).  lda/ldw/ldr/ldc are row strides in
@@ -62,6 +63,9 @@ int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_
 int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
                const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
                int act_col_start, void* workspace, long workspace_bytes, void* stream);
+
+/* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM. */
+int psalm_gemm_set_tile_policy(int bm);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Row / normalisation kernels (one 64-lane wavefront per row, fp32 statistics). */
@@ -124,6 +128,14 @@ int psalm_causal_attention_mfma(const void* qkv, long ld, int q_off, int k_off, 
 int psalm_mha_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out, long ldo,
                         int dtype, const unsigned char* mask, const unsigned char* row_all_masked, int B, int Lq, int Lk,
                         int heads, int head_dim, void* stream);
+/* The same on the matrix cores (bf16), split over the key axis so that 8 heads x S splits fill the chip; V is passed
+ * TRANSPOSED: vt (B*heads*32, ldvt), row h*32+d, columns = keys, zero-padded to ldvt >= ceil(Lk/8)*8 (the value projection
+ * GEMM with swapped operands writes it directly).  Lq <= 128; masked attention needs Lk % 4 == 0.
+ * workspace: psalm_mha_attention_mfma_workspace(B, heads, Lk) bytes. */
+long psalm_mha_attention_mfma_workspace(int B, int heads, int Lk);
+int psalm_mha_attention_mfma(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                             const unsigned char* mask, const unsigned char* row_all_masked, void* workspace, int B, int Lq,
+                             int Lk, int heads, int head_dim, void* stream);
 /* forward_prediction_heads' attention-mask branch (mask2former_transformer_decoder.py:754-760): bilinear resize of the
  * mask logits to (Ht,Wt), sigmoid < 0.5, plus the all-masked row flags. */
 int psalm_attn_mask(const float* masks, unsigned char* out, unsigned char* row_all_masked, int BQ, int h, int w, int Ht,

@@ -1,9 +1,10 @@
 // Matrix-core (MFMA) attention kernels for the bf16 mode of the PSALM path (gfx950, 64-lane wavefronts).
 //
 //   psalm_causal_attention_mfma   Phi prefill attention (modeling_phi.py:189-245, eager softmax :137-160, RoPE :92-122)
+//   psalm_mha_attention_mfma      predictor cross / self attention, split over keys (mask2former_transformer_decoder.py:645-666)
 //   psalm_window_attention_mfma   Swin (shifted-)window attention, 12x12 windows, head_dim 32 (swin_trans.py:117-149,369-387)
 //
-// Formulation ("swapped QK^T", one wavefront per 32-query tile, no LDS, no barriers):
+// Formulation ("swapped QK^T", one wavefront per 32-query tile):
 //   S^T[key][q]  = K . Q^T      v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q rows
 //                  -> a lane owns ONE query column (lane & 31) and 16 keys per 32-key sub-tile, so the softmax
 //                     row statistics are lane-local (one exchange with lane ^ 32 per 64-key tile) and the
@@ -14,10 +15,9 @@
 //                     (key = 16*ks + 8*(j>>2) + 4*hi + (j&3)); V^T is then read as two 8-byte runs per operand and no
 //                     cross-lane shuffle or LDS transpose of P is needed.
 // A small pre-pass (phi_qkv_prep_kernel) applies the partial RoPE, folds 1/sqrt(d) into Q, and lays the three operands
-// out head-major with the contraction index contiguous: Qr/Kr (b,h,token,64) and Vt (b,h,64,token) -- every MFMA operand
-// is then a plain 16-byte (8-byte for V^T) global load, L2-resident (K+V of one head at L=1024: 256 KB).
-// Keys are processed 64 per iteration with the next tile's operands prefetched into registers during the current
-// tile's MFMAs (the grid gives about one wave per SIMD, so latency is hidden by ILP, not occupancy).
+// out head-major with the contraction index contiguous: Qr/Kr (b,h,token,64) and Vt (b,h,64,token), so K and V^T tiles
+// are both plain row-major [64][64] bf16 images that go global -> LDS with global_load_lds (shared by the 4 waves of a
+// block, double-buffered, the next tile in flight during the current tile's MFMAs).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -109,49 +109,49 @@ __global__ void __launch_bounds__(256) phi_qkv_prep_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- main kernel
-struct KVFrag {
-    u32x4_a k[2][4];        // [sub-tile of 32 keys][k-step over d]   A operand of S^T = K . Q^T
-    u32x2_a v[2][2][2][2];  // [sub-tile][k-step of 16 keys][d tile][8-byte half]   A operand of O^T += V^T . P^T
-};
-
-__device__ __forceinline__ void load_kv(KVFrag& f, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vh, int Lp, int k0,
-                                        int lane) {
-    const int n = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            f.k[s][kk] = *reinterpret_cast<const u32x4_a*>(Kh + (long)(k0 + 32 * s + n) * 64 + 16 * kk + 8 * hi);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16_t* p = Vh + (long)(32 * dt + n) * Lp + k0 + 32 * s + 16 * ks + 4 * hi;
-                f.v[s][ks][dt][0] = *reinterpret_cast<const u32x2_a*>(p);
-                f.v[s][ks][dt][1] = *reinterpret_cast<const u32x2_a*>(p + 8);
-            }
-    }
-}
-
-// grid (ceil(L/32), heads, B), block 64 (one wavefront).  Heaviest (last) query tiles are scheduled first.
-__global__ void __launch_bounds__(64) causal_attention_mfma_kernel(const bf16_t* __restrict__ Qr, const bf16_t* __restrict__ Kr,
-                                                                   const bf16_t* __restrict__ Vt,
-                                                                   const unsigned char* __restrict__ key_mask,
-                                                                   bf16_t* __restrict__ out, long ldo, int o_off, int L, int Lp,
-                                                                   int heads) {
-    const int lane = threadIdx.x & 63, n = lane & 31, hi = lane >> 5;
-    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q0 = qt * 32;
+// grid (ceil(L/128), heads, B), block 256 = 4 wavefronts x 32 queries.  Heaviest (last) query blocks are scheduled first.
+// K / V^T tiles of 64 keys are shared by the 4 waves through LDS: global_load_lds_dwordx4 into a double buffer, one
+// barrier per tile; both images are [64 rows][64 bf16] with 128-byte rows and the same XOR swizzle as the GEMM operand
+// tiles (16-byte slot p of row r holds chunk p ^ ((r >> 1) & 7), applied to the per-lane global source address).
+__global__ void __launch_bounds__(256) causal_attention_mfma_kernel(const bf16_t* __restrict__ Qr, const bf16_t* __restrict__ Kr,
+                                                                    const bf16_t* __restrict__ Vt,
+                                                                    const unsigned char* __restrict__ key_mask,
+                                                                    bf16_t* __restrict__ out, long ldo, int o_off, int L, int Lp,
+                                                                    int heads) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2][2 * 64 * 64];     // [stage][K tile | V^T tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = qb * 128 + wave * 32;
     const long bh = (long)b * heads + h;
     const bf16_t* Qh = Qr + bh * Lp * 64;
     const bf16_t* Kh = Kr + bh * Lp * 64;
     const bf16_t* Vh = Vt + bh * 64 * Lp;
     const int qi = q0 + n;                                     // this lane's query (rows >= L are zero padding)
+    const int qrow = min(qi, Lp - 1);
 
     bf16x8 bq[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-        bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a*>(Qh + (long)qi * 64 + 16 * kk + 8 * hi));
+        bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a*>(Qh + (long)qrow * 64 + 16 * kk + 8 * hi));
+
+    // per-lane sources of this wave's 1 KiB chunks: K chunks {wave, wave+4} (8 keys each), V^T chunks {wave, wave+4} (8 d rows)
+    const int lrow = lane >> 3, slot = lane & 7;
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 4 * i) * 8 + lrow;
+        const int c = (slot ^ ((r >> 1) & 7)) * 8;
+        ksrc[i] = Kh + (long)r * 64 + c;                        // + k0 * 64 per tile
+        vsrc[i] = Vh + (long)r * Lp + c;                        // + k0 per tile
+    }
+    auto issue = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            psalm_glds16(ksrc[i] + (long)k0 * 64, &smem[buf][(wave + 4 * i) * 8 * 64]);
+            psalm_glds16(vsrc[i] + k0, &smem[buf][64 * 64 + (wave + 4 * i) * 8 * 64]);
+        }
+    };
 
     f32x16 o[2];
 #pragma unroll
@@ -160,18 +160,21 @@ __global__ void __launch_bounds__(64) causal_attention_mfma_kernel(const bf16_t*
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     constexpr float NEG = -1.0e30f;
     float m = NEG, l = 0.f;
+    const int fsw = (n >> 1) & 7;
 
-    const int last_q = min(L - 1, q0 + 31);
-    const int ntiles = last_q / 64 + 1;
-    KVFrag cur, nxt;
-    load_kv(cur, Kh, Vh, Lp, 0, lane);
+    const int last_q = min(L - 1, qb * 128 + 127);
+    const int ntiles = last_q / 64 + 1;                         // key tiles needed by the block's last query
+    issue(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * 64;
-        if (kt + 1 < ntiles) load_kv(nxt, Kh, Vh, Lp, k0 + 64, lane);
+        const int k0 = kt * 64, buf = kt & 1;
+        __syncthreads();                                        // tile kt landed (vmcnt(0)); everyone is done with the other buffer
+        if (kt + 1 < ntiles) issue(buf ^ 1, k0 + 64);
+        if (k0 > q0 + 31) continue;                             // tile entirely in this wave's future (uniform per wave)
+        const bf16_t* Ks = smem[buf];
+        const bf16_t* Vs = smem[buf] + 64 * 64;
         // key-padding mask of this tile as a wave-uniform 64-bit set (bit j <-> key k0 + j)
         const int kj = k0 + lane;
         const unsigned long long kbits = __ballot(kj < L && key_mask[(long)b * L + kj] != 0);
-
         const unsigned long long kb_hi = kbits >> (4 * hi);
 
         f32x16 s[2];
@@ -180,8 +183,11 @@ __global__ void __launch_bounds__(64) causal_attention_mfma_kernel(const bf16_t*
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.k[t][kk]), bq[kk], s[t], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 ka = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4_a*>(&Ks[(32 * t + n) * 64 + (((2 * kk + hi) ^ fsw) * 8)]));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, bq[kk], s[t], 0, 0, 0);
+            }
         }
         // mask + tile max
         float mloc = NEG;
@@ -224,12 +230,14 @@ __global__ void __launch_bounds__(64) causal_attention_mfma_kernel(const bf16_t*
                 const bf16x8 pfrag = __builtin_bit_cast(bf16x8, u32x4_a{pb[t][ks][0], pb[t][ks][1], pb[t][ks][2], pb[t][ks][3]});
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 vfrag = __builtin_bit_cast(
-                        bf16x8, u32x4_a{cur.v[t][ks][dt][0].x, cur.v[t][ks][dt][0].y, cur.v[t][ks][dt][1].x, cur.v[t][ks][dt][1].y});
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pfrag, o[dt], 0, 0, 0);
+                    // V^T row d = 32*dt + n; keys 32t + 16ks + 4hi + {0..3} and + 8: chunks c0 = 4t + 2ks, c0 + 1
+                    const bf16_t* vrow = &Vs[(32 * dt + n) * 64 + 4 * hi];
+                    const u32x2_a v0 = *reinterpret_cast<const u32x2_a*>(vrow + (((4 * t + 2 * ks) ^ fsw) * 8));
+                    const u32x2_a v1 = *reinterpret_cast<const u32x2_a*>(vrow + (((4 * t + 2 * ks + 1) ^ fsw) * 8));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4_a{v0.x, v0.y, v1.x, v1.y}), pfrag,
+                                                                    o[dt], 0, 0, 0);
                 }
             }
-        if (kt + 1 < ntiles) cur = nxt;
     }
     const float ltot = l + __shfl_xor(l, 32);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
@@ -274,7 +282,7 @@ extern "C" int psalm_causal_attention_mfma(const void* qkv, long ld, int q_off, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phi_qkv_prep_kernel, dim3(Lp / 64, heads, B), dim3(256), 0, s, (const bf16_t*)qkv, ld, q_off, k_off, v_off,
                        cos_table, sin_table, Qr, Kr, Vt, L, Lp, heads, 1.0f / sqrtf((float)head_dim));
-    hipLaunchKernelGGL(causal_attention_mfma_kernel, dim3(cdiv(L, 32), heads, B), dim3(64), 0, s, Qr, Kr, Vt, key_mask,
+    hipLaunchKernelGGL(causal_attention_mfma_kernel, dim3(cdiv(L, 128), heads, B), dim3(256), 0, s, Qr, Kr, Vt, key_mask,
                        (bf16_t*)out, ldo, o_off, L, Lp, heads);
     PSALM_LAUNCH_END("psalm_causal_attention_mfma");
 }
@@ -425,4 +433,203 @@ extern "C" int psalm_window_attention_mfma(const void* qkv, const float* bias_ta
     hipLaunchKernelGGL((window_attention_mfma_kernel<12>), dim3(nwin, heads), dim3(320), 0, (hipStream_t)stream, (const bf16_t*)qkv,
                        bias_table, (bf16_t*)out, nWh, nWw, C, heads, shift);
     PSALM_LAUNCH_END("psalm_window_attention_mfma");
+}
+
+
+// ============================================================================================ predictor MHA (split-KV)
+// nn.MultiheadAttention core for <= 128 queries (Mask2Former: 100) against Lk keys (HW of a feature level, or the 100
+// queries themselves), head_dim 32.  The key axis is split over blockIdx.x so that 8 heads x S splits fill the chip;
+// each block (4 waves x 32 queries) streams its keys in 64-key tiles through LDS (global_load_lds, double-buffered):
+//   K tile  [64 keys][32 d]  64-byte rows,  16-byte slot p of row r holds d-chunk  p ^ ((r >> 2) & 3)
+//   V^T tile [32 d][64 keys] 128-byte rows, slot p of row r holds key-chunk        p ^ ((r >> 1) & 7)
+// V arrives TRANSPOSED (Vt (heads*32, ldvt): produced by the value projection GEMM with swapped operands), so both
+// images are row-major copies.  Swapped-operand MFMAs as in the kernels above.  With S > 1 each block writes its
+// un-normalised partial (O, m, l); mha_combine_kernel merges them.  mask (Lq, Lk) u8 1 = blocked, ignored for rows
+// flagged in row_all_masked (mask2former_transformer_decoder.py:647).
+__global__ void __launch_bounds__(256) mha_attention_mfma_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+                                                                 long ldk, const bf16_t* __restrict__ Vt, long ldvt,
+                                                                 const unsigned char* __restrict__ mask,
+                                                                 const unsigned char* __restrict__ row_all_masked,
+                                                                 bf16_t* __restrict__ out, long ldo, float* __restrict__ part_o,
+                                                                 float* __restrict__ part_ml, int Lq, int Lk, int heads,
+                                                                 int keys_per_split, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2][2 * 64 * 32];     // [stage][K tile (2048) | V^T tile (2048)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
+    const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z, S = gridDim.x;
+    const int kbeg = sp * keys_per_split, kend = min(Lk, kbeg + keys_per_split);
+    const int qi = 32 * wave + n;
+    const int qc = min(qi, Lq - 1);
+    const bf16_t* Qb = Q + (long)b * Lq * ldq;
+    const bf16_t* Kb = K + (long)b * Lk * ldk;
+    const bf16_t* Vb = Vt + (long)b * heads * 32 * ldvt;
+    bf16x8 bq[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+        bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a*>(Qb + (long)qc * ldq + h * 32 + 16 * kk + 8 * hi));
+    const unsigned char* mrow = nullptr;
+    if (mask && !(row_all_masked && row_all_masked[(long)b * Lq + qc])) mrow = mask + ((long)b * Lq + qc) * Lk;
+
+    // this wave's chunks: K chunk `wave` (16 keys x 64 B), V^T chunk `wave` (8 d rows x 128 B)
+    const int krow = 16 * wave + (lane >> 2), kslot = lane & 3;
+    const int kdch = (kslot ^ ((krow >> 2) & 3)) * 8;
+    const int vrow = 8 * wave + (lane >> 3), vslot = lane & 7;
+    const int vch = (vslot ^ ((vrow >> 1) & 7)) * 8;
+    const bf16_t* vsrc = Vb + (long)(h * 32 + vrow) * ldvt;
+    auto issue = [&](int buf, int k0) {
+        psalm_glds16(Kb + (long)min(k0 + krow, Lk - 1) * ldk + h * 32 + kdch, &smem[buf][wave * 16 * 32]);
+        psalm_glds16(vsrc + min(k0 + vch, (int)ldvt - 8), &smem[buf][64 * 32 + wave * 8 * 64]);
+    };
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    constexpr float NEG = -1.0e30f;
+    float m = NEG, l = 0.f;
+    const int fk = (n >> 2) & 3, fv = (n >> 1) & 7;
+    const int ntiles = (kend - kbeg + 63) / 64;
+    if (ntiles > 0) issue(0, kbeg);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kbeg + kt * 64, buf = kt & 1;
+        __syncthreads();
+        if (kt + 1 < ntiles) issue(buf ^ 1, k0 + 64);
+        const bf16_t* Ks = smem[buf];
+        const bf16_t* Vs = smem[buf] + 64 * 32;
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_a*>(&Ks[(32 * t + n) * 32 + (((2 * kk + hi) ^ fk) * 8)]));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, bq[kk], s[t], 0, 0, 0);
+            }
+        }
+        float mloc = NEG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kj = k0 + 32 * t + 8 * g + 4 * hi;            // keys kj..kj+3 live in accumulator registers 4g..4g+3
+                unsigned mw = 0;
+                if (mrow && kj < Lk) mw = *reinterpret_cast<const unsigned*>(mrow + kj);     // Lk % 4 == 0 (checked on the host)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (kj + i < kend) && !((mw >> (8 * i)) & 0xffu);
+                    const float v = ok ? s[t][4 * g + i] * scale : NEG;
+                    s[t][4 * g + i] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float mn = fmaxf(m, mloc);
+        const float alpha = __expf(m - mn);
+        m = mn;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned pb[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float x0 = s[t][8 * ks + 2 * jj], x1 = s[t][8 * ks + 2 * jj + 1];
+                    const float p0 = x0 > 0.5f * NEG ? __expf(x0 - mn) : 0.f;
+                    const float p1 = x1 > 0.5f * NEG ? __expf(x1 - mn) : 0.f;
+                    psum += p0 + p1;
+                    pb[jj] = pk2(p0, p1);
+                }
+                const bf16_t* vr = &Vs[n * 64 + 4 * hi];
+                const u32x2_a v0 = *reinterpret_cast<const u32x2_a*>(vr + (((4 * t + 2 * ks) ^ fv) * 8));
+                const u32x2_a v1 = *reinterpret_cast<const u32x2_a*>(vr + (((4 * t + 2 * ks + 1) ^ fv) * 8));
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4_a{v0.x, v0.y, v1.x, v1.y}),
+                                                            __builtin_bit_cast(bf16x8, u32x4_a{pb[0], pb[1], pb[2], pb[3]}), o, 0, 0, 0);
+            }
+        l = l * alpha + psum;
+    }
+    const float ltot = l + __shfl_xor(l, 32);
+    if (S == 1) {
+        if (qi < Lq) {
+            const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+            bf16_t* op = out + ((long)b * Lq + qi) * ldo + h * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<u32x2_a*>(op + 8 * g + 4 * hi) =
+                    u32x2_a{pk2(o[4 * g] * inv, o[4 * g + 1] * inv), pk2(o[4 * g + 2] * inv, o[4 * g + 3] * inv)};
+        }
+        return;
+    }
+    // partials: part_o [b][h][split][128 q][32 d] fp32, part_ml [b][h][split][128][2]
+    const long pbase = (((long)b * heads + h) * S + sp) * 128 + qi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<psalm_f32x4*>(part_o + pbase * 32 + 8 * g + 4 * hi) = psalm_f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    if (hi == 0) { part_ml[pbase * 2] = m; part_ml[pbase * 2 + 1] = ltot; }
+}
+
+// one thread per (b, q, h, d): merge the S partial softmax states
+__global__ void __launch_bounds__(256) mha_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                          bf16_t* __restrict__ out, long ldo, int B, int Lq, int heads, int S) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Lq * heads * 32) return;
+    const int d = (int)(idx & 31);
+    long t = idx >> 5;
+    const int h = (int)(t % heads);
+    t /= heads;
+    const int q = (int)(t % Lq), b = (int)(t / Lq);
+    const long base = ((long)b * heads + h) * S * 128 + q;
+    float mx = -1.0e30f;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, part_ml[(base + (long)s * 128) * 2]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const long p = base + (long)s * 128;
+        const float ms = part_ml[p * 2], ls = part_ml[p * 2 + 1];
+        const float f = ls > 0.f ? __expf(ms - mx) : 0.f;
+        den += ls * f;
+        num += part_o[p * 32 + d] * f;
+    }
+    out[((long)b * Lq + q) * ldo + h * 32 + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
+}
+
+// q (B*Lq, *) row stride ldq;  k (B*Lk, *) row stride ldk;  vt (B*heads*32, ldvt): V TRANSPOSED, row (h*32+d), columns = keys,
+// zero-padded to ldvt >= ceil(Lk/8)*8;  out (B*Lq, heads*32) row stride ldo, bf16.  Lq <= 128, head_dim 32.
+// mask (B,Lq,Lk) u8 (needs Lk % 4 == 0) / row_all_masked (B,Lq) u8, both optional.
+// workspace: psalm_mha_attention_mfma_workspace(B, heads, Lk) bytes (split-KV partials).
+static int mha_splits(int heads, int B, int Lk) {
+    int S = (512 + heads * B - 1) / (heads * B);                 // ~2 blocks per CU
+    const int maxS = (Lk + 63) / 64;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S;
+}
+extern "C" long psalm_mha_attention_mfma_workspace(int B, int heads, int Lk) {
+    const long S = mha_splits(heads, B, Lk);
+    return S > 1 ? (long)B * heads * S * 128 * (32 + 2) * (long)sizeof(float) : 0;
+}
+extern "C" int psalm_mha_attention_mfma(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out,
+                                        long ldo, const unsigned char* mask, const unsigned char* row_all_masked, void* workspace,
+                                        int B, int Lq, int Lk, int heads, int head_dim, void* stream) {
+    PSALM_CHECK_ARG(head_dim == 32, "psalm_mha_attention_mfma: head_dim must be 32");
+    PSALM_CHECK_ARG(Lq >= 1 && Lq <= 128, "psalm_mha_attention_mfma: 1 <= Lq <= 128");
+    PSALM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= (Lk + 7) / 8 * 8 &&
+                        (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)vt % 16 == 0 && (uintptr_t)out % 8 == 0,
+                    "psalm_mha_attention_mfma: operand alignment (row strides multiples of 8 elements, 16-byte bases)");
+    PSALM_CHECK_ARG(!mask || Lk % 4 == 0, "psalm_mha_attention_mfma: masked attention needs Lk % 4 == 0");
+    if (B == 0 || Lk == 0) return 0;
+    const int S = mha_splits(heads, B, Lk);
+    PSALM_CHECK_ARG(S == 1 || workspace, "psalm_mha_attention_mfma: workspace required");
+    int kps = ((Lk + S - 1) / S + 63) / 64 * 64;
+    const int Seff = (Lk + kps - 1) / kps;
+    float* po = (float*)workspace;
+    float* pml = po ? po + (long)B * heads * Seff * 128 * 32 : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mha_attention_mfma_kernel, dim3(Seff, heads, B), dim3(256), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                       (const bf16_t*)vt, ldvt, mask, row_all_masked, (bf16_t*)out, ldo, po, pml, Lq, Lk, heads, kps,
+                       1.0f / sqrtf((float)head_dim));
+    if (Seff > 1)
+        hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)(((long)B * Lq * heads * 32 + 255) / 256)), dim3(256), 0, st, po, pml,
+                           (bf16_t*)out, ldo, B, Lq, heads, Seff);
+    PSALM_LAUNCH_END("psalm_mha_attention_mfma");
 }

@@ -29,6 +29,7 @@
 #define ACT_GELU 2
 #define ACT_GELU_NEW 3
 #define ACT_POST_RESIDUAL 16   // flag: apply the activation AFTER adding the residual (ResNet block: relu(out + residual))
+#define ACT_BIAS_ROW 32        // flag: bias is indexed by the output ROW (C = W_x . X^T products, i.e. transposed projections)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -76,7 +77,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename TC>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x16& acc, int row0, int col, int lane) {
     if (col >= g.N) return;
-    const float b = g.bias ? g.bias[col] : 0.f;
+    const bool brow = (g.act & ACT_BIAS_ROW) != 0;
+    const float b = (g.bias && !brow) ? g.bias[col] : 0.f;
     const int act = g.act & 15;
     const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
     const bool do_act = act != ACT_NONE && col >= g.act_col_start;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x16& 
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < g.M) {
-            float v = acc[r] + b;
+            float v = acc[r] + (brow && g.bias ? g.bias[row] : b);
             if (do_act && !post) v = apply_act(v, act);
             if (R) v += ldf(R + (long)row * g.ldr + col);
             if (do_act && post) v = apply_act(v, act);
@@ -226,16 +228,25 @@ struct GemmFastArgs {
     int vec_store;      // 1: C / residual rows allow 8-element vector accesses (N % 8 == 0, 16-byte aligned rows)
 };
 
-template <typename TC, int BM>
-__global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+// Tile configurations (BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32x16 MFMA tiles):
+//   256 x 256, 2 x 4 waves (512 threads, 128 KB LDS, 1 block/CU): large GEMMs -- half the L2->LDS bytes per flop of
+//              a 128^2 tile (the 128^2 kernel needs ~64 B/clk/CU from L2 at full MFMA rate, beyond what L2 sustains);
+//   128 x 128, 2 x 2 waves (256 threads, 64 KB LDS, 2 blocks/CU): mid-size GEMMs where 256^2 tiles cannot fill 256 CUs;
+//    64 x 128, 2 x 2 waves: M <= 192.
+template <typename TC, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const GemmArgs& g = fa.g;
-    constexpr int BN = 128, BK = 64;
-    constexpr int TM = BM / 64;
-    constexpr int A_CH = BM / 32, B_CH = BN / 32;               // 8-row chunks per wave per tile
+    constexpr int BK = 64, NW = WM * WN, NT = 64 * NW;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_CH = BM / 8 / NW, B_CH = BN / 8 / NW;       // 8-row (1 KiB) chunks per wave per tile
+    static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
+    constexpr int SMEM_BYTES = 2 * (BM + BN) * BK * 2;
+    constexpr int EP = (BM * BN * 4 > SMEM_BYTES) ? WM : 1;     // epilogue passes (one wave-row of the tile per pass)
+    static_assert(BM / EP * BN * 4 <= SMEM_BYTES, "epilogue slab must fit in the operand buffers");
     __shared__ __attribute__((aligned(16))) bf16_t smem[2][(BM + BN) * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
     const int kbeg = blockIdx.y * fa.k_per_split;
@@ -249,13 +260,13 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const int lrow = lane >> 3, slot = lane & 7;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int r = (wave + 4 * i) * 8 + lrow;
+        const int r = (wave + NW * i) * 8 + lrow;
         const int kc = slot ^ ((r >> 1) & 7);
         asrc[i] = A + (long)min(bm + r, g.M - 1) * g.lda + kbeg + kc * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int r = (wave + 4 * i) * 8 + lrow;
+        const int r = (wave + NW * i) * 8 + lrow;
         const int kc = slot ^ ((r >> 1) & 7);
         bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + kbeg + kc * 8;
     }
@@ -263,22 +274,22 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmFastArgs fa) {
         bf16_t* As = smem[buf];
         bf16_t* Bs = smem[buf] + BM * BK;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + 4 * i) * 8 * BK);
+        for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * 8 * BK);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + 4 * i) * 8 * BK);
+        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + NW * i) * 8 * BK);
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment read offsets: row (lane&31) of a 32-row sub-tile, k-chunk (2*kk + hi) ^ f,  f = ((lane&31) >> 1) & 7
     const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> 1) & 7;
-    const int a_row0 = wm * (BM / 2) + n32, b_row0 = wn * 64 + n32;
+    const int a_row0 = wm * (BM / WM) + n32, b_row0 = wn * (BN / WN) + n32;
 
     const int nk = (kend - kbeg) / BK;
     issue(0, 0);
@@ -291,89 +302,101 @@ __global__ void __launch_bounds__(256) gemm_bf16_glds_kernel(GemmFastArgs fa) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co = ((2 * kk + hi) ^ fsw) * 8;
-            bf16x8 af[TM], bfr[2];
+            bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
                 bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
     // per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
-    // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, 16 lanes per 128-column row.
-    float* Cs = reinterpret_cast<float*>(&smem[0][0]);           // [BM][BN] fp32 = BM*512 B <= sizeof(smem)
-    static_assert(sizeof(float) * BM * BN <= sizeof(bf16_t) * 2 * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                Cs[row * BN + wn * 64 + j * 32 + n32] = acc[i][j][r];
-            }
-    __syncthreads();
-    const int c8 = (tid & 15) * 8;                               // this thread's 8 columns of the tile
+    // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, BN/8 lanes per row.  Tiles larger than the buffers go
+    // in EP passes of BM/EP rows (one wave-row each).
+    float* Cs = reinterpret_cast<float*>(&smem[0][0]);
+    constexpr int ROWS_E = BM / EP;                               // rows per pass
+    constexpr int TPR = BN / 8;                                   // threads per row
+    constexpr int RPI = NT / TPR;                                 // rows per iteration
+    const int c8 = (tid % TPR) * 8;
     const int col0 = bn + c8;
-    if (col0 >= g.N) return;
     const bool split = fa.slab != nullptr;
     const int act = g.act & 15;
     const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
     float bias8[8];
+    const bool brow = (g.act & ACT_BIAS_ROW) != 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) bias8[c] = (!split && g.bias && col0 + c < g.N) ? g.bias[col0 + c] : 0.f;
+    for (int c = 0; c < 8; ++c) bias8[c] = (!split && !brow && g.bias && col0 + c < g.N) ? g.bias[col0 + c] : 0.f;
     TC* C = (TC*)g.C;
     const TC* R = (const TC*)g.res;
     float* P = split ? fa.slab + (long)blockIdx.y * g.M * g.N : nullptr;
-#pragma unroll 2
-    for (int it = 0; it < BM / 16; ++it) {
-        const int rl = it * 16 + (tid >> 4);
-        const int row = bm + rl;
-        if (row >= g.M) break;
-        const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
-        const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (split) {
-            float* dst = P + (long)row * g.N + col0;
-            if (fa.vec_store) {
-                reinterpret_cast<f32x4_g*>(dst)[0] = v0;
-                reinterpret_cast<f32x4_g*>(dst)[1] = v1;
-            } else {
+#pragma unroll 1
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep > 0) __syncthreads();                              // previous pass fully read out
+        if (EP == 1 || wm == ep) {
+            const int rbase = EP == 1 ? wm * (BM / WM) : 0;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];
-            }
-            continue;
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];
+                    }
         }
-        float rres[8];
-        if (R) {
-            if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
+        __syncthreads();
+        if (col0 >= g.N) continue;
+#pragma unroll 2
+        for (int it = 0; it < ROWS_E / RPI; ++it) {
+            const int rl = it * RPI + tid / TPR;
+            const int row = bm + ep * ROWS_E + rl;
+            if (row >= g.M) break;
+            const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
+            const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (split) {
+                float* dst = P + (long)row * g.N + col0;
+                if (fa.vec_store) {
+                    reinterpret_cast<f32x4_g*>(dst)[0] = v0;
+                    reinterpret_cast<f32x4_g*>(dst)[1] = v1;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];
+                }
+                continue;
+            }
+            float rres[8];
+            if (R) {
+                if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) rres[c] = col0 + c < g.N ? ldf(R + (long)row * g.ldr + col0 + c) : 0.f;
+                }
+            }
+            const float rb = (brow && g.bias) ? g.bias[row] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float x = v[c] + bias8[c] + rb;
+                const bool do_act = act != ACT_NONE && col0 + c >= g.act_col_start;
+                if (do_act && !post) x = apply_act(x, act);
+                if (R) x += rres[c];
+                if (do_act && post) x = apply_act(x, act);
+                v[c] = x;
+            }
+            TC* dst = C + (long)row * g.ldc + col0;
+            if (fa.vec_store) store8(dst, v);
             else {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rres[c] = col0 + c < g.N ? ldf(R + (long)row * g.ldr + col0 + c) : 0.f;
+                for (int c = 0; c < 8; ++c) if (col0 + c < g.N) stf(dst + c, v[c]);
             }
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float x = v[c] + bias8[c];
-            const bool do_act = act != ACT_NONE && col0 + c >= g.act_col_start;
-            if (do_act && !post) x = apply_act(x, act);
-            if (R) x += rres[c];
-            if (do_act && post) x = apply_act(x, act);
-            v[c] = x;
-        }
-        TC* dst = C + (long)row * g.ldc + col0;
-        if (fa.vec_store) store8(dst, v);
-        else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) if (col0 + c < g.N) stf(dst + c, v[c]);
         }
     }
 }
@@ -404,7 +427,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
     for (int i = 0; i < 4; ++i) {
         const int col = c0 + i;
         if (col >= g.N) break;
-        float x = v[i] + (g.bias ? g.bias[col] : 0.f);
+        float x = v[i] + (g.bias ? g.bias[(g.act & ACT_BIAS_ROW) ? row : col] : 0.f);
         const bool do_act = act != ACT_NONE && col >= g.act_col_start;
         if (do_act && !post) x = apply_act(x, act);
         if (R) x += ldf(R + (long)row * g.ldr + col);
@@ -498,6 +521,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
             epilogue_store<TC>(g, acc[i][j], bm + wm * (BM / 2) + i * 32, bn + wn * 64 + j * 32 + (lane & 31), lane);
 }
 
+// Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
+// (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
+static int g_tile_policy = 0;
+extern "C" int psalm_gemm_set_tile_policy(int bm) {
+    if (bm != 0 && bm != 256 && bm != 128 && bm != 64) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
+    g_tile_policy = bm;
+    return 0;
+}
+
 // C = act(A . W^T + bias) + residual.   A (M,K) lda, dtype a_dtype;  W (N,K) ldw, dtype w_dtype (selects the
 // arithmetic mode);  bias (N) f32 or NULL;  residual (M,N) ldr, dtype c_dtype, or NULL;  C (M,N) ldc, c_dtype.
 // Constraints: K % 8 == 0; 16-byte aligned row starts (lda*sizeof % 16 == 0 etc.);  w f32 requires a f32.
@@ -521,12 +553,23 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
 
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         // ---- direct-to-LDS fast path
-        const int BM = M > 192 ? 128 : 64;
+        int BM, BN;
+        // 256^2 tiles pay off only when they alone fill the chip and the K loop is long enough to amortise the bigger
+        // prologue / two-pass epilogue (measured r1e: 4096^3 1092 vs 937 TF/s, Phi [k|v|q|fc1] 713 vs 630; K <= 256 or
+        // < 200 tiles: the 128^2 configuration (2 blocks/CU, optional split-K) wins)
+        const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+        const bool can_split = workspace != nullptr && K >= 1024;
+        if (M >= 512 && N >= 256 && K >= 512 && t256 >= 200) { BM = 256; BN = 256; }
+        else if (M > 192) { BM = 128; BN = 128; }
+        else { BM = 64; BN = 128; }
+        if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; }
         g.tiles_m = cdiv(M, BM);
+        g.tiles_n = cdiv(N, BN);
         const long tiles = (long)g.tiles_m * g.tiles_n;
+        const long fill = BM == 256 ? 256 : 448;                                // blocks that fill the chip (1 vs ~2 per CU)
         int splits = 1;
-        if (tiles < 200 && K >= 1024 && workspace) {
-            splits = (int)((448 + tiles - 1) / tiles);                       // aim at ~1.75 blocks per CU
+        if (tiles < (BM == 256 ? 160 : 200) && can_split) {
+            splits = (int)((fill + tiles - 1) / tiles);
             if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
             if (splits > 32) splits = 32;
             const long per = (long)M * N * (long)sizeof(float);
@@ -542,25 +585,28 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
         if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
         else fa.vec_store = (N % 8 == 0 && (uintptr_t)C % 16 == 0 && (ldc * csz) % 16 == 0 &&
                              (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * csz) % 16 == 0))) ? 1 : 0;
-        const dim3 grid((unsigned)tiles, splits), block(256);
-        // partials are fp32 regardless of TC; with split-K the kernel's TC only selects an (unused) epilogue
-        if (BM == 128) {
-            if (c_dtype == PSALM_F32 || splits > 1) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 128>), grid, block, 0, s, fa);
-            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 128>), grid, block, 0, s, fa);
-        } else {
-            if (c_dtype == PSALM_F32 || splits > 1) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 64>), grid, block, 0, s, fa);
-            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 64>), grid, block, 0, s, fa);
-        }
+        const dim3 grid((unsigned)tiles, splits);
+        const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
+#define LAUNCH_GLDS(BM_, BN_, WM_, WN_)                                                                                     \
+    do {                                                                                                                    \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    } while (0)
+        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4);
+        else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2);
+        else LAUNCH_GLDS(64, 128, 2, 2);
+#undef LAUNCH_GLDS
         if (splits > 1) {
             const long n4 = (N + 3) / 4;
             const dim3 rgrid((unsigned)(((long)M * n4 + 255) / 256));
-            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, block, 0, s, g, (const float*)workspace, splits);
-            else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, block, 0, s, g, (const float*)workspace, splits);
+            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
+            else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
         }
         PSALM_LAUNCH_END("psalm_gemm");
     }
 
     // ---- register-staged path (fp32 activations converted on the fly, odd K, or exact fp32 arithmetic)
+    g.tiles_n = cdiv(N, 128);
     // 128-row tiles unless that leaves the 256 CUs under-filled
     const bool small = (long)cdiv(M, 128) * g.tiles_n < 256 || M <= 64;
     const int BM = small ? 64 : 128;

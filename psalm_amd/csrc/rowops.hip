@@ -34,14 +34,69 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
     }
 }
 
+// Vector form for C % 8 == 0, C <= 2048 and 16-byte aligned rows: the row is read ONCE, 8 consecutive channels per lane
+// per step (16-byte bf16 / 2 x 16-byte fp32 accesses), kept in registers for the mean and the centred variance.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) layernorm_vec_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
+                                                            bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + row * ldx;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            ld8(xr + c, v[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[i][k];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float g8[8], b8[8], o8[8];
+            ld8(gamma + c, g8);
+            ld8(beta + c, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mean) * rstd * g8[k] + b8[k];
+            st8(y + row * ldy + c, o8);
+            if (y2) st8(y2 + row * ldy2 + c, o8);
+        }
+    }
+}
+
 // y2 (optional, bf16, row stride ldy2): a second copy of the result in the GEMM operand dtype, so a fp32 residual
 // stream and the bf16 A operand of the next projection come out of one pass.
 extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
     if (rows == 0) return 0;
+    const long xs = x_dtype == PSALM_F32 ? 4 : 2, ys = y_dtype == PSALM_F32 ? 4 : 2;
+    const bool vec = C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0 && (ldx * xs) % 16 == 0 && (uintptr_t)y % 16 == 0 &&
+                     (ldy * ys) % 16 == 0 && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0 &&
+                     (!y2_bf16 || ((uintptr_t)y2_bf16 % 16 == 0 && (ldy2 * 2) % 16 == 0));
     PSALM_DISPATCH(x_dtype, TI, PSALM_DISPATCH(y_dtype, TO, {
-        hipLaunchKernelGGL((layernorm_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
+        if (vec)
+            hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
     }));
     PSALM_LAUNCH_END("psalm_layernorm");
 }

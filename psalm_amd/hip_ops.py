@@ -22,6 +22,7 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libpsalm_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_NEW = 0, 1, 2, 3
 ACT_POST_RESIDUAL = 16
+ACT_BIAS_ROW = 32
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
@@ -46,8 +47,8 @@ class _ProfiledLib:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version") or \
-                name.endswith("_workspace"):
+        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version",
+                                                         "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -146,14 +147,18 @@ class Ops:
                 raise PsalmHipError("gemm operands need a contiguous last dimension")
         if residual is not None and (residual.dtype != out.dtype or residual.shape != out.shape):
             raise PsalmHipError("gemm residual must match the output's dtype and shape")
-        if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
-            raise PsalmHipError("gemm bias must be float32 (N,)")
+        if bias is not None and (bias.dtype != torch.float32 or bias.numel() != (M if act & ACT_BIAS_ROW else N)):
+            raise PsalmHipError("gemm bias must be float32 (N,) -- or (M,) with ACT_BIAS_ROW")
         rc = self.lib.psalm_gemm(self._pv(a), _dt(a), c_long(a.stride(0)), self._pv(w), _dt(w), c_long(w.stride(0)),
                                  self._pv(bias), self._pv(residual), c_long(residual.stride(0) if residual is not None else 0),
                                  self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start,
                                  self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm")
         return out
+
+    def gemm_tile_policy(self, bm: int):
+        """0 = automatic, 256 / 128 / 64 = force the direct-to-LDS kernel's tile height (tuning / tests)."""
+        self._check(self.lib.psalm_gemm_set_tile_policy(bm), "psalm_gemm_set_tile_policy")
 
     # ------------------------------------------------------------------ row ops
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None, out2=None):
@@ -285,6 +290,25 @@ class Ops:
                                           c_long(v.stride(0)), self._p(out), c_long(D), _dt(q), self._p(mask),
                                           self._p(row_all_masked), B, Lq, Lk, heads, 32, self._stream())
         self._check(rc, "psalm_mha_attention")
+        return out
+
+    def mha_attention_t(self, q, k, vt, B, Lq, Lk, heads, mask=None, row_all_masked=None):
+        """Matrix-core split-KV form: q (B*Lq, D) / k (B*Lk, D) row-strided bf16 views; vt (B*D, ldvt) = V transposed
+        (row h*32+d, columns = keys, zero padded).  mask (B,Lq,Lk) u8 1 = blocked."""
+        D = heads * 32
+        out = self.empty(B * Lq, D, dtype=torch.bfloat16)
+        self.lib.psalm_mha_attention_mfma_workspace.restype = c_long
+        nbytes = self.lib.psalm_mha_attention_mfma_workspace(B, heads, Lk)
+        ws = None
+        if nbytes:
+            key = ("mha_ws", nbytes)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        rc = self.lib.psalm_mha_attention_mfma(self._pv(q), c_long(q.stride(0)), self._pv(k), c_long(k.stride(0)), self._pv(vt),
+                                               c_long(vt.stride(0)), self._p(out), c_long(D), self._p(mask), self._p(row_all_masked),
+                                               self._p(ws), B, Lq, Lk, heads, 32, self._stream())
+        self._check(rc, "psalm_mha_attention_mfma")
         return out
 
     def attn_mask(self, masks, Ht, Wt):

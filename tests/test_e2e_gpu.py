@@ -144,3 +144,28 @@ def test_tiny_vs_oracle_on_gpu(task, batch):
             err = float((a - w).abs().max() / w.abs().max())
             _report(test=f"tiny_{task}", precision=precision, image=b, mask_pred_err=err)
             assert err < tol, (precision, err)
+
+
+@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 2)])
+def test_graph_replay_is_bitwise_eager(task, batch):
+    """use_graphs=True: 1st call eager, 2nd call captures the launch sequence into a hipGraph, later calls replay it with
+    new inputs copied into the graph's static buffers.  Every mode must give bit-identical results."""
+    from psalm_amd.model import PSALM
+    cfg = PsalmConfig.tiny(task)
+    sd = make_state_dict(cfg, seed=12)
+    eager = PSALM(cfg, sd, precision="bf16")
+    graphed = PSALM(cfg, sd, precision="bf16", use_graphs=True)
+    for call, seed in enumerate((4, 5, 6, 4)):             # same shapes, different pixels / token ids each call
+        inputs = make_inputs(cfg, task, size=96, batch=batch, seed=seed, num_classes=9)
+        want = eager.eval_seg(**inputs)
+        got = graphed.eval_seg(**inputs)
+        torch.cuda.synchronize()
+        for b in range(batch):
+            assert torch.equal(got[b]["mask_pred"], want[b]["mask_pred"]), (call, b)
+            assert torch.equal(got[b]["instances"].scores, want[b]["instances"].scores)
+            assert torch.equal(got[b]["instances"].pred_masks, want[b]["instances"].pred_masks)
+            if task == "panoptic":
+                assert torch.equal(got[b]["sem_seg"], want[b]["sem_seg"])
+                assert torch.equal(got[b]["panoptic_seg"][0], want[b]["panoptic_seg"][0])
+                assert got[b]["panoptic_seg"][1] == want[b]["panoptic_seg"][1]
+    assert any("graph" in e for e in graphed._graphs.values())

@@ -90,3 +90,25 @@ def test_gemm_fast_path_strided_views(ops):
     err = (big_c[:, 16:88].cpu().double() - want).abs().max()
     assert err <= 2 ** -8 * want.abs().max()
     assert big_c[:, :16].abs().max() == 0 and big_c[:, 88:].abs().max() == 0
+
+
+@pytest.mark.parametrize("policy", [256, 128, 64])
+@pytest.mark.parametrize("M,N,K,cd,split", [(300, 260, 128, "bf16", False), (270, 300, 1088, "f32", True)])
+def test_gemm_forced_tiles(ops, policy, M, N, K, cd, split):
+    """Every tile configuration of the direct-to-LDS kernel (256x256 / 8 waves with its two-pass LDS epilogue, 128x128, 64x128)
+    on the same ragged problem, with and without split-K."""
+    g = torch.Generator().manual_seed(policy + M)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(DT[cd])
+    want = _ref(a.float(), w.float(), bias, res.float(), H.ACT_GELU, 0)
+    d = ops.device
+    ops.gemm_tile_policy(policy)
+    try:
+        got = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d), H.ACT_GELU, 0, out_dtype=DT[cd]).cpu().double()
+    finally:
+        ops.gemm_tile_policy(0)
+    scale = want.abs().max().item()
+    tol = (2 ** -8 if cd == "bf16" else 4e-6) * scale + 1e-6
+    assert (got - want).abs().max().item() <= tol

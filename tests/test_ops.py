@@ -206,6 +206,49 @@ def test_mha_attention_and_mask(ops, dtype):
     assert (got2 - want2).abs().max() <= tol(dtype, want2.abs().max())
 
 
+@pytest.mark.parametrize("Lq,Lk,masked", [(100, 1024, True), (100, 100, False), (37, 200, True), (128, 4096, True)])
+def test_mha_attention_mfma_split_kv(ops, Lq, Lk, masked):
+    """Matrix-core split-KV MHA (transposed V operand, partial softmax states merged by the combine kernel) vs torch."""
+    B, heads, hd = 1, 8, 32
+    D = heads * hd
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = (torch.randn(B * Lq, D + 8, generator=g)).bfloat16()
+    kbuf = (torch.randn(B * Lk, 3 * D, generator=g)).bfloat16()
+    ldvt = (Lk + 7) // 8 * 8 + 8
+    vt = torch.zeros(B * D, ldvt, dtype=torch.bfloat16)
+    vt[:, :Lk] = (torch.randn(B * D, Lk, generator=g)).bfloat16()
+    qq, kk = q[:, 8:8 + D], kbuf[:, D:2 * D]
+    mask = flags = None
+    a = (qq.float().view(B, Lq, heads, hd).transpose(1, 2) * hd ** -0.5) @ kk.float().view(B, Lk, heads, hd).transpose(1, 2).transpose(-2, -1)
+    if masked:
+        mask = (torch.rand(B, Lq, Lk, generator=g) < 0.6)
+        mask[0, 1, :] = True                                       # an all-masked row: flagged -> attends everywhere (TD:647)
+        mask[0, 2, : Lk - 3] = True                                # a row whose only visible keys sit in the last split
+        flags = mask.all(-1)
+        wm = mask.clone()
+        wm[flags] = False
+        a = a.masked_fill(wm[:, None], float("-inf"))
+    want = (a.softmax(-1) @ vt[:, :Lk].float().view(B, heads, hd, Lk).transpose(-1, -2)).transpose(1, 2).reshape(B * Lq, D)
+    d = ops.device
+    qd, kd = q.to(d), kbuf.to(d)
+    got = ops.mha_attention_t(qd[:, 8:8 + D], kd[:, D:2 * D], vt.to(d), B, Lq, Lk, heads,
+                              mask.to(torch.uint8).to(d) if masked else None, flags.to(torch.uint8).to(d) if masked else None).cpu().float()
+    assert (got - want).abs().max() <= tol(torch.bfloat16, want.abs().max())
+
+
+def test_gemm_row_bias_transposed_projection(ops):
+    """V^T = W_v . X^T with the bias broadcast along rows (how the predictor produces the transposed value operand)."""
+    from psalm_amd import hip_ops as H
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(200, 64, generator=g).bfloat16()
+    Wv = (torch.randn(96, 64, generator=g) * 0.3).bfloat16()
+    bv = torch.randn(96, generator=g)
+    want = (X.double() @ Wv.double().t() + bv.double()).t()
+    d = ops.device
+    got = ops.gemm(Wv.to(d), X.to(d), bv.to(d), act=H.ACT_BIAS_ROW, out_dtype=torch.bfloat16).cpu().double()
+    assert got.shape == (96, 200) and (got - want).abs().max() <= 2 ** -8 * want.abs().max()
+
+
 def test_im2col_and_convs(ops):
     g = torch.Generator().manual_seed(9)
     img = torch.randn(2, 3, 18, 13, generator=g)

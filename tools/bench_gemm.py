@@ -34,26 +34,34 @@ SHAPES = [  # name, M, N, K, out dtype
 def main():
     ops = get_ops()
     res = []
-    for name, M, N, K, cdt in SHAPES:
-        a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
-        w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
-        bias = torch.randn(N, device="cuda")
-        out = torch.empty(M, N, device="cuda", dtype=cdt)
-        for _ in range(3):
-            ops.gemm(a, w, bias, out=out)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 20
-        e0.record()
-        for _ in range(n):
-            ops.gemm(a, w, bias, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / n * 1e3
-        tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-        gb = (M * K * 2 + N * K * 2 + M * N * out.element_size()) / (us * 1e-6) / 1e9
-        res.append({"name": name, "M": M, "N": N, "K": K, "us": round(us, 1), "TFLOPs": round(tf, 1), "GBps": round(gb, 0)})
-        print(f"{name:22s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:7.1f} TF/s  {gb:7.0f} GB/s")
+    policies = [0]
+    if "--ab" in sys.argv:
+        policies = [0, 256, 128]
+    for pol in policies:
+      ops.gemm_tile_policy(pol)
+      print(f"---- tile policy {pol}")
+      for name, M, N, K, cdt in SHAPES:
+          if pol == 256 and M < 256:
+              continue
+          a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+          w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+          bias = torch.randn(N, device="cuda")
+          out = torch.empty(M, N, device="cuda", dtype=cdt)
+          for _ in range(3):
+              ops.gemm(a, w, bias, out=out)
+          torch.cuda.synchronize()
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          n = 20
+          e0.record()
+          for _ in range(n):
+              ops.gemm(a, w, bias, out=out)
+          e1.record()
+          torch.cuda.synchronize()
+          us = e0.elapsed_time(e1) / n * 1e3
+          tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+          gb = (M * K * 2 + N * K * 2 + M * N * out.element_size()) / (us * 1e-6) / 1e9
+          res.append({"policy": pol, "name": name, "M": M, "N": N, "K": K, "us": round(us, 1), "TFLOPs": round(tf, 1), "GBps": round(gb, 0)})
+          print(f"{name:22s} M={M:6d} N={N:6d} K={K:6d}  {us:9.1f} us  {tf:7.1f} TF/s  {gb:7.0f} GB/s")
     if "--json" in sys.argv:
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
             json.dump(res, f, indent=1)
