@@ -81,45 +81,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- instrumented steps (not part of `value`): per-kernel HIP-event timing
+    # ---- instrumented steps (not part of `value`): HIP events (torch's current stream = the launch stream) around every
+    # C-ABI launch, attributed to kernel instantiations through psalm_gemm_describe (the library's own selection function)
     roof = None
     if rank == 0:
         recs = []
         model.use_graphs = False                                  # per-launch events need the eager launch path
         model.eval_seg(**inputs)
         model.ops.lib.records = recs
-        nprof = 2
+        nprof = 3
         for _ in range(nprof):
             model.eval_seg(**inputs)
         torch.cuda.synchronize()
         model.ops.lib.records = None
-        agg = {}
-        shapes = {}
-        gemm_flops = gemm_ms = 0.0
-        gemm_n = 0
+        agg, shapes, kern = {}, {}, {}
         for name, a, e0, e1 in recs:
             ms = e0.elapsed_time(e1)
             d = agg.setdefault(name, [0, 0.0])
             d[0] += 1
             d[1] += ms
-            if name == "psalm_gemm" and a[4] == 1:            # w_dtype == bf16
+            if name == "psalm_gemm" and a[4] == 1:            # w_dtype == bf16 -> MFMA bf16 arithmetic
                 M, N, K = a[12], a[13], a[14]
-                gemm_flops += 2.0 * M * N * K
-                gemm_ms += ms
-                gemm_n += 1
-                sh = shapes.setdefault(f"M{M} N{N} K{K} a{'f32' if a[1] == 0 else 'bf16'} c{'f32' if a[10] == 0 else 'bf16'}", [0, 0.0, 2.0 * M * N * K])
+                a_bf16, c_bf16 = a[1] == 1, a[10] == 1
+                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True)
+                if path == 1:
+                    kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}>" + \
+                            (" + splitk_reduce_kernel" if splits > 1 else "")
+                else:
+                    kname = f"gemm_bf16_kernel<{'bf16' if a_bf16 else 'f32'},{'bf16' if c_bf16 else 'f32'},{BM}>"
+                kd = kern.setdefault(kname, [0, 0.0, 0.0])
+                kd[0] += 1
+                kd[1] += ms
+                kd[2] += 2.0 * M * N * K
+                sh = shapes.setdefault(f"M{M} N{N} K{K} a{'bf16' if a_bf16 else 'f32'} c{'bf16' if c_bf16 else 'f32'} -> {kname}", [0, 0.0, 2.0 * M * N * K])
                 sh[0] += 1
                 sh[1] += ms
         breakdown = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         breakdown["_gemm_shapes"] = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 4),
                                          "TFLOPs": round(v[2] * v[0] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else None}
                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
-        if gemm_ms > 0:
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (psalm_gemm, bf16 weights)", "achieved": round(ach, 1),
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": gemm_n / nprof, "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2),
-                    "algorithmic_gflop_per_step": round(gemm_flops / nprof / 1e9, 1)}
+        breakdown["_gemm_kernels"] = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 4),
+                                          "TFLOPs": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+        if kern:
+            # dominant kernel = the single-kernel (un-split) GEMM instantiation with the largest share of the step
+            cands = {k: v for k, v in kern.items() if "splitk" not in k} or kern
+            kname, (n, ms, fl) = max(cands.items(), key=lambda kv: kv[1][1])
+            ach = fl / (ms * 1e-3) / 1e12
+            all_ms = sum(v[1] for v in kern.values())
+            all_fl = sum(v[2] for v in kern.values())
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")     # rocprofv3 --pmc pass of this same command
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("kernel_prefix") and kname.startswith(tj["kernel_prefix"]):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
+                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+                    "share_of_step_ms": round(ms / nprof, 3),
+                    "all_bf16_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
+                                       "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof}}
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
             with open(args.breakdown, "w") as f:

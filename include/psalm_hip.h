@@ -64,6 +64,8 @@ int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype,
                const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
                int act_col_start, void* workspace, long workspace_bytes, void* stream);
 
+/* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
+int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM. */
 int psalm_gemm_set_tile_policy(int bm);
 

@@ -74,6 +74,16 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 }
 #endif
 
+// Counted wait on the vector-memory counter (LDS-DMA copies included) + raw workgroup barrier, for software pipelines
+// that keep copies in flight across the barrier (a plain __syncthreads() drains vmcnt to 0).  N must be a literal.
+#ifdef PSALM_EMU_BUILD
+#define PSALM_WAIT_VMCNT(N) do { } while (0)          /* the stand-in's copies are synchronous */
+#define PSALM_RAW_BARRIER() __syncthreads()
+#else
+#define PSALM_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+
 // ----------------------------------------------------------------------------- host side
 extern "C" void psalm_set_error(const char* msg);
 

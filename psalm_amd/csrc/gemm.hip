@@ -65,6 +65,7 @@ struct GemmArgs {
     long lda, ldw, ldr, ldc;
     int M, N, K, act, act_col_start;
     int tiles_m, tiles_n;
+    int row_fast;       // 1: consecutive tile ids walk the M tiles of one N column first (share the W tile in one XCD's L2)
 };
 
 // XCD-aware tile id: hardware places block b on XCD b%8; give each XCD a contiguous run of tile ids
@@ -233,22 +234,23 @@ struct GemmFastArgs {
 //              a 128^2 tile (the 128^2 kernel needs ~64 B/clk/CU from L2 at full MFMA rate, beyond what L2 sustains);
 //   128 x 128, 2 x 2 waves (256 threads, 64 KB LDS, 2 blocks/CU): mid-size GEMMs where 256^2 tiles cannot fill 256 CUs;
 //    64 x 128, 2 x 2 waves: M <= 192.
-template <typename TC, int BM, int BN, int WM, int WN>
+template <typename TC, int BM, int BN, int WM, int WN, int NS>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const GemmArgs& g = fa.g;
     constexpr int BK = 64, NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_CH = BM / 8 / NW, B_CH = BN / 8 / NW;       // 8-row (1 KiB) chunks per wave per tile
     static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
-    constexpr int SMEM_BYTES = 2 * (BM + BN) * BK * 2;
+    constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2;      // NS-deep ring of operand tiles
     constexpr int EP = (BM * BN * 4 > SMEM_BYTES) ? WM : 1;     // epilogue passes (one wave-row of the tile per pass)
     static_assert(BM / EP * BN * 4 <= SMEM_BYTES, "epilogue slab must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2][(BM + BN) * BK];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+    const int bm = (g.row_fast ? tile % g.tiles_m : tile / g.tiles_n) * BM;
+    const int bn = (g.row_fast ? tile / g.tiles_m : tile % g.tiles_n) * BN;
     const int kbeg = blockIdx.y * fa.k_per_split;
     const int kend = min(g.K, kbeg + fa.k_per_split);
     const bf16_t* A = (const bf16_t*)g.A;
@@ -291,12 +293,27 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> 1) & 7;
     const int a_row0 = wm * (BM / WM) + n32, b_row0 = wn * (BN / WN) + n32;
 
+    // NS-deep ring, prefetch distance NS-1 tiles, ONE barrier per K step.  At the top of step kt the copies of tiles
+    // kt .. kt+NS-2 are in flight; a counted vmcnt retires exactly tile kt (the copies of later tiles stay in flight
+    // across the raw barrier), the barrier makes every wave's tile-kt data visible and proves that all waves are done
+    // with the stage read in step kt-1, which is then refilled with tile kt+NS-1.
+    constexpr int LPT = A_CH + B_CH;                             // copy instructions per wave per tile
     const int nk = (kend - kbeg) / BK;
-    issue(0, 0);
-    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) issue(p, p * BK);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue(buf ^ 1, (kt + 1) * BK);
+        const int buf = kt % NS;
+        if constexpr (NS == 2) {
+            PSALM_WAIT_VMCNT(0);
+        } else {
+            const int ahead = min(nk - 1 - kt, NS - 2);          // tiles after kt whose copies have been issued
+            if (ahead >= 2) { static_assert(NS <= 4, "ring depth"); if constexpr (LPT == 8) PSALM_WAIT_VMCNT(16); else if constexpr (LPT == 6) PSALM_WAIT_VMCNT(12); else PSALM_WAIT_VMCNT(0); }
+            else if (ahead == 1) { if constexpr (LPT == 8) PSALM_WAIT_VMCNT(8); else if constexpr (LPT == 6) PSALM_WAIT_VMCNT(6); else PSALM_WAIT_VMCNT(0); }
+            else PSALM_WAIT_VMCNT(0);
+        }
+        PSALM_RAW_BARRIER();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
 #pragma unroll
@@ -315,8 +332,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();                                             // all waves done with the operand ring before it is reused
     // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
     // per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
     // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, BN/8 lanes per row.  Tiles larger than the buffers go
@@ -524,9 +541,53 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
 // (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
 static int g_tile_policy = 0;
+static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
+    if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128 ring depth 2 / 3 (tuning)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
+    return 0;
+}
+
+// Tile / split-K selection of the direct-to-LDS path (pure function of the problem size).
+static void select_fast_config(int M, int N, int K, bool have_ws, long workspace_bytes, int& BM, int& BN, int& splits) {
+    // 256^2 tiles pay off only when they alone fill the chip and the K loop is long enough to amortise the bigger
+    // prologue / two-pass epilogue (measured r1e: 4096^3 1092 vs 937 TF/s, Phi [k|v|q|fc1] 713 vs 630; K <= 256 or
+    // < 200 tiles: the 128^2 configuration (2 blocks/CU, optional split-K) wins)
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    const bool can_split = have_ws && K >= 1024;
+    if (M >= 512 && N >= 256 && K >= 512 && t256 >= 200) { BM = 256; BN = 256; }
+    else if (M > 192) { BM = 128; BN = 128; }
+    else { BM = 64; BN = 128; }
+    if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; }
+    const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
+    const long fill = BM == 256 ? 256 : 448;                                // blocks that fill the chip (1 vs ~2 per CU)
+    splits = 1;
+    if (tiles < (BM == 256 ? 160 : 200) && can_split) {
+        splits = (int)((fill + tiles - 1) / tiles);
+        if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
+        if (splits > 32) splits = 32;
+        const long per = (long)M * N * (long)sizeof(float);
+        if ((long)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+        if (splits < 2) splits = 1;
+    }
+    if (splits > 1) {
+        const int kps = cdiv(cdiv(K, 64), splits) * 64;
+        splits = cdiv(K, kps);
+    }
+}
+
+// Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS), out[1] = BM,
+// out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
+extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
+    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
+        int BM, BN, splits;
+        select_fast_config(M, N, K, workspace_bytes > 0, workspace_bytes, BM, BN, splits);
+        out4[0] = 1; out4[1] = BM; out4[2] = BN; out4[3] = splits;
+    } else {
+        const bool small = (long)cdiv(M, 128) * cdiv(N, 128) < 256 || M <= 64;
+        out4[0] = 0; out4[1] = small ? 64 : 128; out4[2] = 128; out4[3] = 1;
+    }
     return 0;
 }
 
@@ -548,38 +609,20 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     g.A = A; g.W = W; g.bias = bias; g.res = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.act = act; g.act_col_start = act_col_start;
+    g.row_fast = 0;
     g.tiles_n = cdiv(N, 128);
     hipStream_t s = (hipStream_t)stream;
 
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         // ---- direct-to-LDS fast path
-        int BM, BN;
-        // 256^2 tiles pay off only when they alone fill the chip and the K loop is long enough to amortise the bigger
-        // prologue / two-pass epilogue (measured r1e: 4096^3 1092 vs 937 TF/s, Phi [k|v|q|fc1] 713 vs 630; K <= 256 or
-        // < 200 tiles: the 128^2 configuration (2 blocks/CU, optional split-K) wins)
-        const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-        const bool can_split = workspace != nullptr && K >= 1024;
-        if (M >= 512 && N >= 256 && K >= 512 && t256 >= 200) { BM = 256; BN = 256; }
-        else if (M > 192) { BM = 128; BN = 128; }
-        else { BM = 64; BN = 128; }
-        if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; }
+        int BM, BN, splits;
+        select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
         g.tiles_m = cdiv(M, BM);
         g.tiles_n = cdiv(N, BN);
         const long tiles = (long)g.tiles_m * g.tiles_n;
-        const long fill = BM == 256 ? 256 : 448;                                // blocks that fill the chip (1 vs ~2 per CU)
-        int splits = 1;
-        if (tiles < (BM == 256 ? 160 : 200) && can_split) {
-            splits = (int)((fill + tiles - 1) / tiles);
-            if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
-            if (splits > 32) splits = 32;
-            const long per = (long)M * N * (long)sizeof(float);
-            if ((long)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
-            if (splits < 2) splits = 1;
-        }
         GemmFastArgs fa;
         fa.g = g;
         fa.k_per_split = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-        if (splits > 1) splits = cdiv(K, fa.k_per_split);
         fa.slab = splits > 1 ? (float*)workspace : nullptr;
         const long csz = c_dtype == PSALM_F32 ? 4 : 2;
         if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
@@ -587,14 +630,15 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
                              (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * csz) % 16 == 0))) ? 1 : 0;
         const dim3 grid((unsigned)tiles, splits);
         const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
-#define LAUNCH_GLDS(BM_, BN_, WM_, WN_)                                                                                     \
+#define LAUNCH_GLDS(BM_, BN_, WM_, WN_, NS_)                                                                                \
     do {                                                                                                                    \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
-        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4);
-        else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2);
-        else LAUNCH_GLDS(64, 128, 2, 2);
+        fa.g.row_fast = N > M ? 1 : 0;                            // the larger operand's tiles stay in one XCD's L2
+        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2);
+        else if (BM == 128) { if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3); else LAUNCH_GLDS(128, 128, 2, 2, 2); }
+        else LAUNCH_GLDS(64, 128, 2, 2, 2);
 #undef LAUNCH_GLDS
         if (splits > 1) {
             const long n4 = (N + 3) / 4;

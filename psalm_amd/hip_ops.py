@@ -79,6 +79,7 @@ class Ops:
         cdll = ctypes.CDLL(lib_path)
         cdll.psalm_last_error.restype = c_char_p
         cdll.psalm_backend.restype = c_char_p
+        self._cdll_raw = cdll
         self.lib = _ProfiledLib(cdll)
         self.backend = self.lib.psalm_backend().decode()
         self.is_emu = self.backend == "emu"
@@ -155,6 +156,12 @@ class Ops:
                                  self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm")
         return out
+
+    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True):
+        """(path, BM, BN, splits) psalm_gemm uses for this problem (path 1 = direct-to-LDS kernel)."""
+        out = (c_int * 4)()
+        self._cdll_raw.psalm_gemm_describe(M, N, K, BF16 if a_bf16 else F32, BF16 if w_bf16 else F32, c_long(self.GEMM_WS_BYTES), out)
+        return tuple(out)
 
     def gemm_tile_policy(self, bm: int):
         """0 = automatic, 256 / 128 / 64 = force the direct-to-LDS kernel's tile height (tuning / tests)."""

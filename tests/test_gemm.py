@@ -112,3 +112,20 @@ def test_gemm_forced_tiles(ops, policy, M, N, K, cd, split):
     scale = want.abs().max().item()
     tol = (2 ** -8 if cd == "bf16" else 4e-6) * scale + 1e-6
     assert (got - want).abs().max().item() <= tol
+
+
+def test_gemm_three_stage_ring(ops):
+    """128x128 configuration with a 3-deep operand ring (copies of 2 tiles in flight across the barrier, counted vmcnt)."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 300, 200, 448                      # 7 K-steps: prologue, steady state and drain of the ring
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
+    want = a.double() @ w.double().t()
+    d = ops.device
+    ops.gemm_tile_policy(1283)
+    try:
+        for _ in range(3):
+            got = ops.gemm(a.to(d), w.to(d), out_dtype=torch.float32).cpu().double()
+            assert (got - want).abs().max().item() <= 4e-6 * want.abs().max().item() + 1e-6
+    finally:
+        ops.gemm_tile_policy(1282)

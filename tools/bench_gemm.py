@@ -37,8 +37,12 @@ def main():
     policies = [0]
     if "--ab" in sys.argv:
         policies = [0, 256, 128]
+    if "--ring" in sys.argv:
+        policies = [1282, 1283]
     for pol in policies:
       ops.gemm_tile_policy(pol)
+      if pol > 1000:
+          ops.gemm_tile_policy(128)
       print(f"---- tile policy {pol}")
       for name, M, N, K, cdt in SHAPES:
           if pol == 256 and M < 256:
