@@ -64,6 +64,13 @@ int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype,
                const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
                int act_col_start, void* workspace, long workspace_bytes, void* stream);
 
+/* Convolution as an implicit GEMM on the direct-to-LDS kernel (no im2col matrix in HBM): x (B,H,W,Cin) bf16 NHWC,
+ * Wt (Cout, k*k*Cin) bf16 with K order (ky,kx,c); out / residual (B*Ho*Wo, Cout); Cin % 64 == 0; `zeros` = >= 16 zero bytes
+ * on the device (source of the padded taps).  act as psalm_gemm.  Replaces F.conv2d at
+ * multimodal_projector/builder.py:85-111 and msdeformattn.py:248-254. */
+int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* Wt, int Cout, int ksize, int stride, int pad,
+                      const float* bias, const void* residual, long ldr, void* out, int c_dtype, long ldc, int act,
+                      const void* zeros, void* workspace, long workspace_bytes, void* stream);
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM. */
@@ -83,6 +90,11 @@ int psalm_swin_window_gather(const void* x, int x_dtype, void* out, int out_dtyp
 /* ... and its back half (swin_trans.py:233-250): window_reverse -> roll(+shift) -> crop -> + shortcut. */
 int psalm_swin_window_merge(const void* win, int win_dtype, const void* shortcut, void* out, int x_dtype, int B, int H,
                             int W, int C, int ws, int shift, void* stream);
+/* ... fused with the block's norm2: out_x = shortcut + merged (fp32 residual stream), out_h = LayerNorm(out_x) in h_dtype
+ * (A operand of the MLP's fc1).  C % 8 == 0, C <= 2048. */
+int psalm_swin_window_merge_ln(const void* win, int win_dtype, const float* shortcut, float* out_x, void* out_h, int h_dtype,
+                               const float* gamma, const float* beta, int B, int H, int W, int C, int ws, int shift, float eps,
+                               void* stream);
 /* PatchMerging.forward up to the reduction GEMM (swin_trans.py:269-296): 2x2 gather-concat + LayerNorm(4C). */
 int psalm_patch_merge_ln(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma, const float* beta,
                          int B, int H, int W, int C, float eps, void* stream);

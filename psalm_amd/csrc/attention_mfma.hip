@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) causal_attention_mfma_kernel(const bf16_t
                                                                     const unsigned char* __restrict__ key_mask,
                                                                     bf16_t* __restrict__ out, long ldo, int o_off, int L, int Lp,
                                                                     int heads) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2][2 * 64 * 64];     // [stage][K tile | V^T tile]
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2][2 * 64 * 64 + 4 * 32];     // [stage][K tile | V^T tile] (+ key-mask bit sets in stage 0's tail)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hi = lane >> 5;
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int q0 = qb * 128 + wave * 32;
@@ -163,8 +163,16 @@ __global__ void __launch_bounds__(256) causal_attention_mfma_kernel(const bf16_t
     const int fsw = (n >> 1) & 7;
 
     const int last_q = min(L - 1, qb * 128 + 127);
-    const int ntiles = last_q / 64 + 1;                         // key tiles needed by the block's last query
+    const int ntiles = last_q / 64 + 1;                         // key tiles needed by the block's last query (<= 32: L <= 2048)
     issue(0, 0);
+    // key-padding mask of every tile as 64-bit sets (bit j of set t <-> key 64t + j), built once: no dependent global load
+    // inside the tile loop.  Wave w builds tiles w, w+4, ...
+    unsigned long long* kbits_s = reinterpret_cast<unsigned long long*>(&smem[0][2 * 64 * 64]);
+    for (int t = wave; t < ntiles; t += 4) {
+        const int kj = t * 64 + lane;
+        const unsigned long long bits = __ballot(kj < L && key_mask[(long)b * L + kj] != 0);
+        if (lane == 0) kbits_s[t] = bits;
+    }
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 64, buf = kt & 1;
         __syncthreads();                                        // tile kt landed (vmcnt(0)); everyone is done with the other buffer
@@ -172,9 +180,7 @@ __global__ void __launch_bounds__(256) causal_attention_mfma_kernel(const bf16_t
         if (k0 > q0 + 31) continue;                             // tile entirely in this wave's future (uniform per wave)
         const bf16_t* Ks = smem[buf];
         const bf16_t* Vs = smem[buf] + 64 * 64;
-        // key-padding mask of this tile as a wave-uniform 64-bit set (bit j <-> key k0 + j)
-        const int kj = k0 + lane;
-        const unsigned long long kbits = __ballot(kj < L && key_mask[(long)b * L + kj] != 0);
+        const unsigned long long kbits = kbits_s[kt];
         const unsigned long long kb_hi = kbits >> (4 * hi);
 
         f32x16 s[2];
@@ -269,6 +275,7 @@ extern "C" int psalm_causal_attention_mfma(const void* qkv, long ld, int q_off, 
                                            const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim,
                                            int rot, void* stream) {
     PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_mfma: head_dim 64 / rotary 32 only (Phi-1.5)");
+    PSALM_CHECK_ARG(L <= 2048, "psalm_causal_attention_mfma: L <= 2048 (Phi-1.5 max_position_embeddings)");
     PSALM_CHECK_ARG(ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ((uintptr_t)qkv % 16) == 0,
                     "psalm_causal_attention_mfma: q/k/v column blocks must be 16-byte aligned (ld and offsets multiples of 8)");
     PSALM_CHECK_ARG(ldo % 4 == 0 && o_off % 4 == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)workspace % 16) == 0,
@@ -488,10 +495,22 @@ __global__ void __launch_bounds__(256) mha_attention_mfma_kernel(const bf16_t* _
     const int fk = (n >> 2) & 3, fv = (n >> 1) & 7;
     const int ntiles = (kend - kbeg + 63) / 64;
     if (ntiles > 0) issue(0, kbeg);
+    // mask bytes of the lane's 32 keys per tile as 8 dwords, fetched one tile ahead (no dependent load in front of the softmax)
+    unsigned mw_cur[8], mw_nxt[8];
+    auto load_mask = [&](unsigned* mw, int k0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kj = k0 + 32 * t + 8 * g + 4 * hi;
+                mw[4 * t + g] = (mrow && kj < Lk) ? *reinterpret_cast<const unsigned*>(mrow + kj) : 0u;     // Lk % 4 == 0 (host check)
+            }
+    };
+    if (ntiles > 0) load_mask(mw_cur, kbeg);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kbeg + kt * 64, buf = kt & 1;
         __syncthreads();
-        if (kt + 1 < ntiles) issue(buf ^ 1, k0 + 64);
+        if (kt + 1 < ntiles) { issue(buf ^ 1, k0 + 64); load_mask(mw_nxt, k0 + 64); }
         const bf16_t* Ks = smem[buf];
         const bf16_t* Vs = smem[buf] + 64 * 32;
         f32x16 s[2];
@@ -511,8 +530,7 @@ __global__ void __launch_bounds__(256) mha_attention_mfma_kernel(const bf16_t* _
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int kj = k0 + 32 * t + 8 * g + 4 * hi;            // keys kj..kj+3 live in accumulator registers 4g..4g+3
-                unsigned mw = 0;
-                if (mrow && kj < Lk) mw = *reinterpret_cast<const unsigned*>(mrow + kj);     // Lk % 4 == 0 (checked on the host)
+                const unsigned mw = mw_cur[4 * t + g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = (kj + i < kend) && !((mw >> (8 * i)) & 0xffu);
@@ -548,6 +566,8 @@ __global__ void __launch_bounds__(256) mha_attention_mfma_kernel(const bf16_t* _
                                                             __builtin_bit_cast(bf16x8, u32x4_a{pb[0], pb[1], pb[2], pb[3]}), o, 0, 0, 0);
             }
         l = l * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mw_cur[i] = mw_nxt[i];
     }
     const float ltot = l + __shfl_xor(l, 32);
     if (S == 1) {
@@ -569,28 +589,31 @@ __global__ void __launch_bounds__(256) mha_attention_mfma_kernel(const bf16_t* _
     if (hi == 0) { part_ml[pbase * 2] = m; part_ml[pbase * 2 + 1] = ltot; }
 }
 
-// one thread per (b, q, h, d): merge the S partial softmax states
+// one wavefront per (b, q, h): lanes 0..31 = d; merge the S partial softmax states (coalesced 128-byte reads per split)
 __global__ void __launch_bounds__(256) mha_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                           bf16_t* __restrict__ out, long ldo, int B, int Lq, int heads, int S) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * Lq * heads * 32) return;
-    const int d = (int)(idx & 31);
-    long t = idx >> 5;
-    const int h = (int)(t % heads);
-    t /= heads;
-    const int q = (int)(t % Lq), b = (int)(t / Lq);
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long)B * Lq * heads) return;
+    const int h = (int)(wv % heads);
+    const int q = (int)((wv / heads) % Lq), b = (int)(wv / ((long)heads * Lq));
     const long base = ((long)b * heads + h) * S * 128 + q;
+    // lanes stride the splits for the max, then every lane walks all splits for its d (lanes >= 32 idle in the sum)
     float mx = -1.0e30f;
-    for (int s = 0; s < S; ++s) mx = fmaxf(mx, part_ml[(base + (long)s * 128) * 2]);
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, part_ml[(base + (long)s * 128) * 2]);
+    mx = wave_max(mx);
+    const int d = lane & 31;
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = (lane >> 5); s < S; s += 2) {                  // the two half-waves take alternate splits
         const long p = base + (long)s * 128;
         const float ms = part_ml[p * 2], ls = part_ml[p * 2 + 1];
         const float f = ls > 0.f ? __expf(ms - mx) : 0.f;
         den += ls * f;
         num += part_o[p * 32 + d] * f;
     }
-    out[((long)b * Lq + q) * ldo + h * 32 + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
+    num += __shfl_xor(num, 32);
+    den += __shfl_xor(den, 32);
+    if (lane < 32) out[((long)b * Lq + q) * ldo + h * 32 + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
 }
 
 // q (B*Lq, *) row stride ldq;  k (B*Lk, *) row stride ldk;  vt (B*heads*32, ldvt): V TRANSPOSED, row (h*32+d), columns = keys,
@@ -598,7 +621,7 @@ __global__ void __launch_bounds__(256) mha_combine_kernel(const float* __restric
 // mask (B,Lq,Lk) u8 (needs Lk % 4 == 0) / row_all_masked (B,Lq) u8, both optional.
 // workspace: psalm_mha_attention_mfma_workspace(B, heads, Lk) bytes (split-KV partials).
 static int mha_splits(int heads, int B, int Lk) {
-    int S = (512 + heads * B - 1) / (heads * B);                 // ~2 blocks per CU
+    int S = (256 + heads * B - 1) / (heads * B);                 // ~1 block per CU
     const int maxS = (Lk + 63) / 64;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -629,7 +652,7 @@ extern "C" int psalm_mha_attention_mfma(const void* q, long ldq, const void* k, 
                        (const bf16_t*)vt, ldvt, mask, row_all_masked, (bf16_t*)out, ldo, po, pml, Lq, Lk, heads, kps,
                        1.0f / sqrtf((float)head_dim));
     if (Seff > 1)
-        hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)(((long)B * Lq * heads * 32 + 255) / 256)), dim3(256), 0, st, po, pml,
+        hipLaunchKernelGGL(mha_combine_kernel, dim3((unsigned)(((long)B * Lq * heads + 3) / 4)), dim3(256), 0, st, po, pml,
                            (bf16_t*)out, ldo, B, Lq, heads, Seff);
     PSALM_LAUNCH_END("psalm_mha_attention_mfma");
 }

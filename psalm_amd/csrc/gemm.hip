@@ -227,6 +227,10 @@ struct GemmFastArgs {
     float* slab;        // split-K partials [splits][M][N] fp32 (nullptr when splits == 1)
     int k_per_split;    // multiple of 64
     int vec_store;      // 1: C / residual rows allow 8-element vector accesses (N % 8 == 0, 16-byte aligned rows)
+    // implicit-GEMM convolution (CONV kernels): A is the NHWC input x (B,H,W,Cin); row m = (b, oy, ox) of the (B,Ho,Wo) output,
+    // k = (ky, kx, c).  Cin % 64 == 0, so one 64-deep K tile lies inside one filter tap and the tap is block-uniform.
+    int cH, cW, cC, cK, cS, cP, cHo, cWo;
+    const bf16_t* zeros;   // >= 16 bytes of zeros: source of the padded (out-of-image) taps
 };
 
 // Tile configurations (BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32x16 MFMA tiles):
@@ -234,7 +238,7 @@ struct GemmFastArgs {
 //              a 128^2 tile (the 128^2 kernel needs ~64 B/clk/CU from L2 at full MFMA rate, beyond what L2 sustains);
 //   128 x 128, 2 x 2 waves (256 threads, 64 KB LDS, 2 blocks/CU): mid-size GEMMs where 256^2 tiles cannot fill 256 CUs;
 //    64 x 128, 2 x 2 waves: M <= 192.
-template <typename TC, int BM, int BN, int WM, int WN, int NS>
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const GemmArgs& g = fa.g;
     constexpr int BK = 64, NW = WM * WN, NT = 64 * NW;
@@ -260,11 +264,21 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     const bf16_t* asrc[A_CH];
     const bf16_t* bsrc[B_CH];
     const int lrow = lane >> 3, slot = lane & 7;
+    int ay[A_CH], ax[A_CH];                                      // CONV: top-left input pixel of this lane's output pixel
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int r = (wave + NW * i) * 8 + lrow;
         const int kc = slot ^ ((r >> 1) & 7);
-        asrc[i] = A + (long)min(bm + r, g.M - 1) * g.lda + kbeg + kc * 8;
+        const int m = min(bm + r, g.M - 1);
+        if constexpr (CONV) {
+            const int ox = m % fa.cWo, oy = (m / fa.cWo) % fa.cHo, b = m / (fa.cWo * fa.cHo);
+            ay[i] = oy * fa.cS - fa.cP;
+            ax[i] = ox * fa.cS - fa.cP;
+            asrc[i] = A + (long)b * fa.cH * fa.cW * fa.cC + kc * 8;           // + ((y*W + x)*C + c0) per K tile
+        } else {
+            ay[i] = ax[i] = 0;
+            asrc[i] = A + (long)m * g.lda + kbeg + kc * 8;
+        }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
@@ -275,8 +289,20 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     auto issue = [&](int buf, int koff) {
         bf16_t* As = smem[buf];
         bf16_t* Bs = smem[buf] + BM * BK;
+        if constexpr (CONV) {
+            const int k0 = kbeg + koff, tap = k0 / fa.cC, c0 = k0 - tap * fa.cC;   // block-uniform filter tap of this K tile
+            const int ky = tap / fa.cK, kx = tap - ky * fa.cK;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * 8 * BK);
+            for (int i = 0; i < A_CH; ++i) {
+                const int y = ay[i] + ky, x = ax[i] + kx;
+                const bool in = y >= 0 && y < fa.cH && x >= 0 && x < fa.cW;
+                const bf16_t* src = in ? asrc[i] + ((long)y * fa.cW + x) * fa.cC + c0 : fa.zeros;
+                psalm_glds16(src, As + (wave + NW * i) * 8 * BK);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * 8 * BK);
+        }
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + NW * i) * 8 * BK);
     };
@@ -591,6 +617,72 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
     return 0;
 }
 
+// Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
+static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s) {
+    const int M = g.M, N = g.N, K = g.K;
+    int BM, BN, splits;
+    select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
+    g.tiles_m = cdiv(M, BM);
+    g.tiles_n = cdiv(N, BN);
+    g.row_fast = N > M ? 1 : 0;                                  // the larger operand's tiles stay in one XCD's L2
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    fa.g = g;
+    fa.k_per_split = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
+    fa.slab = splits > 1 ? (float*)workspace : nullptr;
+    const long csz = c_dtype == PSALM_F32 ? 4 : 2;
+    if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
+    else fa.vec_store = (N % 8 == 0 && (uintptr_t)g.C % 16 == 0 && (g.ldc * csz) % 16 == 0 &&
+                         (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
+    const dim3 grid((unsigned)tiles, splits);
+    const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
+#define LAUNCH_GLDS(BM_, BN_, WM_, WN_, NS_, CV_)                                                                            \
+    do {                                                                                                                     \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    } while (0)
+    if (conv) {
+        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, true);
+        else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
+        else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
+    } else {
+        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
+        else if (BM == 128) { if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false); else LAUNCH_GLDS(128, 128, 2, 2, 2, false); }
+        else LAUNCH_GLDS(64, 128, 2, 2, 2, false);
+    }
+#undef LAUNCH_GLDS
+    if (splits > 1) {
+        const long n4 = (N + 3) / 4;
+        const dim3 rgrid((unsigned)(((long)M * n4 + 255) / 256));
+        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
+    }
+    PSALM_LAUNCH_END("psalm_gemm");
+}
+
+// Convolution as an implicit GEMM on the direct-to-LDS kernel: no im2col matrix in HBM.
+//   x (B,H,W,Cin) bf16 NHWC;  Wt (Cout, k*k*Cin) bf16 with K order (ky, kx, c) (= weight.permute(0,2,3,1));  bias (Cout) f32 or NULL;
+//   residual / out (B*Ho*Wo, Cout) c_dtype, row strides ldr / ldc;  Cin % 64 == 0;  zeros: >= 16 bytes of zeros on the device.
+// Replaces F.conv2d at multimodal_projector/builder.py:85-111 (3x3 s2 / 3x3 s1 / 1x1 s2) and msdeformattn.py:248-254 (FPN 3x3).
+extern "C" int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* Wt, int Cout, int ksize, int stride, int pad,
+                                 const float* bias, const void* residual, long ldr, void* out, int c_dtype, long ldc, int act,
+                                 const void* zeros, void* workspace, long workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(Cin % 64 == 0 && Cin > 0, "psalm_conv2d_nhwc: Cin must be a multiple of 64");
+    PSALM_CHECK_ARG(ksize >= 1 && stride >= 1 && pad >= 0 && zeros != nullptr, "psalm_conv2d_nhwc: bad geometry / zeros buffer missing");
+    PSALM_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)Wt % 16 == 0 && (uintptr_t)zeros % 16 == 0, "psalm_conv2d_nhwc: 16-byte aligned operands");
+    PSALM_CHECK_ARG(c_dtype == PSALM_F32 || c_dtype == PSALM_BF16, "psalm_conv2d_nhwc: bad output dtype");
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    if (B == 0 || Ho <= 0 || Wo <= 0 || Cout == 0) return 0;
+    GemmArgs g;
+    g.A = x; g.W = Wt; g.bias = bias; g.res = residual; g.C = out;
+    g.lda = 0; g.ldw = (long)ksize * ksize * Cin; g.ldr = ldr; g.ldc = ldc;
+    g.M = B * Ho * Wo; g.N = Cout; g.K = ksize * ksize * Cin; g.act = act; g.act_col_start = 0;
+    g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
+    GemmFastArgs fa;
+    fa.cH = H; fa.cW = W; fa.cC = Cin; fa.cK = ksize; fa.cS = stride; fa.cP = pad; fa.cHo = Ho; fa.cWo = Wo;
+    fa.zeros = (const bf16_t*)zeros;
+    return launch_fast(g, fa, true, c_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // C = act(A . W^T + bias) + residual.   A (M,K) lda, dtype a_dtype;  W (N,K) ldw, dtype w_dtype (selects the
 // arithmetic mode);  bias (N) f32 or NULL;  residual (M,N) ldr, dtype c_dtype, or NULL;  C (M,N) ldc, c_dtype.
 // Constraints: K % 8 == 0; 16-byte aligned row starts (lda*sizeof % 16 == 0 etc.);  w f32 requires a f32.
@@ -615,38 +707,10 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
 
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         // ---- direct-to-LDS fast path
-        int BM, BN, splits;
-        select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
-        g.tiles_m = cdiv(M, BM);
-        g.tiles_n = cdiv(N, BN);
-        const long tiles = (long)g.tiles_m * g.tiles_n;
         GemmFastArgs fa;
-        fa.g = g;
-        fa.k_per_split = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-        fa.slab = splits > 1 ? (float*)workspace : nullptr;
-        const long csz = c_dtype == PSALM_F32 ? 4 : 2;
-        if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
-        else fa.vec_store = (N % 8 == 0 && (uintptr_t)C % 16 == 0 && (ldc * csz) % 16 == 0 &&
-                             (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * csz) % 16 == 0))) ? 1 : 0;
-        const dim3 grid((unsigned)tiles, splits);
-        const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
-#define LAUNCH_GLDS(BM_, BN_, WM_, WN_, NS_)                                                                                \
-    do {                                                                                                                    \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
-    } while (0)
-        fa.g.row_fast = N > M ? 1 : 0;                            // the larger operand's tiles stay in one XCD's L2
-        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2);
-        else if (BM == 128) { if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3); else LAUNCH_GLDS(128, 128, 2, 2, 2); }
-        else LAUNCH_GLDS(64, 128, 2, 2, 2);
-#undef LAUNCH_GLDS
-        if (splits > 1) {
-            const long n4 = (N + 3) / 4;
-            const dim3 rgrid((unsigned)(((long)M * n4 + 255) / 256));
-            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
-            else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
-        }
-        PSALM_LAUNCH_END("psalm_gemm");
+        fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
+        fa.zeros = nullptr;
+        return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, s);
     }
 
     // ---- register-staged path (fp32 activations converted on the fly, odd K, or exact fp32 arithmetic)

@@ -179,6 +179,74 @@ extern "C" int psalm_swin_window_merge(const void* win, int win_dtype, const voi
     PSALM_LAUNCH_END("psalm_swin_window_merge");
 }
 
+// ... the same fused with norm2 (swin_trans.py:250-251): x_new = shortcut + merged is written once (fp32 stream) and its
+// LayerNorm (the MLP's input) comes out of the same registers.  C % 8 == 0, C <= 2048.
+template <typename TW, typename TH>
+__global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __restrict__ win, const float* __restrict__ shortcut,
+                                                                   float* __restrict__ out_x, TH* __restrict__ out_h,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   int B, int H, int W, int C, int ws, int shift, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws, N = ws * ws;
+    const int Hp = nWh * ws, Wp = nWw * ws;
+    const long rows = (long)B * H * W;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int xx = (int)(r % W);
+    const int y = (int)((r / W) % H);
+    const int b = (int)(r / ((long)W * H));
+    const int yp = (y - shift + Hp) % Hp, xp = (xx - shift + Wp) % Wp;
+    const long wr = (((long)b * nWh + yp / ws) * nWw + xp / ws) * N + (yp % ws) * ws + (xp % ws);
+    float v[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float a[8];
+            ld8(shortcut + r * C + c, v[i]);
+            ld8(win + wr * C + c, a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[i][k] += a[k]; sum += v[i][k]; }
+            st8(out_x + r * C + c, v[i]);
+        }
+    }
+    const float mean = wave_sum(sum) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((i * 64 + lane) * 8 < C) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float g8[8], b8[8], o8[8];
+            ld8(gamma + c, g8);
+            ld8(beta + c, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mean) * rstd * g8[k] + b8[k];
+            st8(out_h + r * C + c, o8);
+        }
+    }
+}
+
+extern "C" int psalm_swin_window_merge_ln(const void* win, int win_dtype, const float* shortcut, float* out_x, void* out_h, int h_dtype,
+                                          const float* gamma, const float* beta, int B, int H, int W, int C, int ws, int shift,
+                                          float eps, void* stream) {
+    const long rows = (long)B * H * W;
+    if (rows == 0) return 0;
+    PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048, "psalm_swin_window_merge_ln: C % 8 == 0 and C <= 2048");
+    PSALM_DISPATCH(win_dtype, TW, PSALM_DISPATCH(h_dtype, TH, {
+        hipLaunchKernelGGL((swin_window_merge_ln_kernel<TW, TH>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const TW*)win, shortcut, out_x, (TH*)out_h, gamma, beta, B, H, W, C, ws, shift, eps);
+    }));
+    PSALM_LAUNCH_END("psalm_swin_window_merge_ln");
+}
+
 // ---------------------------------------------------------------- Swin PatchMerging: 2x2 gather-concat + LN(4C)
 // swin_trans.py:269-296: channel blocks [x(0::2,0::2), x(1::2,0::2), x(0::2,1::2), x(1::2,1::2)], odd H/W zero-padded.
 template <typename TI, typename TO>

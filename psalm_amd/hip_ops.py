@@ -120,10 +120,12 @@ class Ops:
     GEMM_WS_BYTES = 96 << 20
 
     def _gemm_ws(self):
-        """Caller-owned split-K scratch handed to psalm_gemm (one buffer for the life of the binding)."""
-        ws = self._ws.get("gemm")
+        """Caller-owned split-K scratch handed to psalm_gemm: one buffer per launch stream for the life of the binding
+        (two GEMMs on different streams may run concurrently and must not share partial-sum slabs)."""
+        key = ("gemm", 0 if self.is_emu else torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
-            ws = self._ws["gemm"] = torch.empty(self.GEMM_WS_BYTES, dtype=torch.uint8, device=self.device)
+            ws = self._ws[key] = torch.empty(self.GEMM_WS_BYTES, dtype=torch.uint8, device=self.device)
         return ws
 
     def empty(self, *shape, dtype=torch.float32):
@@ -155,6 +157,25 @@ class Ops:
                                  self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start,
                                  self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm")
+        return out
+
+    def conv2d_nhwc(self, x, B, H, W, wt, ksize, stride, pad, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
+        """Implicit-GEMM convolution: x (B*H*W, Cin) bf16 NHWC tokens, wt (Cout, k*k*Cin) bf16 (K order ky,kx,c) -> (B*Ho*Wo, Cout)."""
+        Cin, Cout = x.shape[-1], wt.shape[0]
+        if x.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16 or wt.shape[1] != ksize * ksize * Cin:
+            raise PsalmHipError("conv2d_nhwc: bf16 operands, weight (Cout, k*k*Cin)")
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        out = self.empty(B * Ho * Wo, Cout, dtype=out_dtype or x.dtype)
+        if residual is not None and (residual.dtype != out.dtype or residual.shape != out.shape):
+            raise PsalmHipError("conv2d_nhwc: residual must match the output")
+        z = self._ws.get("zeros")
+        if z is None:
+            z = self._ws["zeros"] = torch.zeros(256, dtype=torch.uint8, device=self.device)
+        rc = self.lib.psalm_conv2d_nhwc(self._p(x), B, H, W, Cin, self._p(wt), Cout, ksize, stride, pad, self._p(bias), self._pv(residual),
+                                        c_long(residual.stride(0) if residual is not None else 0), self._p(out), _dt(out),
+                                        c_long(out.stride(0)), act, self._p(z), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES),
+                                        self._stream())
+        self._check(rc, "psalm_conv2d_nhwc")
         return out
 
     def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True):
@@ -200,6 +221,18 @@ class Ops:
                                               ws, shift, self._stream())
         self._check(rc, "psalm_swin_window_merge")
         return out
+
+    def swin_window_merge_ln(self, win, shortcut, gamma, beta, B, H, W, ws, shift, eps=1e-5, h_dtype=None):
+        """(x_new fp32, LayerNorm(x_new) h_dtype): window_reverse/roll/crop + residual fused with the block's norm2."""
+        C = shortcut.shape[-1]
+        if shortcut.dtype != torch.float32:
+            raise PsalmHipError("swin_window_merge_ln: the residual stream must be float32")
+        out_x = torch.empty_like(shortcut)
+        out_h = self.empty(shortcut.shape[0], C, dtype=h_dtype or win.dtype)
+        rc = self.lib.psalm_swin_window_merge_ln(self._p(win), _dt(win), self._p(shortcut), self._p(out_x), self._p(out_h), _dt(out_h),
+                                                 self._p(gamma), self._p(beta), B, H, W, C, ws, shift, c_float(eps), self._stream())
+        self._check(rc, "psalm_swin_window_merge_ln")
+        return out_x, out_h
 
     def patch_merge_ln(self, x, gamma, beta, B, H, W, eps=1e-5, out_dtype=None):
         C = x.shape[-1]

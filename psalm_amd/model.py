@@ -88,15 +88,22 @@ class PSALM:
         self._graphs: Dict = {}
         self._plan_cache: Dict = {}
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
+        self.overlap_streams = False                  # opt-in: pixel decoder on a second HIP stream, concurrent with the LLM
+        #                                               (measured r1k: no gain -- the LLM GEMMs already fill the chip)
+        self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self._prepare_weights(state_dict)
 
     # ======================================================================================= weights
+    @staticmethod
+    def _aligned(t):                      # kernels take 16-byte vector accesses; memory-mapped checkpoint views may not be aligned
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+
     def _W(self, t):                      # GEMM weight
-        return t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device)
+        return self._aligned(t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device))
 
     def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
-        return t.detach().to(torch.float32).contiguous().to(self.device)
+        return self._aligned(t.detach().to(torch.float32).contiguous().to(self.device))
 
     def _prepare_weights(self, sd):
         cfg, w = self.cfg, self.w
@@ -288,8 +295,11 @@ class PSALM:
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
                 aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
                 pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)
-                x = o.swin_window_merge(pw, x, B, Hc, Wc, ws, shift)
-                h = o.layernorm(x, w[q + "n2.g"], w[q + "n2.b"], out_dtype=self.adt)
+                if x.shape[-1] % 8 == 0:
+                    x, h = o.swin_window_merge_ln(pw, x, w[q + "n2.g"], w[q + "n2.b"], B, Hc, Wc, ws, shift, h_dtype=self.adt)
+                else:
+                    x = o.swin_window_merge(pw, x, B, Hc, Wc, ws, shift)
+                    h = o.layernorm(x, w[q + "n2.g"], w[q + "n2.b"], out_dtype=self.adt)
                 h = o.gemm(h, w[q + "fc1.w"], w[q + "fc1.b"], act=H.ACT_GELU, out_dtype=self.adt)
                 x = o.gemm(h, w[q + "fc2.w"], w[q + "fc2.b"], residual=x, out_dtype=torch.float32)
             outs.append((o.layernorm(x, w[f"swin.out{s}.g"], w[f"swin.out{s}.b"], out_dtype=self.adt), Hc, Wc))
@@ -302,6 +312,15 @@ class PSALM:
     def projector(self, res5, B, h, w_):
         """multimodal_projector/builder.py:365-375 (+ BasicBlock :85-111, conv2 applied twice). -> (B*n, hidden) fp32."""
         o, w = self.ops, self.w
+        if self.adt == torch.bfloat16 and res5.shape[-1] % 64 == 0 and w["proj.c2.w"].shape[0] % 64 == 0:
+            # implicit-GEMM convolutions (no im2col matrix in HBM)
+            ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+            y = o.conv2d_nhwc(res5, B, h, w_, w["proj.c1.w"], 3, 2, 1, bias=w["proj.c1.b"], act=H.ACT_RELU)
+            y = o.conv2d_nhwc(y, B, ho, wo, w["proj.c2.w"], 3, 1, 1)
+            ds = o.conv2d_nhwc(res5, B, h, w_, w["proj.ds.w"], 1, 2, 0, bias=w["proj.ds.b"])
+            y = o.conv2d_nhwc(y, B, ho, wo, w["proj.c2f.w"], 3, 1, 1, bias=w["proj.c2f.b"], residual=ds,
+                              act=H.ACT_RELU | H.ACT_POST_RESIDUAL)
+            return o.gemm(y, w["proj.fc.w"], w["proj.fc.b"], out_dtype=torch.float32), ho * wo
         c1 = o.im2col_nhwc(res5, B, h, w_, 3, 2, 1)
         y = o.gemm(c1, w["proj.c1.w"], w["proj.c1.b"], act=H.ACT_RELU, out_dtype=self.adt)
         ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
@@ -477,7 +496,10 @@ class PSALM:
         lat = o.groupnorm_nhwc(lat, w["pd.adapter.gn.g"], w["pd.adapter.gn.b"], 1, H2 * W2, G, relu=True, out_dtype=torch.float32)
         hs, ws_ = shapes[-1]
         y = o.upsample_add_nhwc(lat, ms[-1], 1, hs, ws_, H2, W2, out_dtype=self.adt)
-        y = o.gemm(o.im2col_nhwc(y, 1, H2, W2, 3, 1, 1), w["pd.layer.w"], w["pd.layer.b"], out_dtype=self.adt)
+        if self.adt == torch.bfloat16 and D % 64 == 0:
+            y = o.conv2d_nhwc(y, 1, H2, W2, w["pd.layer.w"], 3, 1, 1, bias=w["pd.layer.b"])
+        else:
+            y = o.gemm(o.im2col_nhwc(y, 1, H2, W2, 3, 1, 1), w["pd.layer.w"], w["pd.layer.b"], out_dtype=self.adt)
         y = o.groupnorm_nhwc(y, w["pd.layer.gn.g"], w["pd.layer.gn.b"], 1, H2 * W2, G, relu=True, out_dtype=self.adt)
         mf = o.gemm(y, w["pd.mf.w"], w["pd.mf.b"], out_dtype=self.wdt)
         return mf, ms, shapes, (H2, W2)
@@ -642,6 +664,11 @@ class PSALM:
             out[k] = dev_blob[off:off + nb].view(t)
         return out
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ======================================================================================= device forward
     def _forward_device(self, images, dv, meta, stages: Optional[dict] = None, postprocess: bool = True):
         """All device work of eval_seg (LP:1350-1466): only kernel launches on the current stream, no host round trip
@@ -660,6 +687,18 @@ class PSALM:
             side = int(math.sqrt(n_img))
             R = sum(n_regions)
             region_feats = o.region_pool(img_tok, dv["region_img"], dv["region_pts"].view(R, -1, 2), side, side, n_img)
+        # ---- the pixel decoder needs only the Swin features, the LLM only the projector tokens: run them concurrently on two
+        # HIP streams (the decoder's ~150 small, latency-bound kernels fill the gaps of the LLM's large GEMMs); joined
+        # before the predictor.  Captured as a fork/join inside the hipGraph in graph mode.
+        pd_out = [None] * B
+        side = None
+        if self.overlap_streams and not o.is_emu:
+            side = self._side_stream()
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for b in range(B):
+                    pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])
         embeds = o.gather_rows([w["embed"], img_tok, w["seg_query"], region_feats], dv["sid"], dv["srow"], cfg.hidden_size,
                                out_dtype=torch.float32)
         hidden = self.llm(embeds, dv["kmask"].view(B, L), B, L)
@@ -685,9 +724,12 @@ class PSALM:
         # ---- per image: pixel decoder + predictor (+ post-processing)
         outs = []
         c0 = r0 = 0
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         for b in range(B):
-            fb = [(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats]
-            mf, ms, shapes, mf_size = self.pixel_decoder(fb)
+            if pd_out[b] is None:
+                pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])
+            mf, ms, shapes, mf_size = pd_out[b]
             nc = meta["n_cls"][b]
             ce = cls_emb[c0:c0 + nc] if cls_emb is not None else None
             c0 += nc

@@ -249,6 +249,45 @@ def test_gemm_row_bias_transposed_projection(ops):
     assert got.shape == (96, 200) and (got - want).abs().max() <= 2 ** -8 * want.abs().max()
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,res", [(1, 9, 7, 64, 72, 3, 1, 1, False), (2, 8, 8, 128, 136, 3, 2, 1, True),
+                                                               (1, 10, 6, 64, 64, 1, 2, 0, False), (1, 6, 6, 320, 96, 3, 1, 1, False)])
+def test_conv2d_implicit_gemm(ops, B, H, W, Cin, Cout, k, stride, pad, res):
+    """Implicit-GEMM convolution (padded taps read a zero page, filter tap block-uniform per K tile, split-K at large K) vs F.conv2d."""
+    from psalm_amd import hip_ops as H_
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    wgt = (torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5).bfloat16()
+    bias = torch.randn(Cout, generator=g)
+    want = F.conv2d(x.float(), wgt.float(), bias, stride=stride, padding=pad)
+    Ho, Wo = want.shape[-2:]
+    want = want.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)
+    r = torch.randn(B * Ho * Wo, Cout, generator=g).bfloat16() if res else None
+    if res:
+        want = torch.relu(want + r.float())
+    d = ops.device
+    xt = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(d)
+    wt = wgt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(d)
+    got = ops.conv2d_nhwc(xt, B, H, W, wt, k, stride, pad, bias=bias.to(d), residual=r.to(d) if res else None,
+                          act=(H_.ACT_RELU | H_.ACT_POST_RESIDUAL) if res else H_.ACT_NONE).cpu().float()
+    assert got.shape == want.shape and (got - want).abs().max() <= tol(torch.bfloat16, want.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,C,shift", [(1, 14, 10, 64, 0), (2, 13, 25, 128, 6)])
+def test_swin_window_merge_ln(ops, B, H, W, C, shift):
+    ws = 12
+    g = torch.Generator().manual_seed(C + shift)
+    nWh, nWw = (H + ws - 1) // ws, (W + ws - 1) // ws
+    win = torch.randn(B * nWh * nWw * ws * ws, C, generator=g).bfloat16()
+    sc = torch.randn(B * H * W, C, generator=g)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    d = ops.device
+    want_x = ops.swin_window_merge(win.to(d), sc.to(d), B, H, W, ws, shift).cpu()
+    want_h = F.layer_norm(want_x, (C,), ga, be, 1e-5)
+    got_x, got_h = ops.swin_window_merge_ln(win.to(d), sc.to(d), ga.to(d), be.to(d), B, H, W, ws, shift, h_dtype=torch.bfloat16)
+    assert torch.equal(got_x.cpu(), want_x)
+    assert (got_h.cpu().float() - want_h).abs().max() <= tol(torch.bfloat16, want_h.abs().max())
+
+
 def test_im2col_and_convs(ops):
     g = torch.Generator().manual_seed(9)
     img = torch.randn(2, 3, 18, 13, generator=g)

@@ -39,6 +39,8 @@ def main():
         policies = [0, 256, 128]
     if "--ring" in sys.argv:
         policies = [1282, 1283]
+    if "--p64" in sys.argv:
+        policies = [0, 64]
     for pol in policies:
       ops.gemm_tile_policy(pol)
       if pol > 1000:

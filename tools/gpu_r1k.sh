@@ -1,0 +1,5 @@
+set -x
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -q -x 2>&1 | tail -3
+timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_r1k.log 2>&1; tail -1 gpurun_out/bench_r1k.log | cut -c1-200
+timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --eager > gpurun_out/bench_r1k_eager.log 2>&1; tail -1 gpurun_out/bench_r1k_eager.log | cut -c1-200
