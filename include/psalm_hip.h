@@ -64,6 +64,13 @@ int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, int w_dtype,
                const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
                int act_col_start, void* workspace, long workspace_bytes, void* stream);
 
+/* psalm_gemm + LayerNorm over the N columns of its fp32 result (ln_out = LN(C)*gamma+beta, ln_dtype, row stride ld_ln): with
+ * split-K the LayerNorm is fused into the slab reduction.  bf16 A / W, K % 64 == 0, c_dtype F32, N % 4 == 0, N <= 8192.
+ * Replaces the residual projection + the NEXT layer's input_layernorm of a Phi layer (modeling_phi.py:263-300). */
+int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
+                  const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act, int act_col_start,
+                  const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, int ln_dtype, long ld_ln, void* workspace,
+                  long workspace_bytes, void* stream);
 /* Convolution as an implicit GEMM on the direct-to-LDS kernel (no im2col matrix in HBM): x (B,H,W,Cin) bf16 NHWC,
  * Wt (Cout, k*k*Cin) bf16 with K order (ky,kx,c); out / residual (B*Ho*Wo, Cout); Cin % 64 == 0; `zeros` = >= 16 zero bytes
  * on the device (source of the padded taps).  act as psalm_gemm.  Replaces F.conv2d at
@@ -83,6 +90,11 @@ int psalm_gemm_set_tile_policy(int bm);
  * (optional) receives a second bf16 copy of the result (the next GEMM's A operand beside a fp32 residual stream). */
 int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                     const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
+/* ... with a third output y3_bf16 = result + add[row % add_rows] (add (add_rows,C) f32): the "tensor + positional embedding"
+ * operand of the next attention projection (msdeformattn.py:51-58; mask2former_transformer_decoder.py:35-37,93-96). */
+int psalm_layernorm3(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2, const float* add,
+                     long add_rows, void* y3_bf16, long ldy3, const float* gamma, const float* beta, int rows, int C, float eps,
+                     void* stream);
 /* SwinTransformerBlock.forward front half (swin_trans.py:206-225): norm1 -> zero-pad to a multiple of ws ->
  * roll(-shift) -> window_partition.  x (B*H*W,C) -> out (B*nW*ws*ws, C). */
 int psalm_swin_window_gather(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,

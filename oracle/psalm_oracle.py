@@ -670,6 +670,15 @@ def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images
             r["sem_seg"] = semantic_inference(cls, mp)
             r["instances"] = instance_inference(cls, mp, is_thing_list, cfg.md_queries, True)
             r["panoptic_seg"] = panoptic_inference(cls, mp, is_thing_list, cfg.object_mask_threshold, cfg.overlap_threshold)
+        elif task == "semantic":
+            # sem_seg_postprocess_before_inference is False for this task (LP:301): the semantic map is computed on the padded
+            # full-size masks and cropped / resized afterwards (LP:1437-1440)
+            cls = po["pred_class_name_logits"][b].float()
+            r["sem_seg"] = sem_seg_postprocess(semantic_inference(cls, mask_up[b]), [oh, ow], height, width)
+            mp = mask_up[b]
+        elif task == "instance":
+            cls = po["pred_class_name_logits"][b].float()
+            r["instances"] = instance_inference(cls, mp, None, cfg.md_queries, False)           # no thing filter (LP:428)
         elif task == "referring":
             r["instances"] = referring_inference(po["pred_SEG_logits"][b].float(), mp, cfg.md_queries)
         elif task == "region":

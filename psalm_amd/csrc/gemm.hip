@@ -479,6 +479,77 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
     }
 }
 
+// Split-K reduce fused with the LayerNorm that follows the GEMM in the network (Phi: x = x + [attn|mlp].W2^T, then the next
+// layer's input_layernorm): one block per output row sums the slabs, applies bias / activation / residual, writes the fp32
+// row AND its LayerNorm (the next GEMM's A operand) -- one pass over the row instead of reduce + a separate LN launch.
+// N % 4 == 0, N <= 8192.
+template <typename TL>
+__global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const float* __restrict__ slab, int splits,
+                                                               const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
+                                                               float ln_eps, TL* __restrict__ ln_out, long ld_ln) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int act = g.act & 15;
+    const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
+    float* C = (float*)g.C;
+    const float* R = (const float*)g.res;
+    constexpr int MAXV = 8;                                       // 8 x 4 x 256 = 8192 columns
+    f32x4_g v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c0 = (tid + 256 * i) * 4;
+        if (c0 < g.N) {
+            f32x4_g a{0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < splits; ++z) {
+                const f32x4_g t = *reinterpret_cast<const f32x4_g*>(slab + ((long)z * g.M + row) * g.N + c0);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int col = c0 + k;
+                float y = x[k] + (g.bias ? g.bias[col] : 0.f);
+                const bool do_act = act != ACT_NONE && col >= g.act_col_start;
+                if (do_act && !post) y = apply_act(y, act);
+                if (R) y += R[(long)row * g.ldr + col];
+                if (do_act && post) y = apply_act(y, act);
+                x[k] = y;
+                sum += y;
+            }
+            v[i] = f32x4_g{x[0], x[1], x[2], x[3]};
+            *reinterpret_cast<f32x4_g*>(C + (long)row * g.ldc + c0) = v[i];
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / g.N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if ((tid + 256 * i) * 4 < g.N) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / g.N + ln_eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c0 = (tid + 256 * i) * 4;
+        if (c0 < g.N) {
+            const f32x4_g ga = *reinterpret_cast<const f32x4_g*>(ln_gamma + c0), be = *reinterpret_cast<const f32x4_g*>(ln_beta + c0);
+            TL* o = ln_out + (long)row * ld_ln + c0;
+            stf(o + 0, (v[i].x - mean) * rstd * ga.x + be.x);
+            stf(o + 1, (v[i].y - mean) * rstd * ga.y + be.y);
+            stf(o + 2, (v[i].z - mean) * rstd * ga.z + be.z);
+            stf(o + 3, (v[i].w - mean) * rstd * ga.w + be.w);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- f32 MFMA (exact)
 template <typename TC, int BM>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
@@ -582,14 +653,17 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     // < 200 tiles: the 128^2 configuration (2 blocks/CU, optional split-K) wins)
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
     const bool can_split = have_ws && K >= 1024;
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    bool no_split = false;
     if (M >= 512 && N >= 256 && K >= 512 && t256 >= 200) { BM = 256; BN = 256; }
+    else if (M > 192 && t128 >= 100 && t128 < 200 && K <= 2048) { BM = 64; BN = 128; no_split = true; }   // r1l: Swin fc2 24 vs 35 us (split-K)
     else if (M > 192) { BM = 128; BN = 128; }
     else { BM = 64; BN = 128; }
-    if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; }
+    if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; no_split = false; }
     const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
     const long fill = BM == 256 ? 256 : 448;                                // blocks that fill the chip (1 vs ~2 per CU)
     splits = 1;
-    if (tiles < (BM == 256 ? 160 : 200) && can_split) {
+    if (tiles < (BM == 256 ? 160 : 200) && can_split && !no_split) {
         splits = (int)((fill + tiles - 1) / tiles);
         if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
         if (splits > 32) splits = 32;
@@ -618,7 +692,12 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
 }
 
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
-static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s) {
+struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; };
+extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
+                               const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
+
+static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s,
+                       const LnEpilogue* ln = nullptr) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
@@ -651,10 +730,24 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     }
 #undef LAUNCH_GLDS
     if (splits > 1) {
+        if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
+            if (ln->dtype == PSALM_F32)
+                hipLaunchKernelGGL((splitk_reduce_ln_kernel<float>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, ln->gamma,
+                                   ln->beta, ln->eps, (float*)ln->out, ln->ld);
+            else
+                hipLaunchKernelGGL((splitk_reduce_ln_kernel<bf16_t>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, ln->gamma,
+                                   ln->beta, ln->eps, (bf16_t*)ln->out, ln->ld);
+            PSALM_LAUNCH_END("psalm_gemm_ln");
+        }
         const long n4 = (N + 3) / 4;
         const dim3 rgrid((unsigned)(((long)M * n4 + 255) / 256));
         if (c_dtype == PSALM_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
         else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), rgrid, dim3(256), 0, s, g, (const float*)workspace, splits);
+    }
+    if (ln) {                                                     // un-split GEMM: the LayerNorm runs as its own (vectorised) kernel
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { psalm_set_error("psalm_gemm_ln: GEMM launch failed"); return (int)e; }
+        return psalm_layernorm(g.C, PSALM_F32, g.ldc, ln->out, ln->dtype, ln->ld, nullptr, 0, ln->gamma, ln->beta, M, N, ln->eps, (void*)s);
     }
     PSALM_LAUNCH_END("psalm_gemm");
 }
@@ -742,4 +835,33 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     } else { psalm_set_error("psalm_gemm: bad weight dtype"); return -1; }
 #undef LAUNCH_BF16
     PSALM_LAUNCH_END("psalm_gemm");
+}
+
+// psalm_gemm followed by LayerNorm over the N columns of the (fp32) result:  C as psalm_gemm,  ln_out = LN(C) * gamma + beta
+// in ln_dtype (row stride ld_ln).  With split-K the LayerNorm is fused into the slab reduction (one pass over each row).
+// Requires bf16 A / W with K % 64 == 0 (the direct-to-LDS path), c_dtype F32, N % 4 == 0, N <= 8192, 16-byte aligned rows.
+// Replaces e.g. `x = x + dense(attn) + fc2(mlp)` + the next layer's `input_layernorm` (modeling_phi.py:263-300).
+extern "C" int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W, int w_dtype, long ldw, const float* bias,
+                             const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act,
+                             int act_col_start, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, int ln_dtype,
+                             long ld_ln, void* workspace, long workspace_bytes, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    PSALM_CHECK_ARG(a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K > 0 && K % 64 == 0, "psalm_gemm_ln: bf16 operands, K % 64 == 0");
+    PSALM_CHECK_ARG(c_dtype == PSALM_F32 && N % 4 == 0 && N <= 8192, "psalm_gemm_ln: fp32 output, N % 4 == 0, N <= 8192");
+    PSALM_CHECK_ARG(!(act & ACT_BIAS_ROW), "psalm_gemm_ln: row bias not supported");
+    PSALM_CHECK_ARG(((uintptr_t)A % 16 == 0) && (lda * 2) % 16 == 0 && ((uintptr_t)W % 16 == 0) && (ldw * 2) % 16 == 0 &&
+                        (uintptr_t)C % 16 == 0 && (ldc * 4) % 16 == 0 && (uintptr_t)ln_gamma % 16 == 0 && (uintptr_t)ln_beta % 16 == 0 &&
+                        (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * 4) % 16 == 0)),
+                    "psalm_gemm_ln: 16-byte aligned rows");
+    PSALM_CHECK_ARG(ln_dtype == PSALM_F32 || ln_dtype == PSALM_BF16, "psalm_gemm_ln: bad LayerNorm output dtype");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.res = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.act_col_start = act_col_start;
+    g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
+    GemmFastArgs fa;
+    fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
+    fa.zeros = nullptr;
+    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, ln_dtype, ld_ln};
+    return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, &ln);
 }

@@ -18,7 +18,8 @@ __device__ __forceinline__ void row_stats(const TI* __restrict__ x, int C, int l
 
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
-                                                        bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ gamma,
+                                                        bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ add, long add_rows,
+                                                        bf16_t* __restrict__ y3, long ldy3, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -31,6 +32,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
         const float v = (ldf(xr + c) - mean) * rstd * gamma[c] + beta[c];
         stf(yr + c, v);
         if (y2) y2[row * ldy2 + c] = f32_to_bf16(v);
+        if (y3) y3[row * ldy3 + c] = f32_to_bf16(v + add[(row % add_rows) * C + c]);
     }
 }
 
@@ -38,8 +40,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
 // per step (16-byte bf16 / 2 x 16-byte fp32 accesses), kept in registers for the mean and the centred variance.
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) layernorm_vec_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
-                                                            bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int rows, int C, float eps) {
+                                                            bf16_t* __restrict__ y2, long ldy2, const float* __restrict__ add,
+                                                            long add_rows, bf16_t* __restrict__ y3, long ldy3,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int rows,
+                                                            int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -77,28 +81,47 @@ __global__ void __launch_bounds__(256) layernorm_vec_kernel(const TI* __restrict
             for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mean) * rstd * g8[k] + b8[k];
             st8(y + row * ldy + c, o8);
             if (y2) st8(y2 + row * ldy2 + c, o8);
+            if (y3) {
+                float a8[8];
+                ld8(add + (row % add_rows) * C + c, a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] += a8[k];
+                st8(y3 + row * ldy3 + c, o8);
+            }
         }
     }
 }
 
 // y2 (optional, bf16, row stride ldy2): a second copy of the result in the GEMM operand dtype, so a fp32 residual
 // stream and the bf16 A operand of the next projection come out of one pass.
-extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
-                               const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
+// y3 (optional, bf16, row stride ldy3) = result + add[row % add_rows] (add (add_rows, C) fp32): the "tensor + positional
+// embedding" operand of the next attention projection (msdeformattn.py:51-58, mask2former_transformer_decoder.py:35-37,93-96).
+extern "C" int psalm_layernorm3(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
+                                const float* add, long add_rows, void* y3_bf16, long ldy3, const float* gamma, const float* beta,
+                                int rows, int C, float eps, void* stream) {
     if (rows == 0) return 0;
     const long xs = x_dtype == PSALM_F32 ? 4 : 2, ys = y_dtype == PSALM_F32 ? 4 : 2;
+    PSALM_CHECK_ARG(!y3_bf16 || (add && add_rows > 0), "psalm_layernorm3: y3 needs the `add` table");
     const bool vec = C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0 && (ldx * xs) % 16 == 0 && (uintptr_t)y % 16 == 0 &&
                      (ldy * ys) % 16 == 0 && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0 &&
-                     (!y2_bf16 || ((uintptr_t)y2_bf16 % 16 == 0 && (ldy2 * 2) % 16 == 0));
+                     (!y2_bf16 || ((uintptr_t)y2_bf16 % 16 == 0 && (ldy2 * 2) % 16 == 0)) &&
+                     (!y3_bf16 || ((uintptr_t)y3_bf16 % 16 == 0 && (ldy3 * 2) % 16 == 0 && (uintptr_t)add % 16 == 0));
     PSALM_DISPATCH(x_dtype, TI, PSALM_DISPATCH(y_dtype, TO, {
         if (vec)
             hipLaunchKernelGGL((layernorm_vec_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
+                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, add, add_rows, (bf16_t*)y3_bf16, ldy3, gamma, beta,
+                               rows, C, eps);
         else
             hipLaunchKernelGGL((layernorm_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, gamma, beta, rows, C, eps);
+                               (const TI*)x, ldx, (TO*)y, ldy, (bf16_t*)y2_bf16, ldy2, add, add_rows, (bf16_t*)y3_bf16, ldy3, gamma, beta,
+                               rows, C, eps);
     }));
     PSALM_LAUNCH_END("psalm_layernorm");
+}
+
+extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
+                               const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
+    return psalm_layernorm3(x, x_dtype, ldx, y, y_dtype, ldy, y2_bf16, ldy2, nullptr, 0, nullptr, 0, gamma, beta, rows, C, eps, stream);
 }
 
 // ---------------------------------------------------------------- Swin: LN1 + pad + cyclic shift + window partition

@@ -159,6 +159,21 @@ class Ops:
         self._check(rc, "psalm_gemm")
         return out
 
+    def gemm_ln(self, a, w, bias, residual, gamma, beta, eps=1e-5, ln_dtype=torch.bfloat16, act=ACT_NONE):
+        """(C fp32, LayerNorm(C) ln_dtype) with C = act(a @ w^T + bias) + residual; bf16 a / w, K % 64 == 0."""
+        M, K = a.shape
+        N = w.shape[0]
+        out = self.empty(M, N, dtype=torch.float32)
+        ln_out = self.empty(M, N, dtype=ln_dtype)
+        if residual is not None and (residual.dtype != torch.float32 or residual.shape != out.shape):
+            raise PsalmHipError("gemm_ln: residual must be float32 (M,N)")
+        rc = self.lib.psalm_gemm_ln(self._pv(a), _dt(a), c_long(a.stride(0)), self._pv(w), _dt(w), c_long(w.stride(0)), self._p(bias),
+                                    self._pv(residual), c_long(residual.stride(0) if residual is not None else 0), self._p(out), F32,
+                                    c_long(N), M, N, K, act, 0, self._p(gamma), self._p(beta), c_float(eps), self._p(ln_out), _dt(ln_out),
+                                    c_long(N), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_gemm_ln")
+        return out, ln_out
+
     def conv2d_nhwc(self, x, B, H, W, wt, ksize, stride, pad, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
         """Implicit-GEMM convolution: x (B*H*W, Cin) bf16 NHWC tokens, wt (Cout, k*k*Cin) bf16 (K order ky,kx,c) -> (B*Ho*Wo, Cout)."""
         Cin, Cout = x.shape[-1], wt.shape[0]
@@ -189,17 +204,23 @@ class Ops:
         self._check(self.lib.psalm_gemm_set_tile_policy(bm), "psalm_gemm_set_tile_policy")
 
     # ------------------------------------------------------------------ row ops
-    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None, out2=None):
-        """LayerNorm over the last dim of a 2-D (row-strided) view.  out2: optional bf16 (rows,C) second copy."""
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_dtype=None, out2=None, add=None, out3=None):
+        """LayerNorm over the last dim of a 2-D (row-strided) view.  out2: optional bf16 (rows,C) second copy;
+        out3: optional bf16 (rows,C) = result + add[row % add.shape[0]] (add fp32 (r,C))."""
         rows, C = x.shape
         if out is None:
             out = self.empty(rows, C, dtype=out_dtype or x.dtype)
-        if out2 is not None and out2.dtype != torch.bfloat16:
-            raise PsalmHipError("layernorm: out2 must be bfloat16")
-        rc = self.lib.psalm_layernorm(self._pv(x), _dt(x), c_long(x.stride(0)), self._pv(out), _dt(out), c_long(out.stride(0)),
-                                      self._pv(out2), c_long(out2.stride(0) if out2 is not None else 0),
-                                      self._p(gamma), self._p(beta), rows, C, c_float(eps), self._stream())
-        self._check(rc, "psalm_layernorm")
+        for t in (out2, out3):
+            if t is not None and t.dtype != torch.bfloat16:
+                raise PsalmHipError("layernorm: out2 / out3 must be bfloat16")
+        if out3 is not None and (add is None or add.dtype != torch.float32 or add.shape[1] != C):
+            raise PsalmHipError("layernorm: out3 needs a float32 (r,C) `add` table")
+        rc = self.lib.psalm_layernorm3(self._pv(x), _dt(x), c_long(x.stride(0)), self._pv(out), _dt(out), c_long(out.stride(0)),
+                                       self._pv(out2), c_long(out2.stride(0) if out2 is not None else 0),
+                                       self._p(add) if out3 is not None else c_void_p(0), c_long(add.shape[0] if out3 is not None else 0),
+                                       self._pv(out3), c_long(out3.stride(0) if out3 is not None else 0),
+                                       self._p(gamma), self._p(beta), rows, C, c_float(eps), self._stream())
+        self._check(rc, "psalm_layernorm3")
         return out
 
     def swin_window_gather(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5, out_dtype=None):

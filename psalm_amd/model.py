@@ -443,14 +443,22 @@ class PSALM:
         cos, sin = self._rope(L)
         x = embeds
         big = o.empty(B * L, 3 * Hd + I, dtype=self.adt)
+        fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
+        h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
-            h = o.layernorm(x, w[f"llm{i}.ln.g"], w[f"llm{i}.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
+            last = i == cfg.num_layers - 1
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place
             o.causal_attention(big, 2 * Hd, 0, Hd, big, 2 * Hd, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
                                cfg.rotary_dim)
-            x = o.gemm(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
-        return o.layernorm(x, w["llm.final.g"], w["llm.final.b"], cfg.layer_norm_eps, out_dtype=torch.float32)
+            ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
+            if fused:
+                x, h = o.gemm_ln(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb, cfg.layer_norm_eps,
+                                 ln_dtype=torch.float32 if last else self.adt)
+            else:
+                x = o.gemm(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
+        return h
 
     # ======================================================================================= pixel decoder (one image)
     def pixel_decoder(self, feats):
@@ -475,9 +483,9 @@ class PSALM:
         lvl_pos = self._cache[key]
         dual = self.adt == torch.bfloat16        # keep a bf16 copy of the fp32 token stream as the GEMM A operand
         src_a = src                              # (first layer: fp32 A through the converting GEMM path)
+        qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
         for i in range(cfg.md_enc_layers):
             q_ = f"pd.enc{i}."
-            qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
             value = o.gemm(src_a, w[q_ + "value.w"], w[q_ + "value.b"], out_dtype=self.adt)
             ow = o.gemm(qin, w[q_ + "ow.w"], w[q_ + "ow.b"], out_dtype=torch.float32)
             att = o.msda_fused(value.view(1, S, D), shapes, starts, ow.view(1, S, -1), M, out_dtype=self.adt).view(S, D)
@@ -486,10 +494,14 @@ class PSALM:
                               w[q_ + "n1.g"], w[q_ + "n1.b"], out2=mid_a)
             hdd = o.gemm(mid_a if dual else src, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
             src_a = o.empty(S, D, dtype=self.adt) if dual else None
+            nxt = dual and i + 1 < cfg.md_enc_layers              # next layer's query input (src + pos) from the same pass
+            qin = o.empty(S, D, dtype=self.adt) if nxt else None
             src = o.layernorm(o.gemm(hdd, w[q_ + "l2.w"], w[q_ + "l2.b"], residual=src, out_dtype=torch.float32),
-                              w[q_ + "n2.g"], w[q_ + "n2.b"], out2=src_a)
+                              w[q_ + "n2.g"], w[q_ + "n2.b"], out2=src_a, add=lvl_pos if nxt else None, out3=qin)
             if not dual:
                 src_a = src
+                if i + 1 < cfg.md_enc_layers:
+                    qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
         ms = [src[starts[l]: starts[l] + h * w_] for l, (h, w_) in enumerate(shapes)]
         tok2, H2, W2 = feats[0]
         lat = o.gemm(tok2, w["pd.adapter.w"], w["pd.adapter.b"], out_dtype=self.adt)
@@ -550,20 +562,24 @@ class PSALM:
             self_vt = self._cache[key]
         out = seg_query
         dec, masks = mask_head(out)
+        out_q = o.add_bcast(out, qe, out_dtype=self.adt)                      # out + query_embed (bf16 operand of the q projections)
         for i in range(nl):
             l = i % nlev
             h, w_ = shapes[l]
             amask, flags = o.attn_mask(masks.view(1, Q, H2, W2), h, w_)
             j = i // nlev
-            qp = o.gemm(o.add_bcast(out, qe, out_dtype=self.adt), w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"], out_dtype=self.adt)
+            qp = o.gemm(out_q, w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"], out_dtype=self.adt)
             if mfma:
                 a = o.mha_attention_t(qp, Kl[l][:, j * D:(j + 1) * D], Vl[l][j * D:(j + 1) * D], 1, Q, h * w_, nh, amask, flags)
             else:
                 a = o.mha_attention(qp, Kl[l][:, j * D:(j + 1) * D], Vl[l][:, j * D:(j + 1) * D], 1, Q, h * w_, nh, amask, flags)
             out_a = o.empty(Q, D, dtype=self.adt) if mfma else None          # bf16 copy of the stream = next GEMM operand
+            out_q = o.empty(Q, D, dtype=self.adt) if mfma else None          # ... and stream + query_embed, from the same LayerNorm pass
             out = o.layernorm(o.gemm(a, w[f"pr{i}.co.w"], w[f"pr{i}.co.b"], residual=out, out_dtype=torch.float32),
-                              w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"], out2=out_a)
-            qk = o.gemm(o.add_bcast(out, qe, out_dtype=self.adt), w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"], out_dtype=self.adt)
+                              w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"], out2=out_a, add=qe if mfma else None, out3=out_q)
+            if not mfma:
+                out_q = o.add_bcast(out, qe, out_dtype=self.adt)
+            qk = o.gemm(out_q, w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"], out_dtype=self.adt)
             if mfma:
                 o.gemm(w[f"pr{i}.sv.w"], out_a, w[f"pr{i}.sv.b"], act=H.ACT_BIAS_ROW, out=self_vt[:, :Q])
                 a = o.mha_attention_t(qk[:, :D], qk[:, D:], self_vt, 1, Q, Q, nh)
@@ -573,8 +589,11 @@ class PSALM:
             out = o.layernorm(o.gemm(a, w[f"pr{i}.so.w"], w[f"pr{i}.so.b"], residual=out, out_dtype=torch.float32),
                               w[f"pr{i}.sn.g"], w[f"pr{i}.sn.b"], out2=out_a)
             hdd = o.gemm(out_a if mfma else out, w[f"pr{i}.f1.w"], w[f"pr{i}.f1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+            out_q = o.empty(Q, D, dtype=self.adt) if mfma else None
             out = o.layernorm(o.gemm(hdd, w[f"pr{i}.f2.w"], w[f"pr{i}.f2.b"], residual=out, out_dtype=torch.float32),
-                              w[f"pr{i}.fn.g"], w[f"pr{i}.fn.b"])
+                              w[f"pr{i}.fn.g"], w[f"pr{i}.fn.b"], add=qe if mfma else None, out3=out_q)
+            if not mfma:
+                out_q = o.add_bcast(out, qe, out_dtype=self.adt)
             dec, masks = mask_head(out)
         res = {"pred_masks": masks.view(Q, H2, W2), "pred_class_name_logits": None, "pred_SEG_logits": None,
                "pred_region_logits": None}
@@ -765,12 +784,33 @@ class PSALM:
         Q = cfg.md_queries
         Hpad, Wpad, oh, ow, height, width = sizes
         mp = o.resize_planes(r["pred_masks"], Hpad, Wpad)                             # LP:1401-1406
-        if (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad):
+        task = self.seg_task
+        resize_after = (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad)
+        if resize_after and task != "semantic":                                       # sem_seg_postprocess_before_inference, LP:301,1427
             mp = o.resize_planes(mp, height, width, crop=(oh, ow))                    # sem_seg_postprocess, LP:1427-1429
-        HW = height * width
+        mh, mw = int(mp.shape[1]), int(mp.shape[2])
+        HW = mh * mw
         mflat = mp.view(Q, HW)
         res = {"_hw": (height, width), "_crop": (oh, ow)}
-        task = self.seg_task
+        if task == "semantic":                                                        # semantic only, post-processed AFTER inference
+            cls = r["pred_class_name_logits"]
+            C1 = cls.shape[1]
+            Kpad = (Q + 63) // 64 * 64
+            probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
+            sem = o.gemm(probsT, o.sigmoid_transpose(mflat, Kpad, self.wdt), out_dtype=torch.float32).view(C1 - 1, mh, mw)   # LP:402-406
+            res["sem_seg"] = o.resize_planes(sem, height, width, crop=(oh, ow)) if resize_after else sem           # LP:1437-1440
+            res["_pending"] = ("semantic",)
+            res["mask_pred"] = mp
+            return res
+        if task == "instance":                                                        # top-k instances, no thing filter (LP:428)
+            cls = r["pred_class_name_logits"]
+            C1 = cls.shape[1]
+            probs, _, _, _ = o.class_softmax(cls, (Q + 63) // 64 * 64, probsT_dtype=self.wdt)
+            mscore = o.mask_scores(mflat)
+            sc, cl, qq, cnt = o.topk_select(probs, C1 - 1, Q, None, mscore)
+            res["_pending"] = ("instance", sc, cl, qq, cnt, o.binarize_gather(mp, Q, qq, cnt))
+            res["mask_pred"] = mp
+            return res
         if task == "panoptic":
             cls = r["pred_class_name_logits"]
             C1 = cls.shape[1]
@@ -812,6 +852,14 @@ class PSALM:
         pend = res.pop("_pending")
         hw = res.pop("_hw")
         oh, ow = res.pop("_crop")
+        if pend[0] == "semantic":
+            return res
+        if pend[0] == "instance":
+            _, sc, cl, qq, cnt, inst_masks = pend
+            n = int(cnt.item())
+            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n].to(torch.int64),
+                                         query_index=qq[:n].to(torch.int64), pred_boxes=torch.zeros(n, 4, device=self.device))
+            return res
         if pend[0] == "panoptic":
             _, sc, cl, qq, cnt, inst_masks, pan, pinfo, ninfo = pend
             n = int(cnt.item())

@@ -250,7 +250,7 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
 
     out = {"images": images, "seg_info": seg_info}
     ids_list: List[List[int]] = []
-    if task == "panoptic":
+    if task in ("panoptic", "semantic", "instance"):          # the three class-prompt tasks share one prompt format
         C = num_classes + 1                                   # + "background" (train_datasets.py:67)
         name_ids, cls_idx = [], []
         for c in range(C):
@@ -298,7 +298,7 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
     out["input_ids"] = input_ids
     out["attention_mask"] = attn
     out["labels"] = input_ids.clone()
-    if task == "panoptic":
+    if task in ("panoptic", "semantic", "instance"):
         out["class_name_embedding_indices"] = (input_ids == CLS_TOKEN_INDEX).to(torch.int64)
     if task == "referring":
         out["refer_embedding_indices"] = (input_ids == REFER_TOKEN_INDEX).to(torch.int64)

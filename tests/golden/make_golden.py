@@ -36,6 +36,10 @@ CASES = {
     "referring_384_b2": dict(task="referring", size=384, batch=2, layers=2, seed=1, pad=32),
     # region / interactive prompt, k=1 region; RNG-dependent point sampling (CC:31-40)
     "region_384": dict(task="region", size=384, batch=1, layers=2, seed=2, pad=0),
+    # the two remaining seg_task variants of eval_seg (LP:268-301): semantic (post-processing AFTER inference, so the padded
+    # crop + resize acts on the 133-plane semantic map) and instance (top-k without the thing filter)
+    "semantic_384": dict(task="semantic", size=384, batch=1, layers=2, seed=3, pad=32),
+    "instance_384": dict(task="instance", size=384, batch=1, layers=2, seed=4, pad=32),
 }
 RNG_SEED_AT_CALL = 1234
 

@@ -169,3 +169,37 @@ def test_graph_replay_is_bitwise_eager(task, batch):
                 assert torch.equal(got[b]["panoptic_seg"][0], want[b]["panoptic_seg"][0])
                 assert got[b]["panoptic_seg"][1] == want[b]["panoptic_seg"][1]
     assert any("graph" in e for e in graphed._graphs.values())
+
+
+@pytest.mark.parametrize("precision,rtol", [("fp32", 1e-3), ("bf16", 6e-2)])
+def test_golden_semantic_384(precision, rtol):
+    case, z, cfg, stages, outs, results = _run_golden("semantic_384", precision)
+    errs, pm = _stage_checks(z, case, cfg, stages, outs, rtol, precision + ":")
+    sem = results[0]["sem_seg"]
+    agree = float((sem.argmax(0).to(torch.uint8).cpu().numpy() == z["sem_seg_argmax"]).mean())
+    _report(test="semantic_384", precision=precision, stage_err=errs, sem_argmax_agree=agree)
+    assert tuple(sem.shape[-2:]) == (case["size"] - case["pad"],) * 2
+    if precision == "fp32":
+        check_signature(z, "sem_seg", sem, 1e-3)
+        assert agree > 0.999
+    else:
+        assert agree > 0.75
+
+
+@pytest.mark.parametrize("precision,rtol", [("fp32", 1e-3), ("bf16", 6e-2)])
+def test_golden_instance_384(precision, rtol):
+    case, z, cfg, stages, outs, results = _run_golden("instance_384", precision)
+    errs, pm = _stage_checks(z, case, cfg, stages, outs, rtol, precision + ":")
+    inst = results[0]["instances"]
+    assert len(inst) == cfg.md_queries
+    sc = np.sort(inst.scores.cpu().numpy())
+    sc_err = float(np.abs(sc - np.sort(z["inst_scores"])).max())
+    _report(test="instance_384", precision=precision, stage_err=errs, score_err=sc_err)
+    if precision == "fp32":
+        og = np.lexsort((inst.pred_classes.cpu().numpy(), -inst.scores.cpu().numpy()))
+        ow = np.lexsort((z["inst_classes"], -z["inst_scores"]))
+        np.testing.assert_allclose(inst.scores.cpu().numpy()[og], z["inst_scores"][ow], atol=2e-3)
+        assert (inst.pred_classes.cpu().numpy()[og] == z["inst_classes"][ow]).all()
+    else:
+        # random-weight bf16 (see test_golden_panoptic_512): individual near-tied candidates swap, the score distribution holds
+        assert float(np.abs(sc - np.sort(z["inst_scores"])).mean()) < 0.05 and sc_err < 0.6

@@ -129,3 +129,21 @@ def test_gemm_three_stage_ring(ops):
             assert (got - want).abs().max().item() <= 4e-6 * want.abs().max().item() + 1e-6
     finally:
         ops.gemm_tile_policy(1282)
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 256, 1024), (130, 512, 128), (200, 2048, 2048)])
+def test_gemm_ln_fused(ops, M, N, K):
+    """psalm_gemm_ln: C = a.w^T + bias + residual (fp32) and LayerNorm(C) from one call -- fused into the split-K reduction
+    when the problem is split (cases 1 and 3), a GEMM + LayerNorm launch otherwise (case 2)."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ga, be = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    want_c = a.double() @ w.double().t() + bias.double() + res.double()
+    want_ln = torch.nn.functional.layer_norm(want_c, (N,), ga.double(), be.double(), 1e-5)
+    d = ops.device
+    for ln_dtype, tol_ln in ((torch.float32, 2e-5), (torch.bfloat16, 2 ** -7)):
+        c, ln = ops.gemm_ln(a.to(d), w.to(d), bias.to(d), res.to(d), ga.to(d), be.to(d), 1e-5, ln_dtype=ln_dtype)
+        assert (c.cpu().double() - want_c).abs().max() <= 4e-6 * want_c.abs().max()
+        assert (ln.cpu().double() - want_ln).abs().max() <= tol_ln * want_ln.abs().max()

@@ -37,6 +37,23 @@ def test_layernorm(ops, dtype, rows, C):
     assert big[:, :8].abs().max() == 0
 
 
+def test_layernorm_three_outputs(ops):
+    """fp32 stream + bf16 copy + bf16 (result + broadcast table) from one LayerNorm pass."""
+    g = torch.Generator().manual_seed(2)
+    rows, C, r = 10, 64, 5
+    x = torch.randn(rows, C, generator=g) * 2 + 0.3
+    ga, be, add = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(r, C, generator=g)
+    want = F.layer_norm(x, (C,), ga, be, 1e-5)
+    d = ops.device
+    o2 = torch.zeros(rows, C, dtype=torch.bfloat16, device=d)
+    o3 = torch.zeros(rows, C, dtype=torch.bfloat16, device=d)
+    o1 = ops.layernorm(x.to(d), ga.to(d), be.to(d), out2=o2, add=add.to(d), out3=o3)
+    assert (o1.cpu() - want).abs().max() < 3e-5 * want.abs().max()
+    assert (o2.cpu().float() - want).abs().max() <= 2 ** -8 * want.abs().max()
+    want3 = want + add.repeat(2, 1)
+    assert (o3.cpu().float() - want3).abs().max() <= 2 ** -8 * want3.abs().max()
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,W,C,ws,shift", [(1, 12, 12, 32, 12, 0), (2, 17, 14, 32, 12, 6), (1, 24, 30, 64, 12, 6)])
 def test_swin_window_gather_and_merge(ops, dtype, B, H, W, C, ws, shift):

@@ -78,3 +78,29 @@ def test_panoptic_512():
     order_g = np.lexsort((z["inst_classes"], -z["inst_scores"]))
     np.testing.assert_allclose(inst.scores.numpy()[order_o], z["inst_scores"][order_g], atol=1e-4)
     assert (inst.pred_classes.numpy()[order_o] == z["inst_classes"][order_g]).all()
+
+
+@pytest.mark.slow
+def test_semantic_384():
+    """seg_task='semantic': the semantic map is computed on the padded masks and post-processed afterwards (LP:301,1437-1440)."""
+    case, z, cfg, results, st = _run("semantic_384")
+    _check_stages(z, st)
+    sem = results[0]["sem_seg"]
+    check_signature(z, "sem_seg", sem, STAGE_RTOL)
+    assert sem.shape[-2:] == (case["size"] - case["pad"],) * 2
+    assert (sem.argmax(0).to(torch.uint8).numpy() == z["sem_seg_argmax"]).mean() > 0.9995
+    assert set(results[0]) >= {"sem_seg"} and "instances" not in results[0] and "panoptic_seg" not in results[0]
+
+
+@pytest.mark.slow
+def test_instance_384():
+    """seg_task='instance': top-k over queries x classes without the thing filter (LP:428 only applies under panoptic_on)."""
+    case, z, cfg, results, st = _run("instance_384")
+    _check_stages(z, st)
+    inst = results[0]["instances"]
+    assert inst.pred_masks.shape[0] == cfg.md_queries == len(z["inst_scores"])
+    og = np.lexsort((inst.pred_classes.numpy(), -inst.scores.numpy()))
+    ow = np.lexsort((z["inst_classes"], -z["inst_scores"]))
+    np.testing.assert_allclose(inst.scores.numpy()[og], z["inst_scores"][ow], atol=1e-4)
+    assert (inst.pred_classes.numpy()[og] == z["inst_classes"][ow]).all()
+    assert np.abs(np.sort(inst.pred_masks.flatten(1).sum(1).numpy()) - np.sort(z["inst_mask_area"])).max() <= 2
