@@ -504,3 +504,4 @@ extern "C" int psalm_segment_mean(const void* x, int x_dtype, long ldx, const in
     }));
     PSALM_LAUNCH_END("psalm_segment_mean");
 }
+
