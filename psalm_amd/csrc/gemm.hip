@@ -238,16 +238,37 @@ struct GemmFastArgs {
 //              a 128^2 tile (the 128^2 kernel needs ~64 B/clk/CU from L2 at full MFMA rate, beyond what L2 sustains);
 //   128 x 128, 2 x 2 waves (256 threads, 64 KB LDS, 2 blocks/CU): mid-size GEMMs where 256^2 tiles cannot fill 256 CUs;
 //    64 x 128, 2 x 2 waves: M <= 192.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false>
+template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_waitcnt vmcnt(N) with a compile-time N
+    static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24, "add the literal");
+    if constexpr (N == 0) PSALM_WAIT_VMCNT(0);
+    else if constexpr (N == 4) PSALM_WAIT_VMCNT(4);
+    else if constexpr (N == 6) PSALM_WAIT_VMCNT(6);
+    else if constexpr (N == 8) PSALM_WAIT_VMCNT(8);
+    else if constexpr (N == 12) PSALM_WAIT_VMCNT(12);
+    else if constexpr (N == 16) PSALM_WAIT_VMCNT(16);
+    else if constexpr (N == 18) PSALM_WAIT_VMCNT(18);
+    else PSALM_WAIT_VMCNT(24);
+}
+
+// BK = 64: 128-byte LDS rows, 8 rows per 1 KiB copy, slot p of row r holds k-chunk p ^ ((r >> 1) & 7);
+// BK = 32:  64-byte LDS rows, 16 rows per copy,       slot p of row r holds k-chunk p ^ ((r >> 2) & 3)   (same rule: the
+//           16 rows of a ds_read_b128 lane group must land on 16 distinct 16-byte slots of the 256-byte bank row).
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const GemmArgs& g = fa.g;
-    constexpr int BK = 64, NW = WM * WN, NT = 64 * NW;
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_CH = BM / 8 / NW, B_CH = BN / 8 / NW;       // 8-row (1 KiB) chunks per wave per tile
+    constexpr int RPC = 512 / BK;                                // rows per 1 KiB copy (8 | 16)
+    constexpr int SLOTS = BK / 8;                                // 16-byte slots per row (8 | 4)
+    constexpr int SWS = BK == 64 ? 1 : 2;                        // swizzle: slot ^= (row >> SWS) & (SLOTS - 1)
+    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(!CONV || BK == 64, "implicit-GEMM convolution uses 64-deep K tiles");
+    constexpr int A_CH = BM / RPC / NW, B_CH = BN / RPC / NW;    // 1 KiB copies per wave per tile
     static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
     constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2;      // NS-deep ring of operand tiles
     constexpr int EP = (BM * BN * 4 > SMEM_BYTES) ? WM : 1;     // epilogue passes (one wave-row of the tile per pass)
     static_assert(BM / EP * BN * 4 <= SMEM_BYTES, "epilogue slab must fit in the operand buffers");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,12 +284,12 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     // per-lane global sources of this wave's chunks (chunk c covers tile rows 8c..8c+7; lane -> row 8c + lane/8, slot lane%8)
     const bf16_t* asrc[A_CH];
     const bf16_t* bsrc[B_CH];
-    const int lrow = lane >> 3, slot = lane & 7;
+    const int lrow = lane / SLOTS, slot = lane % SLOTS;
     int ay[A_CH], ax[A_CH];                                      // CONV: top-left input pixel of this lane's output pixel
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int r = (wave + NW * i) * 8 + lrow;
-        const int kc = slot ^ ((r >> 1) & 7);
+        const int r = (wave + NW * i) * RPC + lrow;
+        const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
         const int m = min(bm + r, g.M - 1);
         if constexpr (CONV) {
             const int ox = m % fa.cWo, oy = (m / fa.cWo) % fa.cHo, b = m / (fa.cWo * fa.cHo);
@@ -282,8 +303,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int r = (wave + NW * i) * 8 + lrow;
-        const int kc = slot ^ ((r >> 1) & 7);
+        const int r = (wave + NW * i) * RPC + lrow;
+        const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
         bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + kbeg + kc * 8;
     }
     auto issue = [&](int buf, int koff) {
@@ -297,14 +318,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const int y = ay[i] + ky, x = ax[i] + kx;
                 const bool in = y >= 0 && y < fa.cH && x >= 0 && x < fa.cW;
                 const bf16_t* src = in ? asrc[i] + ((long)y * fa.cW + x) * fa.cC + c0 : fa.zeros;
-                psalm_glds16(src, As + (wave + NW * i) * 8 * BK);
+                psalm_glds16(src, As + (wave + NW * i) * RPC * BK);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * 8 * BK);
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * RPC * BK);
         }
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + NW * i) * 8 * BK);
+        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + NW * i) * RPC * BK);
     };
 
     f32x16 acc[TM][TN];
@@ -315,8 +336,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets: row (lane&31) of a 32-row sub-tile, k-chunk (2*kk + hi) ^ f,  f = ((lane&31) >> 1) & 7
-    const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> 1) & 7;
+    // fragment read offsets: row (lane&31) of a 32-row sub-tile, k-chunk (2*kk + hi) ^ f,  f = ((lane&31) >> SWS) & (SLOTS-1)
+    const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> SWS) & (SLOTS - 1);
     const int a_row0 = wm * (BM / WM) + n32, b_row0 = wn * (BN / WN) + n32;
 
     // NS-deep ring, prefetch distance NS-1 tiles, ONE barrier per K step.  At the top of step kt the copies of tiles
@@ -331,19 +352,19 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % NS;
         if constexpr (NS == 2) {
-            PSALM_WAIT_VMCNT(0);
+            wait_vmcnt_le<0>();
         } else {
             const int ahead = min(nk - 1 - kt, NS - 2);          // tiles after kt whose copies have been issued
-            if (ahead >= 2) { static_assert(NS <= 4, "ring depth"); if constexpr (LPT == 8) PSALM_WAIT_VMCNT(16); else if constexpr (LPT == 6) PSALM_WAIT_VMCNT(12); else PSALM_WAIT_VMCNT(0); }
-            else if (ahead == 1) { if constexpr (LPT == 8) PSALM_WAIT_VMCNT(8); else if constexpr (LPT == 6) PSALM_WAIT_VMCNT(6); else PSALM_WAIT_VMCNT(0); }
-            else PSALM_WAIT_VMCNT(0);
+            if (NS >= 4 && ahead >= 2) wait_vmcnt_le<(NS >= 4 ? 2 * LPT : 0)>();
+            else if (ahead >= 1) wait_vmcnt_le<LPT>();
+            else wait_vmcnt_le<0>();
         }
         PSALM_RAW_BARRIER();
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             const int co = ((2 * kk + hi) ^ fsw) * 8;
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
@@ -640,7 +661,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 static int g_tile_policy = 0;
 static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
-    if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128 ring depth 2 / 3 (tuning)
+    if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)
+    if (bm == 1323 || bm == 1324) { g_ring_depth = bm - 1000; return 0; }      // 128x128, BK 32, ring depth 3 / 4 (tuning)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
     return 0;
@@ -719,16 +741,27 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
+#define LAUNCH_GLDS32(BM_, BN_, WM_, WN_, NS_)                                                                               \
+    do {                                                                                                                     \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    } while (0)
     if (conv) {
         if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, true);
         else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
         else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
     } else {
         if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
-        else if (BM == 128) { if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false); else LAUNCH_GLDS(128, 128, 2, 2, 2, false); }
+        else if (BM == 128) {
+            if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false);
+            else if (g_ring_depth == 324) LAUNCH_GLDS32(128, 128, 2, 2, 4);
+            else if (g_ring_depth == 323) LAUNCH_GLDS32(128, 128, 2, 2, 3);
+            else LAUNCH_GLDS(128, 128, 2, 2, 2, false);
+        }
         else LAUNCH_GLDS(64, 128, 2, 2, 2, false);
     }
 #undef LAUNCH_GLDS
+#undef LAUNCH_GLDS32
     if (splits > 1) {
         if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
             if (ln->dtype == PSALM_F32)

@@ -114,6 +114,24 @@ def test_gemm_forced_tiles(ops, policy, M, N, K, cd, split):
     assert (got - want).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("policy", [1323, 1324])
+def test_gemm_bk32_ring(ops, policy):
+    """128x128 configuration with 32-deep K tiles (64-byte LDS rows, 4-slot swizzle) and a 3 / 4-deep operand ring."""
+    g = torch.Generator().manual_seed(policy)
+    M, N, K = 260, 200, 448
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
+    bias = torch.randn(N, generator=g)
+    want = a.double() @ w.double().t() + bias.double()
+    d = ops.device
+    ops.gemm_tile_policy(policy)
+    try:
+        got = ops.gemm(a.to(d), w.to(d), bias.to(d), out_dtype=torch.float32).cpu().double()
+        assert (got - want).abs().max().item() <= 4e-6 * want.abs().max().item() + 1e-6
+    finally:
+        ops.gemm_tile_policy(1282)
+
+
 def test_gemm_three_stage_ring(ops):
     """128x128 configuration with a 3-deep operand ring (copies of 2 tiles in flight across the barrier, counted vmcnt)."""
     g = torch.Generator().manual_seed(11)

@@ -38,7 +38,7 @@ def main():
     if "--ab" in sys.argv:
         policies = [0, 256, 128]
     if "--ring" in sys.argv:
-        policies = [1282, 1283]
+        policies = [1282, 1324, 1323]
     if "--p64" in sys.argv:
         policies = [0, 64]
     for pol in policies:
