@@ -100,13 +100,22 @@ def main():
             d = agg.setdefault(name, [0, 0.0])
             d[0] += 1
             d[1] += ms
-            if name == "psalm_gemm" and a[4] == 1:            # w_dtype == bf16 -> MFMA bf16 arithmetic
-                M, N, K = a[12], a[13], a[14]
-                a_bf16, c_bf16 = a[1] == 1, a[10] == 1
+            geo = None
+            if name in ("psalm_gemm", "psalm_gemm_ln") and a[4] == 1:            # w_dtype == bf16 -> MFMA bf16 arithmetic
+                geo = (a[12], a[13], a[14], a[1] == 1, a[10] == 1, "")
+            elif name == "psalm_conv2d_nhwc":                                     # implicit GEMM: M = B*Ho*Wo, N = Cout, K = k*k*Cin
+                B_, H_, W_, Cin, Cout, ks, st, pd_ = a[1], a[2], a[3], a[4], a[6], a[7], a[8], a[9]
+                Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
+                geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
+            if geo is not None:
+                M, N, K, a_bf16, c_bf16, tag = geo
                 path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True)
                 if path == 1:
-                    kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}>" + \
-                            (" + splitk_reduce_kernel" if splits > 1 else "")
+                    kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}{tag}>"
+                    if splits > 1:
+                        kname += " + splitk_reduce_ln_kernel" if name == "psalm_gemm_ln" else " + splitk_reduce_kernel"
+                    elif name == "psalm_gemm_ln":
+                        kname += " + layernorm_vec_kernel"
                 else:
                     kname = f"gemm_bf16_kernel<{'bf16' if a_bf16 else 'f32'},{'bf16' if c_bf16 else 'f32'},{BM}>"
                 kd = kern.setdefault(kname, [0, 0.0, 0.0])
@@ -124,18 +133,18 @@ def main():
                                           "TFLOPs": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
         if kern:
             # dominant kernel = the single-kernel (un-split) GEMM instantiation with the largest share of the step
-            cands = {k: v for k, v in kern.items() if "splitk" not in k} or kern
+            cands = {k: v for k, v in kern.items() if " + " not in k} or kern
             kname, (n, ms, fl) = max(cands.items(), key=lambda kv: kv[1][1])
             ach = fl / (ms * 1e-3) / 1e12
             all_ms = sum(v[1] for v in kern.values())
             all_fl = sum(v[2] for v in kern.values())
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")     # rocprofv3 --pmc pass of this same command
-            if os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")     # rocprofv3 --pmc passes of this same workload
+            if os.path.exists(tpath):                                            # (tools/gpu_final.sh + tools/make_traffic_json.py)
                 with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("kernel_prefix") and kname.startswith(tj["kernel_prefix"]):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    tj = json.load(f).get("kernels", {})
+                if kname in tj:
+                    traffic = tj[kname].get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),

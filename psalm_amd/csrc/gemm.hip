@@ -363,21 +363,32 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        // register double-buffered fragments: the ds_read_b128s of k-step kk+1 are issued BEFORE the MFMAs of k-step kk, so
+        // the LDS latency hides behind TM*TN matrix instructions instead of stalling every group (the straightforward loop
+        // compiled to `ds_read x4; s_waitcnt lgkmcnt(0); mfma x4` -- 45 % MFMA duty at best, r01 final PMC)
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto load_frags = [&](int kk, int slot_) {
             const int co = ((2 * kk + hi) ^ fsw) * 8;
-            bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
+                af[slot_][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+                bfr[slot_][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+        };
+        // (the scheduler otherwise sinks the reads back next to their first use to save registers; the pin costs TM+TN
+        //  fragment registers, which the 256x256 configuration -- 253 VGPRs -- does not have)
+        constexpr bool PIN = (TM * TN <= 4);
+        load_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();                                             // all waves done with the operand ring before it is reused
