@@ -71,6 +71,14 @@ int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W, int w_dty
                   const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act, int act_col_start,
                   const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, int ln_dtype, long ld_ln, void* workspace,
                   long workspace_bytes, void* stream);
+/* fp8 (OCP e4m3fn) path for the Phi projections of the interactive configuration (BASELINE.json configs[4]).
+ * psalm_quantize_rows_fp8: q[m,:] = e4m3(x[m,:] * 448/amax_m), scale[m] = amax_m/448 (software RNE + saturation, identical on
+ * device and in the CPU test build).  psalm_gemm_fp8: C = act((Aq.Wq^T) * a_scale[m] * w_scale[n] + bias) + residual on
+ * v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; K % 128 == 0; epilogue / split-K / tile selection as psalm_gemm. */
+int psalm_quantize_rows_fp8(const void* x, int x_dtype, long ldx, void* q, long ldq, float* scale, int rows, int K, void* stream);
+int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, const void* Wq, long ldw, const float* w_scale, const float* bias,
+                   const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act, int act_col_start,
+                   void* workspace, long workspace_bytes, void* stream);
 /* Convolution as an implicit GEMM on the direct-to-LDS kernel (no im2col matrix in HBM): x (B,H,W,Cin) bf16 NHWC,
  * Wt (Cout, k*k*Cin) bf16 with K order (ky,kx,c); out / residual (B*Ho*Wo, Cout); Cin % 64 == 0; `zeros` = >= 16 zero bytes
  * on the device (source of the padded taps).  act as psalm_gemm.  Replaces F.conv2d at

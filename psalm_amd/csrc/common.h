@@ -24,6 +24,33 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); 
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
+// OCP fp8 e4m3fn (gfx950's FP8 format; NOT MI300X's fnuz): 1-4-3, bias 7, max 448, no inf, NaN = 0x7f.
+// Software round-to-nearest-even with saturation, bit-identical on the device and in the CPU test build.
+__device__ __forceinline__ unsigned char f32_to_e4m3(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    const unsigned sign = (u >> 24) & 0x80u;
+    const unsigned au = u & 0x7fffffffu;
+    const float a = __builtin_bit_cast(float, au);
+    if (au > 0x7f800000u) return (unsigned char)(sign | 0x7f);                 // NaN
+    if (a < 0.015625f) {                                                          // below the smallest normal 2^-6: step 2^-9
+        const float q = __builtin_rintf(a * 512.0f);                              // 0..8 (8 == code of 2^-6)
+        return (unsigned char)(sign | (unsigned)q);
+    }
+    const unsigned r = au + 0x7ffffu + ((au >> 20) & 1u);                         // RNE on the 20 dropped mantissa bits
+    const int e = (int)(r >> 23) - 127 + 7;
+    const unsigned m = (r >> 20) & 7u;
+    if (e > 15 || (e == 15 && m == 7)) return (unsigned char)(sign | 0x7e);       // saturate to 448
+    return (unsigned char)(sign | ((unsigned)e << 3) | m);
+}
+__device__ __forceinline__ float e4m3_to_f32(unsigned char v) {
+    const unsigned e = (v >> 3) & 15u, m = v & 7u;
+    float a;
+    if (e == 0) a = (float)m * 0.001953125f;                                      // subnormal: m * 2^-9
+    else if (e == 15 && m == 7) a = __builtin_bit_cast(float, 0x7fc00000u);       // NaN
+    else a = __builtin_bit_cast(float, ((e + 120u) << 23) | (m << 20));
+    return (v & 0x80u) ? -a : a;
+}
+
 // 8 consecutive elements per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses; p must be 16-byte aligned.
 struct alignas(16) psalm_u32x4 { unsigned x, y, z, w; };
 struct alignas(16) psalm_f32x4 { float x, y, z, w; };

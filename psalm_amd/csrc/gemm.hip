@@ -231,6 +231,9 @@ struct GemmFastArgs {
     // k = (ky, kx, c).  Cin % 64 == 0, so one 64-deep K tile lies inside one filter tap and the tap is block-uniform.
     int cH, cW, cC, cK, cS, cP, cHo, cWo;
     const bf16_t* zeros;   // >= 16 bytes of zeros: source of the padded (out-of-image) taps
+    // fp8 (OCP e4m3) operands (FP8 kernels): per-row dequantisation scales of A (M) and W (N); acc * a_scale[m] * w_scale[n]
+    const float* a_scale;
+    const float* w_scale;
 };
 
 // Tile configurations (BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32x16 MFMA tiles):
@@ -253,7 +256,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // BK = 64: 128-byte LDS rows, 8 rows per 1 KiB copy, slot p of row r holds k-chunk p ^ ((r >> 1) & 7);
 // BK = 32:  64-byte LDS rows, 16 rows per copy,       slot p of row r holds k-chunk p ^ ((r >> 2) & 3)   (same rule: the
 //           16 rows of a ds_read_b128 lane group must land on 16 distinct 16-byte slots of the 256-byte bank row).
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64>
+// FP8 = true: A and W are e4m3 bytes.  The kernel is driven with "bf16 units" (K/2, lda/2, ldw/2): a 64-unit K tile is
+// 128 fp8 = the same 128-byte LDS rows, copies and swizzle as the bf16 kernel; only the fragment reads (8 bytes per lane:
+// 16-byte slot kk, half hi) and the matrix instruction (v_mfma_f32_32x32x16_fp8_fp8, 8 k-steps per tile) differ, and the
+// epilogue applies the per-row dequantisation scales.
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -263,6 +270,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     constexpr int SWS = BK == 64 ? 1 : 2;                        // swizzle: slot ^= (row >> SWS) & (SLOTS - 1)
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(!CONV || BK == 64, "implicit-GEMM convolution uses 64-deep K tiles");
+    static_assert(!FP8 || (BK == 64 && !CONV), "fp8 variant: 128-byte rows, plain GEMM");
     constexpr int A_CH = BM / RPC / NW, B_CH = BN / RPC / NW;    // 1 KiB copies per wave per tile
     static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
     constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2;      // NS-deep ring of operand tiles
@@ -378,6 +386,23 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         };
         // (the scheduler otherwise sinks the reads back next to their first use to save registers; the pin costs TM+TN
         //  fragment registers, which the 256x256 configuration -- 253 VGPRs -- does not have)
+        if constexpr (FP8) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {                     // 8 k-steps of 16 fp8 per 128-byte row
+                const int co = (kk ^ fsw) * 8 + 4 * hi;          // bf16 units: 16-byte slot kk, 8-byte half hi
+                long fa8[TM], fb8[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa8[i] = *reinterpret_cast<const long*>(&As[(a_row0 + 32 * i) * BK + co]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb8[j] = *reinterpret_cast<const long*>(&Bs[(b_row0 + 32 * j) * BK + co]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa8[i], fb8[j], acc[i][j], 0, 0, 0);
+            }
+            continue;
+        }
         constexpr bool PIN = (TM * TN <= 4);
         load_frags(0, 0);
 #pragma unroll
@@ -424,7 +449,13 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];
+                        float v = acc[i][j][r];
+                        if constexpr (FP8) {                      // dequantise: per-row scale of A x per-row scale of W
+                            const int gr = min(bm + (EP == 1 ? 0 : ep * ROWS_E) + row, g.M - 1);
+                            const int gc = min(bn + wn * (BN / WN) + j * 32 + n32, g.N - 1);
+                            v *= fa.a_scale[gr] * fa.w_scale[gc];
+                        }
+                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = v;
                     }
         }
         __syncthreads();
@@ -730,7 +761,7 @@ extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, in
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 
 static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s,
-                       const LnEpilogue* ln = nullptr) {
+                       const LnEpilogue* ln = nullptr, bool fp8 = false) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
@@ -757,7 +788,16 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
-    if (conv) {
+#define LAUNCH_GLDS8(BM_, BN_, WM_, WN_)                                                                                     \
+    do {                                                                                                                     \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    } while (0)
+    if (fp8) {
+        if (BM == 256) LAUNCH_GLDS8(256, 256, 2, 4);
+        else if (BM == 128) LAUNCH_GLDS8(128, 128, 2, 2);
+        else LAUNCH_GLDS8(64, 128, 2, 2);
+    } else if (conv) {
         if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, true);
         else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
         else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
@@ -773,6 +813,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     }
 #undef LAUNCH_GLDS
 #undef LAUNCH_GLDS32
+#undef LAUNCH_GLDS8
     if (splits > 1) {
         if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
             if (ln->dtype == PSALM_F32)
@@ -817,6 +858,7 @@ extern "C" int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, co
     GemmFastArgs fa;
     fa.cH = H; fa.cW = W; fa.cC = Cin; fa.cK = ksize; fa.cS = stride; fa.cP = pad; fa.cHo = Ho; fa.cWo = Wo;
     fa.zeros = (const bf16_t*)zeros;
+    fa.a_scale = fa.w_scale = nullptr;
     return launch_fast(g, fa, true, c_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -847,6 +889,7 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
         GemmFastArgs fa;
         fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
         fa.zeros = nullptr;
+        fa.a_scale = fa.w_scale = nullptr;
         return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, s);
     }
 
@@ -906,6 +949,78 @@ extern "C" int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W
     GemmFastArgs fa;
     fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
     fa.zeros = nullptr;
+    fa.a_scale = fa.w_scale = nullptr;
     LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, ln_dtype, ld_ln};
     return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, &ln);
+}
+
+// ------------------------------------------------------------------------------------------- fp8 (OCP e4m3) path
+// Row-wise dynamic quantisation: q[m,:] = e4m3(x[m,:] * 448 / amax_m), scale[m] = amax_m / 448 (1 for an all-zero row).
+// One wavefront per row.  x (rows,K) f32|bf16 row stride ldx; q (rows,K) bytes row stride ldq; K % 8 == 0.
+template <typename TI>
+__global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const TI* __restrict__ x, long ldx, unsigned char* __restrict__ q,
+                                                                long ldq, float* __restrict__ scale, int rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + row * ldx;
+    float amax = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        float v[8];
+        load8_f32(xr + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned char* qr = q + row * ldq;
+    for (int c = lane * 8; c < K; c += 512) {
+        float v[8];
+        load8_f32(xr + c, v);
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo |= (unsigned)f32_to_e4m3(v[k] * inv) << (8 * k);
+            hi |= (unsigned)f32_to_e4m3(v[4 + k] * inv) << (8 * k);
+        }
+        *reinterpret_cast<unsigned long long*>(qr + c) = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+}
+
+extern "C" int psalm_quantize_rows_fp8(const void* x, int x_dtype, long ldx, void* q, long ldq, float* scale, int rows, int K,
+                                       void* stream) {
+    if (rows == 0) return 0;
+    const long xs = x_dtype == PSALM_F32 ? 4 : 2;
+    PSALM_CHECK_ARG(K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * xs) % 16 == 0 && (uintptr_t)q % 8 == 0 && ldq % 8 == 0,
+                    "psalm_quantize_rows_fp8: K % 8 == 0, 16-byte aligned input rows, 8-byte aligned output rows");
+    PSALM_DISPATCH(x_dtype, TI, {
+        hipLaunchKernelGGL((quantize_rows_fp8_kernel<TI>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const TI*)x, ldx,
+                           (unsigned char*)q, ldq, scale, rows, K);
+    });
+    PSALM_LAUNCH_END("psalm_quantize_rows_fp8");
+}
+
+// C = act((Aq . Wq^T) * a_scale[m] * w_scale[n] + bias) + residual with e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8
+// (fp32 accumulation; products of e4m3 values are exact in fp32).  Aq (M,K) bytes, row stride lda; Wq (N,K) bytes, row stride ldw;
+// a_scale (M), w_scale (N) f32;  K % 128 == 0;  16-byte aligned rows.  Same epilogue / split-K / tile selection as psalm_gemm.
+extern "C" int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, const void* Wq, long ldw, const float* w_scale,
+                              const float* bias, const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K,
+                              int act, int act_col_start, void* workspace, long workspace_bytes, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    PSALM_CHECK_ARG(K > 0 && K % 128 == 0, "psalm_gemm_fp8: K must be a positive multiple of 128");
+    PSALM_CHECK_ARG((uintptr_t)Aq % 16 == 0 && lda % 16 == 0 && (uintptr_t)Wq % 16 == 0 && ldw % 16 == 0, "psalm_gemm_fp8: 16-byte aligned rows");
+    PSALM_CHECK_ARG(a_scale && w_scale, "psalm_gemm_fp8: scales required");
+    PSALM_CHECK_ARG(c_dtype == PSALM_F32 || c_dtype == PSALM_BF16, "psalm_gemm_fp8: bad output dtype");
+    GemmArgs g;
+    g.A = Aq; g.W = Wq; g.bias = bias; g.res = residual; g.C = C;
+    g.lda = lda / 2; g.ldw = ldw / 2; g.ldr = ldr; g.ldc = ldc;          // "bf16 units": two fp8 per unit
+    g.M = M; g.N = N; g.K = K / 2; g.act = act; g.act_col_start = act_col_start;
+    g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
+    GemmFastArgs fa;
+    fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
+    fa.zeros = nullptr;
+    fa.a_scale = a_scale; fa.w_scale = w_scale;
+    return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, nullptr, true);
 }

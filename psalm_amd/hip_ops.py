@@ -174,6 +174,34 @@ class Ops:
         self._check(rc, "psalm_gemm_ln")
         return out, ln_out
 
+    def quantize_rows_fp8(self, x):
+        """x (M,K) f32|bf16 (row-strided view) -> (q uint8 (M,K) e4m3fn bytes, scale f32 (M)): per-row dynamic quantisation."""
+        M, K = x.shape
+        q = self.empty(M, K, dtype=torch.uint8)
+        sc = self.empty(M, dtype=torch.float32)
+        rc = self.lib.psalm_quantize_rows_fp8(self._pv(x), _dt(x), c_long(x.stride(0)), self._p(q), c_long(K), self._p(sc), M, K,
+                                              self._stream())
+        self._check(rc, "psalm_quantize_rows_fp8")
+        return q, sc
+
+    def gemm_fp8(self, aq, a_scale, wq, w_scale, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=torch.bfloat16):
+        """out = act((aq @ wq^T) * a_scale[:,None] * w_scale[None,:] + bias) + residual; aq (M,K) / wq (N,K) uint8 e4m3fn."""
+        M, K = aq.shape
+        N = wq.shape[0]
+        if aq.dtype != torch.uint8 or wq.dtype != torch.uint8 or wq.shape[1] != K:
+            raise PsalmHipError("gemm_fp8: uint8 (e4m3fn) operands with matching K")
+        if out is None:
+            out = self.empty(M, N, dtype=out_dtype)
+        if residual is not None and (residual.dtype != out.dtype or residual.shape != out.shape):
+            raise PsalmHipError("gemm_fp8: residual must match the output")
+        rc = self.lib.psalm_gemm_fp8(self._pv(aq), c_long(aq.stride(0)), self._p(a_scale), self._pv(wq), c_long(wq.stride(0)),
+                                     self._p(w_scale), self._p(bias), self._pv(residual),
+                                     c_long(residual.stride(0) if residual is not None else 0), self._pv(out), _dt(out),
+                                     c_long(out.stride(0)), M, N, K, act, act_col_start, self._p(self._gemm_ws()),
+                                     c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_gemm_fp8")
+        return out
+
     def conv2d_nhwc(self, x, B, H, W, wt, ksize, stride, pad, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
         """Implicit-GEMM convolution: x (B*H*W, Cin) bf16 NHWC tokens, wt (Cout, k*k*Cin) bf16 (K order ky,kx,c) -> (B*Ho*Wo, Cout)."""
         Cin, Cout = x.shape[-1], wt.shape[0]

@@ -12,6 +12,9 @@ Precision modes
             residual streams, LayerNorm/GroupNorm/softmax statistics, sampling offsets, mask and class logits fp32.
     "fp32": weights and activations fp32, GEMMs on the exact fp32 MFMA -- structural parity mode against the fp32
             CPU reference (differences are summation-order round-off only).
+    "fp8" : "bf16" with the Phi projections (q/k/v/fc1 and dense/fc2, 88 % of the model's FLOPs) on v_mfma_f32_32x32x16_fp8_fp8:
+            OCP e4m3fn weights with per-output-row scales (quantised once), activations quantised per token row on the fly
+            (BASELINE.json configs[4]; an extension -- the reference has no fp8 path).
 
 Layout: activations are token-major (rows = pixels/tokens, cols = channels; NHWC for feature maps), so 1x1
 convolutions are GEMMs, 3x3 / strided convolutions are im2col + GEMM, and LayerNorm/softmax rows are contiguous.
@@ -74,12 +77,13 @@ def default_region_point_sampler(nonzero: torch.Tensor, n: int) -> torch.Tensor:
 class PSALM:
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
                  precision: str = "bf16", use_graphs: bool = False):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "fp8"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
         self.cfg = cfg
         self.ops = ops if ops is not None else H.get_ops()        # raises without GPU + libpsalm_hip.so
         self.precision = precision
-        self.wdt = torch.bfloat16 if precision == "bf16" else torch.float32   # weight / GEMM-operand dtype
+        self.llm_fp8 = precision == "fp8"             # Phi projections on e4m3 MFMA (per-row scales); everything else as "bf16"
+        self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16   # weight / GEMM-operand dtype
         self.adt = self.wdt                                                     # GEMM-feeding activation dtype
         self.device = self.ops.device
         self.seg_task = cfg.seg_task
@@ -126,11 +130,20 @@ class PSALM:
         for i in range(cfg.num_layers):
             p = f"model.layers.{i}."
             a = p + "self_attn."
-            w[f"llm{i}.w1"] = W(torch.cat([sd[a + "k_proj.weight"], sd[a + "v_proj.weight"], sd[a + "q_proj.weight"],
-                                           sd[p + "mlp.fc1.weight"]], 0))
+            w1 = torch.cat([sd[a + "k_proj.weight"], sd[a + "v_proj.weight"], sd[a + "q_proj.weight"], sd[p + "mlp.fc1.weight"]], 0)
+            w2 = torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1)
+            if self.llm_fp8:                          # e4m3fn bytes + per-row scales (bf16-rounded weights, like the bf16 mode sees them)
+                for nm, mat in (("w1", w1), ("w2", w2)):
+                    m = mat.detach().float().bfloat16().float()
+                    amax = m.abs().amax(1, keepdim=True)
+                    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+                    w[f"llm{i}.{nm}q"] = self._aligned((m * (1.0 / sc)).to(torch.float8_e4m3fn).view(torch.uint8).contiguous().to(self.device))
+                    w[f"llm{i}.{nm}s"] = Fp(sc.view(-1))
+            else:
+                w[f"llm{i}.w1"] = W(w1)
+                w[f"llm{i}.w2"] = W(w2)
             w[f"llm{i}.b1"] = Fp(torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"],
                                             sd[p + "mlp.fc1.bias"]], 0))
-            w[f"llm{i}.w2"] = W(torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1))
             w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"] + sd[p + "mlp.fc2.bias"])
             norm(f"llm{i}.ln", p + "input_layernorm")
         norm("llm.final", "model.final_layernorm")
@@ -447,11 +460,19 @@ class PSALM:
         h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
             last = i == cfg.num_layers - 1
+            ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
+            if self.llm_fp8:
+                hq, hs = o.quantize_rows_fp8(h)
+                o.gemm_fp8(hq, hs, w[f"llm{i}.w1q"], w[f"llm{i}.w1s"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
+                o.causal_attention(big, 2 * Hd, 0, Hd, big, 2 * Hd, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim, cfg.rotary_dim)
+                aq, as_ = o.quantize_rows_fp8(big[:, 2 * Hd:])                    # one row scale over [attn | gelu(fc1)]
+                x = o.gemm_fp8(aq, as_, w[f"llm{i}.w2q"], w[f"llm{i}.w2s"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
+                continue
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place
             o.causal_attention(big, 2 * Hd, 0, Hd, big, 2 * Hd, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
                                cfg.rotary_dim)
-            ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
             if fused:
                 x, h = o.gemm_ln(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb, cfg.layer_norm_eps,
                                  ln_dtype=torch.float32 if last else self.adt)

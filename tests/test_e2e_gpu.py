@@ -205,3 +205,34 @@ def test_golden_instance_384(precision, rtol):
     else:
         # random-weight bf16 (see test_golden_panoptic_512): individual near-tied candidates swap, the score distribution holds
         assert float(np.abs(sc - np.sort(z["inst_scores"])).mean()) < 0.05 and sc_err < 0.6
+
+
+def test_fp8_llm_path_on_gpu():
+    """precision="fp8" (BASELINE.json configs[4]: interactive / region prompts with the fp8 MFMA LLM path): full-size architecture
+    with a 2-layer LLM, 384x384, vs the oracle evaluated with the same e4m3 fake-quantisation (tolerance = bf16 mode's), plus the
+    distance to the reference-generated golden vectors (reported; e4m3 has 3 mantissa bits)."""
+    from psalm_amd.model import PSALM
+    case, z = load_case("region_384")
+    cfg = PsalmConfig(num_layers=case["layers"], seg_task=case["task"])
+    sd = make_state_dict(cfg, seed=case["seed"])
+    inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"])
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    torch.manual_seed(RNG_SEED_AT_CALL)
+    _, st8 = O.eval_seg(sd, cfg, return_stages=True, postprocess=False, llm_fp8=True, **inputs)
+    model = PSALM(cfg, sd, precision="fp8")
+    stages = {}
+    torch.manual_seed(RNG_SEED_AT_CALL)
+    outs = model.forward_logits(stages=stages, **kw)
+    torch.manual_seed(RNG_SEED_AT_CALL)
+    res = model.eval_seg(**inputs)
+    torch.cuda.synchronize()
+    Lb = st8["lengths"][0]
+    hs = stages["hidden_states"][0, :Lb].float().cpu()
+    e_h = float((hs - st8["hidden_states"][0, :Lb]).abs().max() / st8["hidden_states"][0, :Lb].abs().max())
+    pm = outs[0]["pred_masks"].float().cpu()
+    e_m = float((pm - st8["pred_masks"][0]).abs().max() / st8["pred_masks"][0].abs().max())
+    g = torch.from_numpy(z["pred_masks_s4"])[0]
+    e_gold = float((pm[:, ::4, ::4] - g).abs().max() / g.abs().max())
+    _report(test="fp8_region_384", hidden_err_vs_fp8_oracle=e_h, mask_err_vs_fp8_oracle=e_m, mask_err_vs_reference_golden=e_gold)
+    assert e_h < 3e-2 and e_m < 0.12
+    assert res[0]["instances"].pred_masks.shape[0] == cfg.md_queries

@@ -94,3 +94,27 @@ def test_tiny_eval_seg_postprocess_fp32(task, batch, pad):
             assert _rel(gi.scores, wi.scores) < 2e-3
             assert (gi.pred_masks.cpu() != wi.pred_masks).float().mean() < 1e-3
             assert _rel(g["gt"], w["gt"]) < 1e-5
+
+
+def test_tiny_fp8_llm_path_vs_fake_quant_oracle():
+    """precision="fp8": Phi projections on the e4m3 MFMA path.  Checked against the oracle evaluated with the same e4m3
+    fake-quantisation of the Phi linears (llm_fp8=True); tolerance = the bf16 mode's (all other arithmetic is the bf16 mode's).
+    Also reports how far the fp8 path is from the fp32 reference arithmetic."""
+    cfg = PsalmConfig.tiny("region")
+    sd = make_state_dict(cfg, seed=11)
+    inputs = make_inputs(cfg, "region", size=96, batch=2, seed=3)
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    torch.manual_seed(77)
+    _, st8 = O.eval_seg(sd, cfg, return_stages=True, postprocess=False, llm_fp8=True, **inputs)
+    torch.manual_seed(77)
+    _, st32 = O.eval_seg(sd, cfg, return_stages=True, postprocess=False, **inputs)
+    stages = {}
+    torch.manual_seed(77)
+    outs = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp8").forward_logits(stages=stages, **kw)
+    for b in range(2):
+        Lb = st8["lengths"][b]
+        assert _rel(stages["hidden_states"][b, :Lb], st8["hidden_states"][b, :Lb]) < 3e-2
+        assert _rel(outs[b]["pred_masks"], st8["pred_masks"][b]) < 8e-2
+    d32 = max(_rel(stages["hidden_states"][b, :st32["lengths"][b]], st32["hidden_states"][b, :st32["lengths"][b]]) for b in range(2))
+    d8 = max(_rel(stages["hidden_states"][b, :st8["lengths"][b]], st8["hidden_states"][b, :st8["lengths"][b]]) for b in range(2))
+    assert d8 < d32, (d8, d32)        # closer to its own arithmetic than to fp32: the quantisation itself is what is being tested

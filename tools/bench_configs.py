@@ -4,7 +4,7 @@ against the CPU oracle on the same seeded inputs, full-size architecture.
     python tools/bench_configs.py [--json out.json] [--skip-oracle] [--fp32]
   config 2  COCO-panoptic 1024x1024 batch=1            (bf16; --fp32 adds the exact-fp32 mode)
   config 3  RefCOCO referring 640x640 batch=4 (ragged sentences)
-  config 5* interactive (region prompts) 1024x1024 batch=2 -- bf16 LLM (the fp8 LLM path is not built yet)
+  config 5  interactive (region prompts) 1024x1024 batch=2 -- bf16 LLM and fp8 (OCP e4m3) LLM projections
 """
 import json
 import sys
@@ -67,7 +67,9 @@ def main():
     oracle = "--skip-oracle" not in sys.argv
     out = [run("2: panoptic 1024 b1", "panoptic", 1024, 1, "bf16", oracle),
            run("3: referring 640 b4", "referring", 640, 4, "bf16", oracle),
-           run("5*: region 1024 b2 (bf16 LLM)", "region", 1024, 2, "bf16", oracle)]
+           run("5*: region 1024 b2 (bf16 LLM)", "region", 1024, 2, "bf16", oracle),
+           run("5: region 1024 b2 (fp8 e4m3 LLM projections)", "region", 1024, 2, "fp8", oracle),
+           run("2': panoptic 1024 b1 (fp8 e4m3 LLM projections)", "panoptic", 1024, 1, "fp8", oracle)]
     if "--fp32" in sys.argv:
         out.append(run("2: panoptic 1024 b1 (exact fp32 mode)", "panoptic", 1024, 1, "fp32", oracle, steps=3))
     if "--json" in sys.argv:
