@@ -654,8 +654,9 @@ def region_inference(region_cls, mask_pred):                         # LP:387-40
 def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images, seg_info, class_name_ids=None,
              class_name_embedding_indices=None, cls_indices=None, token_refer_id=None, refer_embedding_indices=None,
              labels=None, is_thing_list=None, region_point_sampler: Callable = default_region_point_sampler,
-             return_stages: bool = False, postprocess: bool = True, msda_fn=msda_core, llm_fp8: bool = False):
-    """LP:1317-1472.  Returns list[dict] for ALL images (and the stage tensors if asked).
+             return_stages: bool = False, postprocess: bool = True, msda_fn=msda_core, llm_fp8: bool = False, vp_images=None):
+    """LP:1317-1472 (and, with vp_images, PSALMForDAVISEval.eval_video LP:1845-1998).  Returns list[dict] for ALL images
+    (and the stage tensors if asked).
     llm_fp8: evaluate the Phi projections with e4m3 fake-quantised operands (see phi_forward) -- checker for precision="fp8"."""
     task = cfg.seg_task
     st = {}
@@ -664,8 +665,16 @@ def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images
     st.update(res2=feats[0], res3=feats[1], res4=feats[2], res5=feats[3], image_tokens=image_tokens)
     region_features = None
     if (input_ids == REGION_TOKEN_INDEX).sum() != 0:                 # LP:1346-1349, LP:791-797
-        region_features = region_pooling(image_tokens, [s["instances"].region_masks.tensor for s in seg_info],
-                                         cfg.region_points, region_point_sampler)
+        if vp_images is not None:
+            # PSALMForDAVISEval.eval_video (LP:1845-1998): identical to eval_seg except that the region features are pooled
+            # from the PREVIOUS frame `vp_images` (its own Swin + projector pass) at `vp_region_masks` (LP:1663-1670)
+            vp_tokens = projector_forward(sd, swin_forward(sd, cfg, vp_images)[-1])
+            st["vp_image_tokens"] = vp_tokens
+            region_features = region_pooling(vp_tokens, [s["instances"].vp_region_masks.tensor for s in seg_info],
+                                             cfg.region_points, region_point_sampler)
+        else:
+            region_features = region_pooling(image_tokens, [s["instances"].region_masks.tensor for s in seg_info],
+                                             cfg.region_points, region_point_sampler)
         st["region_features"] = region_features
     sp = splice_inputs(sd, cfg, input_ids, attention_mask, image_tokens, class_name_ids, cls_indices, token_refer_id,
                        region_features, class_name_embedding_indices is not None, refer_embedding_indices is not None)

@@ -25,7 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct alignas(16) u32x4_a { unsigned x, y, z, w; };
 struct alignas(8) u32x2_a { unsigned x, y; };
 
-__device__ __forceinline__ unsigned pk2(float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ unsigned pk2(float a, float b) { return pack_bf16x2(a, b); }
 
 // ---------------------------------------------------------------------------------------------- pre-pass
 // grid (Lp/64, heads, B), block 256.  buf (B*L, ld) bf16 with q/k/v column blocks.  Lp = ceil(L/64)*64.
@@ -195,17 +195,24 @@ __global__ void __launch_bounds__(256) causal_attention_mfma_kernel(const bf16_t
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, bq[kk], s[t], 0, 0, 0);
             }
         }
-        // mask + tile max
+        // mask + tile max.  Tiles entirely below the diagonal with no padded key (almost all of them) skip the mask arithmetic.
         float mloc = NEG;
+        if (k0 + 63 <= q0 && kbits == ~0ull) {                  // wave-uniform
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;      // key index within the 64-key tile
-                const bool ok = ((kb_hi >> (kl - 4 * hi)) & 1ull) && (k0 + kl <= qi);
-                s[t][r] = ok ? s[t][r] : NEG;
-                mloc = fmaxf(mloc, s[t][r]);
-            }
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index within the 64-key tile
+                    const bool ok = ((kb_hi >> (kl - 4 * hi)) & 1ull) && (k0 + kl <= qi);
+                    s[t][r] = ok ? s[t][r] : NEG;
+                    mloc = fmaxf(mloc, s[t][r]);
+                }
+        }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float mn = fmaxf(m, mloc);
         const float alpha = __expf(m - mn);
@@ -302,6 +309,8 @@ extern "C" int psalm_causal_attention_mfma(const void* qkv, long ld, int q_off, 
 // (swin_trans.py:131-134) is one LDS read at byte address  Aq4 - Bk4  per score.  The whole 160-key score row of a
 // query lives in accumulator registers (5 x 16 fp32), so the softmax is exact two-pass (no online rescale).
 // Same swapped-operand trick as above: S^T = K.Q^T, O^T = V^T.P^T with P^T taken straight from the accumulators.
+template <bool V> struct MaskTag { static constexpr bool value = V; };
+
 template <int WS>
 __global__ void __launch_bounds__(320) window_attention_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                     const float* __restrict__ bias_table,
@@ -377,23 +386,33 @@ __global__ void __launch_bounds__(320) window_attention_mfma_kernel(const bf16_t
     constexpr float NEG = -1.0e30f;
     float mx = NEG;
     const char* Bbytes = reinterpret_cast<const char*>(Bs);
+    // scale + relative-position bias (+ shift mask): the -100 mask can only differ from 0 in windows of the last window row /
+    // column of a shifted block (block-uniform), and padded keys (144..159) are the compile-time registers g >= 2 of tile 4.
+    auto finish_scores = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // accumulator registers 4g..4g+3 hold keys 32t + 8g + 4hi + {0,1,2,3}: one 16-byte read of the key table
-            const u32x4_a kt4 = *reinterpret_cast<const u32x4_a*>(&Kt[32 * t + 8 * g + 4 * hi]);
-            const unsigned kv[4] = {kt4.x, kt4.y, kt4.z, kt4.w};
+            for (int g = 0; g < 4; ++g) {
+                if (32 * t + 8 * g >= N) {                                   // padded keys: no contribution
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kl = (int)(kv[i] >> 16);
-                float v = s[t][4 * g + i] * scale + *reinterpret_cast<const float*>(Bbytes + (Aq4 - (int)(kv[i] & 0xffffu)));
-                if (shift > 0 && kl != qlabel) v += -100.0f;
-                v = kl == 15 ? NEG : v;
-                s[t][4 * g + i] = v;
-                mx = fmaxf(mx, v);
+                    for (int i = 0; i < 4; ++i) s[t][4 * g + i] = NEG;
+                    continue;
+                }
+                // accumulator registers 4g..4g+3 hold keys 32t + 8g + 4hi + {0,1,2,3}: one 16-byte read of the key table
+                const u32x4_a kt4 = *reinterpret_cast<const u32x4_a*>(&Kt[32 * t + 8 * g + 4 * hi]);
+                const unsigned kv[4] = {kt4.x, kt4.y, kt4.z, kt4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = s[t][4 * g + i] * scale + *reinterpret_cast<const float*>(Bbytes + (Aq4 - (int)(kv[i] & 0xffffu)));
+                    if (MASKED && (int)(kv[i] >> 16) != qlabel) v += -100.0f;
+                    s[t][4 * g + i] = v;
+                    mx = fmaxf(mx, v);
+                }
             }
-        }
+    };
+    if (last_r || last_c) finish_scores(MaskTag<true>{});
+    else finish_scores(MaskTag<false>{});
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
     f32x16 o;

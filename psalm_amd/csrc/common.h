@@ -19,6 +19,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-ev
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two floats -> packed bf16 pair (lo = a, hi = b), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950
+typedef float psalm_f32x2_v __attribute__((ext_vector_type(2)));
+typedef __bf16 psalm_bf16x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const psalm_f32x2_v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, psalm_bf16x2_v));
+}
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
@@ -73,8 +80,7 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, const float* v) {
     *reinterpret_cast<psalm_u32x4*>(p) =
-        psalm_u32x4{(unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16), (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16),
-                    (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16), (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16)};
+        psalm_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
 }
 
 // 64-lane wavefront reductions (CDNA wave = 64)

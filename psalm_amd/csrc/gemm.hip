@@ -46,7 +46,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // 8 consecutive K elements of one row -> 8 bf16 (16 B).  Out-of-range rows / K-chunks give zeros.
 __device__ __forceinline__ u32x4_s load8_bf16(const bf16_t* p, bool ok) {

@@ -629,7 +629,7 @@ class PSALM:
 
     # ======================================================================================= host preparation
     def _prepare(self, input_ids, attention_mask, images, seg_info, class_name_ids, class_name_embedding_indices, cls_indices,
-                 token_refer_id, refer_embedding_indices, region_point_sampler):
+                 token_refer_id, refer_embedding_indices, region_point_sampler, video: bool = False):
         """Everything of one call that is host integer / RNG work (llava_phi.py:767-971 token splicing, region point
         sampling context_cluster.py:345-356, crop boxes LP:1418-1423), packed into ONE byte blob so that a call costs a
         single host->device copy.  Returns (blob uint8 ndarray, layout {name: (offset, count, dtype)}, meta)."""
@@ -643,7 +643,8 @@ class PSALM:
         arrays = {}
         n_regions = None
         if bool((input_ids == REGION_TOKEN_INDEX).any()):
-            pts, n_regions = self.region_points([s["instances"].region_masks.tensor for s in seg_info], region_point_sampler)
+            pts, n_regions = self.region_points([(s["instances"].vp_region_masks if video else s["instances"].region_masks).tensor
+                                                 for s in seg_info], region_point_sampler)                # LP:792 / LP:1664
             arrays["region_img"] = np.asarray([b for b, k in enumerate(n_regions) for _ in range(k)], np.int32)
             arrays["region_pts"] = np.ascontiguousarray(pts.numpy(), np.float32)
         # the splice plan depends only on the (small) integer prompt tensors: identical prompts -- every image of a panoptic /
@@ -691,7 +692,7 @@ class PSALM:
             blob[o0:o0 + a.nbytes] = a.view(np.uint8).reshape(-1)
         meta = {"B": B, "L": plan["L"], "lens": plan["lens"], "n_img": n_img, "n_cls": tuple(plan["n_cls"]),
                 "n_regions": tuple(n_regions) if n_regions is not None else None, "post": tuple(post),
-                "img_shape": tuple(images.shape), "layout": tuple(sorted(layout.items()))}
+                "img_shape": tuple(images.shape), "layout": tuple(sorted(layout.items())), "video": video}
         return blob, layout, meta
 
     @staticmethod
@@ -710,7 +711,7 @@ class PSALM:
         return self._side
 
     # ======================================================================================= device forward
-    def _forward_device(self, images, dv, meta, stages: Optional[dict] = None, postprocess: bool = True):
+    def _forward_device(self, images, dv, meta, stages: Optional[dict] = None, postprocess: bool = True, vp_images=None):
         """All device work of eval_seg (LP:1350-1466): only kernel launches on the current stream, no host round trip
         (so the whole call can be captured into one hipGraph).  images (B,3,H,W) fp32 on device; dv: device views of
         the prepared blob.  Returns per-image predictor outputs (postprocess=False) or result dicts with `_pending`."""
@@ -726,7 +727,11 @@ class PSALM:
         if n_regions is not None:                                                      # region pooling (LP:791-797)
             side = int(math.sqrt(n_img))
             R = sum(n_regions)
-            region_feats = o.region_pool(img_tok, dv["region_img"], dv["region_pts"].view(R, -1, 2), side, side, n_img)
+            pool_tok = img_tok
+            if vp_images is not None:            # eval_video: pool from the previous frame's projector tokens (LP:1663-1670)
+                vf = self.swin(vp_images)
+                pool_tok, _ = self.projector(vf[3][0], B, vf[3][1], vf[3][2])
+            region_feats = o.region_pool(pool_tok, dv["region_img"], dv["region_pts"].view(R, -1, 2), side, side, n_img)
         # ---- the pixel decoder needs only the Swin features, the LLM only the projector tokens: run them concurrently on two
         # HIP streams (the decoder's ~150 small, latency-bound kernels fill the gaps of the LLM's large GEMMs); joined
         # before the predictor.  Captured as a fork/join inside the hipGraph in graph mode.
@@ -788,14 +793,17 @@ class PSALM:
     def forward_logits(self, input_ids, attention_mask, images, seg_info=None, class_name_ids=None,
                        class_name_embedding_indices=None, cls_indices=None, token_refer_id=None,
                        refer_embedding_indices=None, labels=None, region_point_sampler: Callable = default_region_point_sampler,
-                       stages: Optional[dict] = None):
+                       stages: Optional[dict] = None, vp_images=None):
         """Everything of eval_seg up to the predictor outputs (LP:1350-1398).  Returns a list (one per image) of
         dicts with pred_masks (Q,h,w) fp32, pred_class_name_logits (Q,C+1) / pred_SEG_logits (Q,1) / pred_region_logits (k,Q)."""
         images = images.to(self.device, torch.float32).contiguous()
+        if vp_images is not None:
+            vp_images = vp_images.to(self.device, torch.float32).contiguous()
         blob, layout, meta = self._prepare(input_ids, attention_mask, images, seg_info, class_name_ids, class_name_embedding_indices,
-                                           cls_indices, token_refer_id, refer_embedding_indices, region_point_sampler)
+                                           cls_indices, token_refer_id, refer_embedding_indices, region_point_sampler,
+                                           video=vp_images is not None)
         dv = self._views(torch.from_numpy(blob).to(self.device), layout)
-        return self._forward_device(images, dv, meta, stages=stages, postprocess=False)
+        return self._forward_device(images, dv, meta, stages=stages, postprocess=False, vp_images=vp_images)
 
     # ======================================================================================= post-processing + eval_seg
     def _postprocess(self, r, sizes):
@@ -904,25 +912,28 @@ class PSALM:
         return res
 
     # ---- hipGraph execution: the ~600 launches of one call are captured once per input signature and replayed
-    def _run_graphed(self, images, blob, layout, meta):
-        key = (self.seg_task, self.precision, meta["img_shape"], meta["L"], meta["n_cls"], meta["n_regions"], meta["post"],
+    def _run_graphed(self, images, blob, layout, meta, vp_images=None):
+        key = (self.seg_task, self.precision, meta["video"], meta["img_shape"], meta["L"], meta["n_cls"], meta["n_regions"], meta["post"],
                meta["layout"], tuple(int(bool(x)) for x in self.is_thing_list) if self.is_thing_list is not None else None)
         ent = self._graphs.get(key)
         host = torch.from_numpy(blob)
         if ent is None:                                    # first sighting: eager run (fills caches / workspaces, warms the allocator)
             self._graphs[key] = {"seen": 1}
             dv = self._views(host.to(self.device), layout)
-            return self._forward_device(images, dv, meta)
+            return self._forward_device(images, dv, meta, vp_images=vp_images)
         if "graph" not in ent:                             # second sighting: capture
             ent["images"] = images.clone()
+            ent["vp"] = vp_images.clone() if vp_images is not None else None
             ent["blob"] = host.to(self.device)
             dv = self._views(ent["blob"], layout)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                ent["outs"] = self._forward_device(ent["images"], dv, meta)
+                ent["outs"] = self._forward_device(ent["images"], dv, meta, vp_images=ent["vp"])
             ent["graph"] = g
         ent["images"].copy_(images)
+        if vp_images is not None:
+            ent["vp"].copy_(vp_images)
         ent["blob"].copy_(host)
         ent["graph"].replay()
         return ent["outs"]
@@ -932,7 +943,7 @@ class PSALM:
                  use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
                  seg_info=None, class_name_ids=None, class_name_embedding_indices=None, cls_indices=None,
                  token_refer_id=None, refer_embedding_indices=None, is_thing_list=None,
-                 region_point_sampler: Callable = default_region_point_sampler):
+                 region_point_sampler: Callable = default_region_point_sampler, vp_images=None):
         """Same keyword signature as the reference's PSALM.eval_seg (llava_phi.py:1317-1336).  Returns list[dict] with
         `sem_seg`, `instances`, `panoptic_seg` (panoptic) / `instances` (referring) / `instances`,`gt` (region), one entry
         per image (the reference stops after image 0, LP:1472).
@@ -942,12 +953,26 @@ class PSALM:
             assert is_thing_list is not None, "is_thing_list need to be given"        # LP:1337-1339
             self.is_thing_list = is_thing_list
         images = images.to(self.device, torch.float32).contiguous()
+        if vp_images is not None:
+            vp_images = vp_images.to(self.device, torch.float32).contiguous()
         blob, layout, meta = self._prepare(input_ids, attention_mask, images, seg_info, class_name_ids,
                                            class_name_embedding_indices, cls_indices, token_refer_id, refer_embedding_indices,
-                                           region_point_sampler)
+                                           region_point_sampler, video=vp_images is not None)
         if self.use_graphs and not self.ops.is_emu:
-            results = self._run_graphed(images, blob, layout, meta)
+            results = self._run_graphed(images, blob, layout, meta, vp_images)
         else:
             dv = self._views(torch.from_numpy(blob).to(self.device), layout)
-            results = self._forward_device(images, dv, meta)
+            results = self._forward_device(images, dv, meta, vp_images=vp_images)
         return [self._finalize(r, seg_info[b]) for b, r in enumerate(results)]
+
+    def eval_video(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                   use_cache=None, output_attentions=None, output_hidden_states=None, images=None, vp_images=None,
+                   return_dict=None, seg_info=None, class_name_ids=None, class_name_embedding_indices=None, cls_indices=None,
+                   token_refer_id=None, refer_embedding_indices=None, is_thing_list=None,
+                   region_point_sampler: Callable = default_region_point_sampler):
+        """PSALMForDAVISEval.eval_video (llava_phi.py:1845-1998), same keyword signature: eval_seg whose <region> features are
+        pooled from the previous frame `vp_images` at `seg_info[i]['instances'].vp_region_masks` (LP:1663-1670)."""
+        return self.eval_seg(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images, seg_info=seg_info,
+                             class_name_ids=class_name_ids, class_name_embedding_indices=class_name_embedding_indices,
+                             cls_indices=cls_indices, token_refer_id=token_refer_id, refer_embedding_indices=refer_embedding_indices,
+                             is_thing_list=is_thing_list, region_point_sampler=region_point_sampler, vp_images=vp_images)

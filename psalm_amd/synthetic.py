@@ -218,13 +218,15 @@ class RegionInstances:
         def __init__(self, t):
             self.tensor = t
 
-    def __init__(self, region_masks: torch.Tensor, gt_masks: torch.Tensor):
+    def __init__(self, region_masks: torch.Tensor, gt_masks: torch.Tensor, vp_region_masks: Optional[torch.Tensor] = None):
         self.region_masks = RegionInstances._T(region_masks)
         self.gt_masks = gt_masks
+        if vp_region_masks is not None:           # DAVIS / eval_video: prompt masks drawn on the PREVIOUS frame (llava_phi.py:1664)
+            self.vp_region_masks = RegionInstances._T(vp_region_masks)
 
 
 def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batch: int = 1, seed: int = 0,
-                num_classes: int = 133, pad: Optional[int] = None) -> dict:
+                num_classes: int = 133, pad: Optional[int] = None, video: bool = False) -> dict:
     """Keyword dict for `eval_seg(**inputs)`.
 
     panoptic : [txt.. <image> txt..] + C x [<cls> ,] + [txt.. <seg> txt]   (train_datasets.py:208-217)
@@ -285,7 +287,12 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
                 cx = int(torch.randint(size // 8, size - size // 8, (1,), generator=g))
                 masks.append(_disc(size, cy, cx, max(2, size // 100)))
             rm = torch.stack(masks)
-            seg_info[b]["instances"] = RegionInstances(rm, rm.clone().float())
+            vp = None
+            if video:                                          # visual prompts live on the previous frame: different discs
+                vp = torch.stack([_disc(size, int(torch.randint(size // 8, size - size // 8, (1,), generator=g)),
+                                        int(torch.randint(size // 8, size - size // 8, (1,), generator=g)), max(2, size // 80))
+                                  for _ in range(k)])
+            seg_info[b]["instances"] = RegionInstances(rm, rm.clone().float(), vp)
     else:
         raise ValueError(task)
 
@@ -295,6 +302,8 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
     for b, ids in enumerate(ids_list):
         input_ids[b, : len(ids)] = torch.tensor(ids)
         attn[b, : len(ids)] = True
+    if video:
+        out["vp_images"] = torch.randn(batch, 3, size, size, generator=g, dtype=torch.float32)
     out["input_ids"] = input_ids
     out["attention_mask"] = attn
     out["labels"] = input_ids.clone()

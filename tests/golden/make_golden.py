@@ -40,6 +40,8 @@ CASES = {
     # crop + resize acts on the 133-plane semantic map) and instance (top-k without the thing filter)
     "semantic_384": dict(task="semantic", size=384, batch=1, layers=2, seed=3, pad=32),
     "instance_384": dict(task="instance", size=384, batch=1, layers=2, seed=4, pad=32),
+    # PSALMForDAVISEval.eval_video (LP:1845-1998): region prompts pooled from the previous frame (vp_images, vp_region_masks)
+    "video_region_384": dict(task="region", size=384, batch=1, layers=2, seed=5, pad=0, video=True),
 }
 RNG_SEED_AT_CALL = 1234
 
@@ -57,8 +59,10 @@ def signature(t: torch.Tensor, n=256):
             "absmax": np.float64(t.abs().max()), "idx": idx.numpy(), "val": t[idx].numpy()}
 
 
-def build_reference(cfg: PsalmConfig, sd):
+def build_reference(cfg: PsalmConfig, sd, video=False):
     PSALM, LlavaConfig = ref_shim.reference_classes()
+    if video:
+        from psalm.model.language_model.llava_phi import PSALMForDAVISEval as PSALM  # type: ignore
     mask_cfg = ref_shim.load_reference_mask_cfg(cfg.seg_task)
     hf = LlavaConfig(vocab_size=cfg.vocab_size + 2, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                      num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads,
@@ -80,8 +84,8 @@ def run_case(name, c):
     t0 = time.time()
     sd = make_state_dict(cfg, seed=c["seed"], include_lm_head=True)
     print(f"[{name}] synthetic state dict: {len(sd)} tensors, {sum(v.numel() for v in sd.values())/1e9:.2f} B params, {time.time()-t0:.1f}s")
-    model = build_reference(cfg, sd)
-    inputs = make_inputs(cfg, task=c["task"], size=c["size"], batch=c["batch"], seed=c["seed"], pad=c["pad"])
+    model = build_reference(cfg, sd, video=c.get("video", False))
+    inputs = make_inputs(cfg, task=c["task"], size=c["size"], batch=c["batch"], seed=c["seed"], pad=c["pad"], video=c.get("video", False))
 
     stages = {}
     hooks = []
@@ -103,7 +107,7 @@ def run_case(name, c):
     torch.manual_seed(RNG_SEED_AT_CALL)
     t0 = time.time()
     with torch.no_grad():
-        out = model.eval_seg(**inputs)
+        out = model.eval_video(**inputs) if c.get("video") else model.eval_seg(**inputs)
     dt = time.time() - t0
     print(f"[{name}] reference eval_seg: {dt:.2f}s, returned {len(out)} result(s) (reference stops after image 0, LP:1472)")
     for h in hooks:

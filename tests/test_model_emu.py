@@ -118,3 +118,23 @@ def test_tiny_fp8_llm_path_vs_fake_quant_oracle():
     d32 = max(_rel(stages["hidden_states"][b, :st32["lengths"][b]], st32["hidden_states"][b, :st32["lengths"][b]]) for b in range(2))
     d8 = max(_rel(stages["hidden_states"][b, :st8["lengths"][b]], st8["hidden_states"][b, :st8["lengths"][b]]) for b in range(2))
     assert d8 < d32, (d8, d32)        # closer to its own arithmetic than to fp32: the quantisation itself is what is being tested
+
+
+def test_tiny_eval_video_vs_oracle():
+    """eval_video (PSALMForDAVISEval, LP:1845-1998): region features pooled from the previous frame; fp32 mode vs the oracle.
+    (The post-processing around it is eval_seg's; the full call is checked on the GPU against the reference-generated golden.)"""
+    cfg = PsalmConfig.tiny("region")
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, "region", size=96, batch=1, seed=4, video=True)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    torch.manual_seed(5)
+    _, st = O.eval_seg(sd, cfg, return_stages=True, postprocess=False, **inputs)
+    torch.manual_seed(5)
+    a = model.forward_logits(**kw)[0]
+    assert _rel(a["pred_region_logits"], st["pred_region_logits"][0]) < 2e-3
+    assert _rel(a["pred_masks"], st["pred_masks"][0]) < 2e-3
+    # the previous frame really is what the region tokens are pooled from: region logits change when it is dropped
+    torch.manual_seed(5)
+    b_ = model.forward_logits(**{k: v for k, v in kw.items() if k != "vp_images"})[0]
+    assert (a["pred_region_logits"] - b_["pred_region_logits"]).abs().max() > 1e-3 * a["pred_region_logits"].abs().max()

@@ -18,7 +18,8 @@ def _run(name):
     case, z = load_case(name)
     cfg = PsalmConfig(num_layers=case["layers"], seg_task=case["task"])
     sd = make_state_dict(cfg, seed=case["seed"])
-    inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"])
+    inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"],
+                         video=case.get("video", False))
     torch.manual_seed(RNG_SEED_AT_CALL)
     results, st = O.eval_seg(sd, cfg, return_stages=True, **inputs)
     return case, z, cfg, results, st
@@ -26,7 +27,8 @@ def _run(name):
 
 def _check_stages(z, st):
     for k in ("res2", "res3", "res4", "res5", "image_tokens", "hidden_states", "mask_features", "pred_masks"):
-        check_signature(z, k, st[k], STAGE_RTOL)
+        # eval_video: the reference's projector hook fires last for the previous frame (vp_images), LP:1665
+        check_signature(z, k, st["vp_image_tokens"] if (k == "image_tokens" and "vp_image_tokens" in st) else st[k], STAGE_RTOL)
     for i in range(3):
         check_signature(z, f"ms{i}", st["multi_scale_features"][i], STAGE_RTOL)
 
@@ -104,3 +106,13 @@ def test_instance_384():
     np.testing.assert_allclose(inst.scores.numpy()[og], z["inst_scores"][ow], atol=1e-4)
     assert (inst.pred_classes.numpy()[og] == z["inst_classes"][ow]).all()
     assert np.abs(np.sort(inst.pred_masks.flatten(1).sum(1).numpy()) - np.sort(z["inst_mask_area"])).max() <= 2
+
+
+@pytest.mark.slow
+def test_video_region_384():
+    """PSALMForDAVISEval.eval_video: region features pooled from the previous frame (golden generated by the reference class)."""
+    case, z, cfg, results, st = _run("video_region_384")
+    _check_stages(z, st)
+    got = torch.cat([x.reshape(-1) for x in st["pred_region_logits"]]).numpy()
+    np.testing.assert_allclose(got, z["pred_region_logits"], rtol=0, atol=2e-4 * np.abs(z["pred_region_logits"]).max())
+    np.testing.assert_allclose(results[0]["instances"].scores.numpy(), z["inst_scores"], atol=1e-4)
