@@ -8,9 +8,11 @@ decoder -> semantic / instance / panoptic post-processing at full resolution.  R
 architecture (seeded), bf16 MFMA GEMMs with fp32 accumulation.  Images are independent, so N GPUs = N replicas of the
 weights (one RCCL broadcast at start-up) each processing its own image: weak scaling, no data-path collective.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel family (the bf16 MFMA GEMM) measured with HIP
-events around every launch in extra, instrumented steps after the timed region; `cpu_baseline` is the oracle
-(CPU restatement of the reference, fp32) timed on this host for one image of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel -- the un-split bf16 MFMA GEMM instantiation with the
+largest share of the step -- from HIP events (on the launch stream) around every C-ABI launch in extra, instrumented eager steps
+after the timed region; `traffic` = its HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
+(profiles/r01_pmc_hbm_traffic.json).  `cpu_baseline` is the oracle (CPU restatement of the reference, fp32) timed on this host
+for one image of the same workload; `parity_vs_cpu_oracle` compares the timed run's last result with it.
 """
 import argparse
 import json

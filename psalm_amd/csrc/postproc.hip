@@ -126,75 +126,108 @@ extern "C" int psalm_mask_scores(const float* mask, float* score, float* workspa
 // index), in descending order.  Then the reference's filtering (LP:417-446):
 //   label = idx % C, query = idx / C; keep only is_thing[label] (if is_thing != NULL);
 //   out_score = value * mask_score[query]; compacted in pick order.  count[0] = number kept.
+// Radix select on the 46-bit key (sortable value bits << 14 | (16383 - index)): keys are distinct, so the k-th largest key is a
+// sharp threshold (no tie handling) and sorting the k survivors by key reproduces "value descending, index ascending".
+__device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                  // monotone map float -> unsigned
+    return ((unsigned long long)u << 14) | (unsigned long long)(16383 - idx);
+}
+
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ vals, int Q, int C, int stride, int k,
                                                            const int* __restrict__ is_thing, const float* __restrict__ mask_score,
                                                            float* __restrict__ out_score, int* __restrict__ out_class,
                                                            int* __restrict__ out_query, int* __restrict__ count, int apply_sigmoid) {
-    __shared__ float wv[16];
-    __shared__ int wi[16];
-    __shared__ int picked_idx;
-    __shared__ float picked_val;
-    __shared__ int nkept;
+    __shared__ int hist[256];
+    __shared__ unsigned long long sel_key[128];
+    __shared__ float sel_val[128];
+    __shared__ unsigned long long prefix_s;
+    __shared__ int remaining_s, nsel;
     constexpr int PER = 16;                       // up to 16384 candidates
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int n = Q * C;
+    const int kk = min(min(k, n), 128);
     float v[PER];
+    unsigned long long key[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = tid + j * 1024;
-        float x = -3.0e38f;
+        float x = 0.f;
         if (i < n) {
             x = vals[(long)(i / C) * stride + (i % C)];
             if (apply_sigmoid) x = sigmoidf_(x);
         }
         v[j] = x;
+        key[j] = i < n ? topk_key(x, i) : 0ull;                      // 0 < every real key (real keys have bit 45 or the index field set)
     }
-    if (tid == 0) nkept = 0;
+    if (tid == 0) { prefix_s = 0ull; remaining_s = kk; nsel = 0; }
     __syncthreads();
-    for (int r = 0; r < k && r < n; ++r) {
-        float best = -3.0e38f;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int i = tid + j * 1024;
-            if (v[j] > best) { best = v[j]; bi = i; }       // ascending i within a thread: first max kept
-        }
-        const float wbest = wave_max(best);
-        int cand = (best == wbest && best > -3.0e38f) ? bi : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
-        if (lane == 0) { wv[wave] = wbest; wi[wave] = cand; }
+    // 6 passes over 8-bit digits, most significant first (bits 47..0 cover the 46-bit key)
+    for (int shift = 40; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        if (tid == 0) {
-            float b = -3.0e38f;
-            int bidx = 0x7fffffff;
-            for (int w = 0; w < 16; ++w)
-                if (wv[w] > b || (wv[w] == b && wi[w] < bidx)) { b = wv[w]; bidx = wi[w]; }
-            picked_idx = bidx;
-            picked_val = b;
-            const int lab = bidx % C, qq = bidx / C;
+        const unsigned long long prefix = prefix_s;
+        const unsigned long long himask = shift == 40 ? 0ull : (~0ull << (shift + 8));
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (key[j] != 0ull && (key[j] & himask) == prefix) atomicAdd(&hist[(int)((key[j] >> shift) & 255ull)], 1);
+        __syncthreads();
+        if (tid == 0) {                                               // walk the digits from the top: where does the k-th key fall
+            int rem = remaining_s, d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= rem) break;
+                rem -= hist[d];
+            }
+            remaining_s = rem;
+            prefix_s = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long thr = prefix_s;                          // the kk-th largest key
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (key[j] != 0ull && key[j] >= thr && kk > 0) {
+            const int slot = atomicAdd(&nsel, 1);
+            sel_key[slot] = key[j];
+            sel_val[slot] = v[j];
+        }
+    __syncthreads();
+    for (int e = nsel + tid; e < 128; e += 1024) { sel_key[e] = 0ull; sel_val[e] = 0.f; }
+    __syncthreads();
+    // bitonic sort of 128 (key, value) pairs, descending by key
+    for (int size = 2; size <= 128; size <<= 1)
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            if (tid < 64) {
+                const int lo = 2 * tid - (tid & (st - 1));            // index pairs (lo, lo + st)
+                const int hi_ = lo + st;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = sel_key[lo], b = sel_key[hi_];
+                if ((a < b) == desc) {
+                    sel_key[lo] = b; sel_key[hi_] = a;
+                    const float fa = sel_val[lo]; sel_val[lo] = sel_val[hi_]; sel_val[hi_] = fa;
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        int nkept = 0;
+        for (int r = 0; r < kk; ++r) {
+            const int idx = 16383 - (int)(sel_key[r] & 16383ull);
+            const int lab = idx % C, qq = idx / C;
             if (!is_thing || is_thing[lab]) {
-                out_score[nkept] = b * (mask_score ? mask_score[qq] : 1.f);
+                out_score[nkept] = sel_val[r] * (mask_score ? mask_score[qq] : 1.f);
                 out_class[nkept] = lab;
                 out_query[nkept] = qq;
                 nkept++;
             }
         }
-        __syncthreads();
-        const int pi = picked_idx;
-        if ((pi & 1023) == tid) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                if (j == (pi >> 10)) v[j] = -3.0e38f;
-        }
+        count[0] = nkept;
     }
-    __syncthreads();
-    if (tid == 0) count[0] = nkept;
 }
 
 extern "C" int psalm_topk_select(const float* vals, int Q, int C, int stride, int k, const int* is_thing, const float* mask_score,
                                  float* out_score, int* out_class, int* out_query, int* count, int apply_sigmoid, void* stream) {
-    PSALM_CHECK_ARG((long)Q * C <= 16384, "psalm_topk_select: at most 16384 candidates");
+    PSALM_CHECK_ARG((long)Q * C <= 16384 && k <= 128, "psalm_topk_select: at most 16384 candidates, k <= 128");
     hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vals, Q, C, stride, k, is_thing, mask_score,
                        out_score, out_class, out_query, count, apply_sigmoid);
     PSALM_LAUNCH_END("psalm_topk_select");

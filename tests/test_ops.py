@@ -305,6 +305,29 @@ def test_swin_window_merge_ln(ops, B, H, W, C, shift):
     assert (got_h.cpu().float() - want_h).abs().max() <= tol(torch.bfloat16, want_h.abs().max())
 
 
+@pytest.mark.parametrize("Q,C,k,thing,sig", [(100, 133, 100, True, False), (100, 1, 100, False, True), (12, 9, 12, True, False), (7, 3, 30, False, False)])
+def test_topk_select(ops, Q, C, k, thing, sig):
+    """radix-select top-k (value descending, ties by lowest flat index) + thing filter + mask-score product, LP:407-447 / 308-324."""
+    g = torch.Generator().manual_seed(Q * C + k)
+    stride = C + 1
+    vals = torch.rand(Q, stride, generator=g)
+    vals[:, :C] = (vals[:, :C] * 50).round() / 50           # many exact ties
+    if sig:
+        vals = vals * 8 - 4
+    is_thing = (torch.rand(C, generator=g) < 0.6).to(torch.int32) if thing else None
+    ms = torch.rand(Q, generator=g)
+    d = ops.device
+    sc, cl, qq, cnt = ops.topk_select(vals.to(d), C, k, is_thing.to(d) if thing else None, ms.to(d), apply_sigmoid=sig)
+    n = int(cnt.item())
+    flat = (vals[:, :C].sigmoid() if sig else vals[:, :C]).reshape(-1)
+    order = sorted(range(flat.numel()), key=lambda i: (-flat[i].item(), i))[:min(k, flat.numel())]
+    want = [(flat[i].item() * ms[i // C].item(), i % C, i // C) for i in order if (not thing or is_thing[i % C])]
+    assert n == len(want)
+    got = list(zip(sc.cpu()[:n].tolist(), cl.cpu()[:n].tolist(), qq.cpu()[:n].tolist()))
+    for (gs, gc, gq), (ws_, wc, wq) in zip(got, want):
+        assert (gc, gq) == (wc, wq) and abs(gs - ws_) < 1e-6
+
+
 def test_im2col_and_convs(ops):
     g = torch.Generator().manual_seed(9)
     img = torch.randn(2, 3, 18, 13, generator=g)
