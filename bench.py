@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
@@ -46,6 +46,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # N ranks build their (seeded) weights concurrently on the host
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from psalm_amd.config import PsalmConfig
@@ -112,7 +113,11 @@ def main():
             if geo is not None:
                 M, N, K, a_bf16, c_bf16, tag = geo
                 path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True)
-                if path == 1:
+                if path == 2 and name == "psalm_gemm":
+                    kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}>"
+                elif path == 1 or path == 2:
+                    if path == 2:                             # psalm_gemm_ln has no skinny variant: it takes the tiled path
+                        BM, BN, splits = (64, 128, 1)
                     kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}{tag}>"
                     if splits > 1:
                         kname += " + splitk_reduce_ln_kernel" if name == "psalm_gemm_ln" else " + splitk_reduce_kernel"
@@ -197,6 +202,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                           # rank 0's instrumented steps / JSON line are done before anyone leaves
         dist.destroy_process_group()
 
 

@@ -253,6 +253,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
     else PSALM_WAIT_VMCNT(24);
 }
 
+// BK = 128: 256-byte LDS rows, 4 rows per 1 KiB copy, slot p of row r holds k-chunk p ^ (r & 15)  (half the K steps -- and
+//           barriers / exposed copy latencies -- of BK = 64; 128 KB LDS, 1 block/CU: for grids that cannot fill 2 blocks/CU anyway);
 // BK = 64: 128-byte LDS rows, 8 rows per 1 KiB copy, slot p of row r holds k-chunk p ^ ((r >> 1) & 7);
 // BK = 32:  64-byte LDS rows, 16 rows per copy,       slot p of row r holds k-chunk p ^ ((r >> 2) & 3)   (same rule: the
 //           16 rows of a ds_read_b128 lane group must land on 16 distinct 16-byte slots of the 256-byte bank row).
@@ -267,8 +269,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPC = 512 / BK;                                // rows per 1 KiB copy (8 | 16)
     constexpr int SLOTS = BK / 8;                                // 16-byte slots per row (8 | 4)
-    constexpr int SWS = BK == 64 ? 1 : 2;                        // swizzle: slot ^= (row >> SWS) & (SLOTS - 1)
-    static_assert(BK == 64 || BK == 32, "BK");
+    constexpr int SWS = BK == 128 ? 0 : (BK == 64 ? 1 : 2);      // swizzle: slot ^= (row >> SWS) & (SLOTS - 1)
+    static_assert(BK == 128 || BK == 64 || BK == 32, "BK");
     static_assert(!CONV || BK == 64, "implicit-GEMM convolution uses 64-deep K tiles");
     static_assert(!FP8 || (BK == 64 && !CONV), "fp8 variant: 128-byte rows, plain GEMM");
     constexpr int A_CH = BM / RPC / NW, B_CH = BN / RPC / NW;    // 1 KiB copies per wave per tile
@@ -507,6 +509,49 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     }
 }
 
+// ------------------------------------------------------------------------------------------- skinny GEMM (M <= 128)
+// The Mask2Former predictor issues ~100 dependent GEMMs with M = 100 queries (N, K in {256, 512, 2048}): a few MFLOP each,
+// pure latency.  The tiled kernel above costs ~10 us per launch there (LDS staging + one barrier per K step + the LDS epilogue
+// for 4 blocks of work); this one has NO staging and NO K-loop barrier: a block owns one 32x32 output tile, its 4 wavefronts
+// split K four ways, every lane pulls its MFMA fragments straight from global / L2 with 16-byte loads (all loads of a chunk in
+// flight together), the 4 partial tiles meet once in LDS, and the epilogue is applied from registers.
+template <typename TC>
+__global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g) {
+    __shared__ float part[3][32 * 32];                           // partial tiles of waves 1..3
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
+    const bf16_t* A = (const bf16_t*)g.A + (long)min(bm + n32, g.M - 1) * g.lda + 8 * hi;
+    const bf16_t* W = (const bf16_t*)g.W + (long)min(bn + n32, g.N - 1) * g.ldw + 8 * hi;
+    const int ksteps = g.K / 16;                                 // K % 64 == 0 -> divisible by 4
+    const int per = ksteps / 4, k0 = wave * per;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = 0; kb < per; kb += 8) {                        // chunks of 8 k-steps: 16 independent 16-byte loads per lane
+        u32x4_s fa_[8], fb_[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (kb + i < per) {
+                fa_[i] = *reinterpret_cast<const u32x4_s*>(A + (long)(k0 + kb + i) * 16);
+                fb_[i] = *reinterpret_cast<const u32x4_s*>(W + (long)(k0 + kb + i) * 16);
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (kb + i < per)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]), __builtin_bit_cast(bf16x8, fb_[i]), acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += part[0][r * 64 + lane] + part[1][r * 64 + lane] + part[2][r * 64 + lane];
+        epilogue_store<TC>(g, acc, bm, bn + n32, lane);
+    }
+}
+
 // C = epilogue(sum_z slab[z]); one thread per 4 consecutive columns.
 template <typename TC>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const float* __restrict__ slab, int splits) {
@@ -701,11 +746,14 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
 // (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
 static int g_tile_policy = 0;
+static long g_skinny_nmax = 4096;    // skinny kernel for M <= 128 and N <= this
 static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)
     if (bm == 1323 || bm == 1324) { g_ring_depth = bm - 1000; return 0; }      // 128x128, BK 32, ring depth 3 / 4 (tuning)
-    if (bm != 0 && bm != 256 && bm != 128 && bm != 64) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
+    if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
+    if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
+    if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
     return 0;
 }
@@ -723,7 +771,8 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     else if (M > 192 && t128 >= 100 && t128 < 200 && K <= 2048) { BM = 64; BN = 128; no_split = true; }   // r1l: Swin fc2 24 vs 35 us (split-K)
     else if (M > 192) { BM = 128; BN = 128; }
     else { BM = 64; BN = 128; }
-    if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; no_split = false; }
+    if (g_tile_policy == 12864) { if (M > 192) { BM = 128; BN = 64; } }       // experiment: 48 KB LDS -> 3 blocks/CU
+    else if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; no_split = false; }
     const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
     const long fill = BM == 256 ? 256 : 448;                                // blocks that fill the chip (1 vs ~2 per CU)
     splits = 1;
@@ -741,10 +790,12 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     }
 }
 
-// Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS), out[1] = BM,
+// Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS, 2 skinny), out[1] = BM,
 // out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
 extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
-    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
+    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+        out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;                     // skinny kernel
+    } else if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         int BM, BN, splits;
         select_fast_config(M, N, K, workspace_bytes > 0, workspace_bytes, BM, BN, splits);
         out4[0] = 1; out4[1] = BM; out4[2] = BN; out4[3] = splits;
@@ -783,6 +834,11 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
+#define LAUNCH_GLDS128(BM_, BN_, WM_, WN_)                                                                                   \
+    do {                                                                                                                     \
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 128>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 128>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    } while (0)
 #define LAUNCH_GLDS32(BM_, BN_, WM_, WN_, NS_)                                                                               \
     do {                                                                                                                     \
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
@@ -803,8 +859,10 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
     } else {
         if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
+        else if (BM == 128 && BN == 64) LAUNCH_GLDS(128, 64, 2, 2, 2, false);
         else if (BM == 128) {
             if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false);
+            else if (g_ring_depth == 128 && K % 128 == 0 && fa.k_per_split % 128 == 0) LAUNCH_GLDS128(128, 128, 2, 2);
             else if (g_ring_depth == 324) LAUNCH_GLDS32(128, 128, 2, 2, 4);
             else if (g_ring_depth == 323) LAUNCH_GLDS32(128, 128, 2, 2, 3);
             else LAUNCH_GLDS(128, 128, 2, 2, 2, false);
@@ -813,6 +871,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     }
 #undef LAUNCH_GLDS
 #undef LAUNCH_GLDS32
+#undef LAUNCH_GLDS128
 #undef LAUNCH_GLDS8
     if (splits > 1) {
         if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
@@ -884,6 +943,13 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     g.tiles_n = cdiv(N, 128);
     hipStream_t s = (hipStream_t)stream;
 
+    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+        // ---- skinny path: latency-bound GEMMs of the predictor (measured r1x: ~3 us vs ~10 us per launch)
+        const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g);
+        PSALM_LAUNCH_END("psalm_gemm");
+    }
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         // ---- direct-to-LDS fast path
         GemmFastArgs fa;

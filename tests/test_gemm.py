@@ -92,7 +92,7 @@ def test_gemm_fast_path_strided_views(ops):
     assert big_c[:, :16].abs().max() == 0 and big_c[:, 88:].abs().max() == 0
 
 
-@pytest.mark.parametrize("policy", [256, 128, 64])
+@pytest.mark.parametrize("policy", [256, 128, 64, 12864])
 @pytest.mark.parametrize("M,N,K,cd,split", [(300, 260, 128, "bf16", False), (270, 300, 1088, "f32", True)])
 def test_gemm_forced_tiles(ops, policy, M, N, K, cd, split):
     """Every tile configuration of the direct-to-LDS kernel (256x256 / 8 waves with its two-pass LDS epilogue, 128x128, 64x128)
@@ -114,11 +114,12 @@ def test_gemm_forced_tiles(ops, policy, M, N, K, cd, split):
     assert (got - want).abs().max().item() <= tol
 
 
-@pytest.mark.parametrize("policy", [1323, 1324])
+@pytest.mark.parametrize("policy", [1323, 1324, 128128])
 def test_gemm_bk32_ring(ops, policy):
-    """128x128 configuration with 32-deep K tiles (64-byte LDS rows, 4-slot swizzle) and a 3 / 4-deep operand ring."""
+    """128x128 configuration with 32-deep K tiles (64-byte LDS rows, 4-slot swizzle) and a 3 / 4-deep operand ring; and with
+    128-deep K tiles (256-byte rows, 16-slot swizzle)."""
     g = torch.Generator().manual_seed(policy)
-    M, N, K = 260, 200, 448
+    M, N, K = 260, 200, 512 if policy == 128128 else 448
     a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
     bias = torch.randn(N, generator=g)

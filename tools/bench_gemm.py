@@ -41,9 +41,15 @@ def main():
         policies = [1282, 1324, 1323]
     if "--p64" in sys.argv:
         policies = [0, 64]
+    if "--p12864" in sys.argv:
+        policies = [0, 12864]
+    if "--bk128" in sys.argv:
+        policies = [1282, 128128]
+    if "--skinny" in sys.argv:
+        policies = [7778, 7777]
     for pol in policies:
       ops.gemm_tile_policy(pol)
-      if pol > 1000:
+      if 1000 < pol < 7000 or pol == 128128:
           ops.gemm_tile_policy(128)
       print(f"---- tile policy {pol}")
       for name, M, N, K, cdt in SHAPES:
