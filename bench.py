@@ -97,9 +97,19 @@ def main():
             model.eval_seg(**inputs)
         torch.cuda.synchronize()
         model.ops.lib.records = None
+        # an event pair around NOTHING still measures ~5 us of stream overhead: measured here and used ONLY to rank the kernel
+        # instantiations (reported times stay raw: for the long dominant kernel they agree with the rocprofv3 kernel trace)
+        cal = []
+        for _ in range(200):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            c1.record()
+            cal.append((c0, c1))
+        torch.cuda.synchronize()
+        ev_over = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2]
         agg, shapes, kern = {}, {}, {}
         for name, a, e0, e1 in recs:
-            ms = e0.elapsed_time(e1)
+            ms = e0.elapsed_time(e1)              # raw event time: agrees with the rocprofv3 kernel-trace durations for long kernels
             d = agg.setdefault(name, [0, 0.0])
             d[0] += 1
             d[1] += ms
@@ -141,7 +151,8 @@ def main():
         if kern:
             # dominant kernel = the single-kernel (un-split) GEMM instantiation with the largest share of the step
             cands = {k: v for k, v in kern.items() if " + " not in k} or kern
-            kname, (n, ms, fl) = max(cands.items(), key=lambda kv: kv[1][1])
+            # ranking only: take the per-launch event overhead out, otherwise the instantiation with the most launches wins
+            kname, (n, ms, fl) = max(cands.items(), key=lambda kv: kv[1][1] - kv[1][0] * ev_over)
             ach = fl / (ms * 1e-3) / 1e12
             all_ms = sum(v[1] for v in kern.values())
             all_fl = sum(v[2] for v in kern.values())
@@ -156,7 +167,7 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-                    "share_of_step_ms": round(ms / nprof, 3),
+                    "share_of_step_ms": round(ms / nprof, 3), "event_pair_overhead_us": round(ev_over * 1e3, 2),
                     "all_bf16_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
                                        "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof}}
         if args.breakdown:

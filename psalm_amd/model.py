@@ -751,17 +751,18 @@ class PSALM:
             stages.update(inputs_embeds=embeds.view(B, L, -1), hidden_states=hidden.view(B, L, -1), lengths=meta["lens"])
         # ---- LLM states -> decoder embeddings (LP:1366-1390)
         Q = cfg.md_queries
-        seg_q = o.gemm(o.segment_mean(hidden, dv["seg_off"], dv["seg_rows"]), w["seg_query_projector.w"],
+        # (row-set means come out in the GEMM operand dtype: bf16 -> the skinny MFMA kernel instead of the converting path)
+        seg_q = o.gemm(o.segment_mean(hidden, dv["seg_off"], dv["seg_rows"], out_dtype=self.adt), w["seg_query_projector.w"],
                        w["seg_query_projector.b"], out_dtype=torch.float32)
         cls_emb = seg_emb = reg_emb = None
         if "cls_off" in dv:
-            cls_emb = o.gemm(o.segment_mean(hidden, dv["cls_off"], dv["cls_rows"]), w["class_name_projector.w"],
+            cls_emb = o.gemm(o.segment_mean(hidden, dv["cls_off"], dv["cls_rows"], out_dtype=self.adt), w["class_name_projector.w"],
                              w["class_name_projector.b"], out_dtype=self.wdt)
         if "refer_off" in dv:
-            seg_emb = o.gemm(o.segment_mean(hidden, dv["refer_off"], dv["refer_rows"]), w["SEG_token_projector.w"],
+            seg_emb = o.gemm(o.segment_mean(hidden, dv["refer_off"], dv["refer_rows"], out_dtype=self.adt), w["SEG_token_projector.w"],
                              w["SEG_token_projector.b"], out_dtype=self.wdt)
         if "region_off" in dv:
-            reg_emb = o.gemm(o.segment_mean(hidden, dv["region_off"], dv["region_rows"]), w["region_projector.w"],
+            reg_emb = o.gemm(o.segment_mean(hidden, dv["region_off"], dv["region_rows"], out_dtype=self.adt), w["region_projector.w"],
                              w["region_projector.b"], out_dtype=self.adt)
         if stages is not None:
             stages.update(seg_query=seg_q.view(B, Q, -1), class_name_embedding=cls_emb, SEG_embedding=seg_emb,
