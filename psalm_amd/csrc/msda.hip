@@ -64,6 +64,85 @@ __device__ __forceinline__ void msda_sample(const TV* __restrict__ vbase, int Hl
     }
 }
 
+// 8 channels per lane (16-byte bf16 / 2 x 16-byte fp32 corner reads): half the load instructions and half the redundant
+// per-(query, head) softmax / location arithmetic of the 4-channel mapping.  Used by the fused kernel when D % 8 == 0.
+template <typename TV>
+__device__ __forceinline__ void msda_sample8(const TV* __restrict__ vbase, int Hl, int Wl, int row_stride, float loc_x,
+                                             float loc_y, float wgt, float* acc) {
+    const float h_im = loc_y * Hl - 0.5f;
+    const float w_im = loc_x * Wl - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - h_low, lw = w_im - w_low;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
+        const TV* p00 = vbase + ((long)h_low * Wl + w_low) * row_stride;
+        float v1[8], v2[8], v3[8], v4[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v1[k] = 0.f; v2[k] = 0.f; v3[k] = 0.f; v4[k] = 0.f; }
+        if (h0 && w0) ld8(p00, v1);
+        if (h0 && w1) ld8(p00 + row_stride, v2);
+        if (h1 && w0) ld8(p00 + (long)Wl * row_stride, v3);
+        if (h1 && w1) ld8(p00 + (long)(Wl + 1) * row_stride, v4);
+        const float w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += wgt * (w1c * v1[k] + w2c * v2[k] + w3c * v3[k] + w4c * v4[k]);
+    }
+}
+
+template <typename TV, typename TO, int L, int P>
+__global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__ value, MsdaLevels lv,
+                                                          const float* __restrict__ ow, TO* __restrict__ out, int B, int S,
+                                                          int M, int D) {
+    const int G = D >> 3;
+    const int Lq = S;
+    const long total = (long)B * Lq * M * G;
+    constexpr int LP = L * P;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        long t = idx / G;
+        const int m = (int)(t % M);
+        t /= M;
+        const int q = (int)(t % Lq);
+        const int b = (int)(t / Lq);
+        int lq = 0;
+#pragma unroll
+        for (int l = 1; l < L; ++l)
+            if (q >= lv.start[l]) lq = l;
+        const int qi = q - lv.start[lq];
+        const float ref_x = ((qi % lv.W[lq]) + 0.5f) / lv.W[lq];
+        const float ref_y = ((qi / lv.W[lq]) + 0.5f) / lv.H[lq];
+        const float* row = ow + ((long)b * Lq + q) * (M * LP * 3);
+        const float* offp = row + m * LP * 2;
+        const float* lgp = row + M * LP * 2 + m * LP;
+        float lg[LP];
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) { lg[i] = lgp[i]; mx = fmaxf(mx, lg[i]); }
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
+        const float inv = 1.f / den;
+        const int row_stride = M * D;
+        const TV* vb = value + (long)b * S * row_stride + m * D + g * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const TV* vl = vb + (long)lv.start[l] * row_stride;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int i = l * P + p;
+                const float lx = ref_x + offp[2 * i] / lv.W[l];
+                const float ly = ref_y + offp[2 * i + 1] / lv.H[l];
+                msda_sample8<TV>(vl, lv.H[l], lv.W[l], row_stride, lx, ly, lg[i] * inv, acc);
+            }
+        }
+        st8(out + (((long)b * Lq + q) * M + m) * D + g * 8, acc);
+    }
+}
+
 // Plugin form: explicit sampling locations / attention weights (the reference op's contract).
 template <typename TV, typename TO, int LP_UNROLL>
 __global__ void __launch_bounds__(256) msda_forward_kernel(const TV* __restrict__ value, MsdaLevels lv,
@@ -189,9 +268,18 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
     MsdaLevels lv;
     int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
     PSALM_CHECK_ARG(rc == 0, "psalm_msda_fused: bad level table");
+    const int block = 256;
+    if (D % 8 == 0 && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0) {       // 8 channels per lane
+        const long total8 = (long)B * S * M * (D / 8);
+        if (total8 == 0) return 0;
+        PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
+            hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4>), dim3((unsigned)((total8 + block - 1) / block)), dim3(block), 0,
+                               (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);
+        }));
+        PSALM_LAUNCH_END("psalm_msda_fused");
+    }
     const long total = (long)B * S * M * (D / 4);
     if (total == 0) return 0;
-    const int block = 256;
     const int grid = (int)((total + block - 1) / block);
     PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
         hipLaunchKernelGGL((msda_fused_kernel<TV, TO, 3, 4>), dim3(grid), dim3(block), 0, (hipStream_t)stream,

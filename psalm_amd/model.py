@@ -152,7 +152,8 @@ class PSALM:
         vt = "model.vision_tower."
         E, ps = cfg.swin_embed_dim, cfg.swin_patch
         pe = sd[vt + "patch_embed.proj.weight"].reshape(E, -1)                 # (E, 3*ps*ps), K order (c,ky,kx)
-        self.pe_kpad = (pe.shape[1] + 7) // 8 * 8
+        # K of the patch-embed GEMM: padded to 64 in the bf16 modes (direct-to-LDS kernel), to 8 in the exact mode
+        self.pe_kpad = (pe.shape[1] + 63) // 64 * 64 if self.wdt == torch.bfloat16 else (pe.shape[1] + 7) // 8 * 8
         w["swin.pe.w"] = W(torch.nn.functional.pad(pe, (0, self.pe_kpad - pe.shape[1])))
         w["swin.pe.b"] = Fp(sd[vt + "patch_embed.proj.bias"])
         norm("swin.pe.ln", vt + "patch_embed.norm")
@@ -294,7 +295,7 @@ class PSALM:
         o, w, cfg = self.ops, self.w, self.cfg
         B, _, Hi, Wi = images.shape
         ps, ws = cfg.swin_patch, cfg.swin_window
-        cols = o.patch_im2col(images, ps, self.pe_kpad, out_dtype=torch.float32)
+        cols = o.patch_im2col(images, ps, self.pe_kpad, out_dtype=self.adt)
         Hc, Wc = (Hi + ps - 1) // ps, (Wi + ps - 1) // ps
         x = o.gemm(cols, w["swin.pe.w"], w["swin.pe.b"], out_dtype=torch.float32)
         x = o.layernorm(x, w["swin.pe.ln.g"], w["swin.pe.ln.b"])
@@ -503,7 +504,13 @@ class PSALM:
             self._cache[key] = torch.cat([self._pos_embed(h, w_) + w["pd.level_embed"][l][None] for l, (h, w_) in enumerate(shapes)], 0).contiguous()
         lvl_pos = self._cache[key]
         dual = self.adt == torch.bfloat16        # keep a bf16 copy of the fp32 token stream as the GEMM A operand
-        src_a = src                              # (first layer: fp32 A through the converting GEMM path)
+        if dual:                                 # bf16 copy of the GroupNorm output for the first layer's value projection
+            key = ("zrow", D)
+            if key not in self._cache:
+                self._cache[key] = o.zeros(1, D, dtype=torch.float32)
+            src_a = o.add_bcast(src, self._cache[key], out_dtype=self.adt)
+        else:
+            src_a = src
         qin = o.add_bcast(src, lvl_pos, out_dtype=self.adt)
         for i in range(cfg.md_enc_layers):
             q_ = f"pd.enc{i}."
