@@ -91,6 +91,7 @@ class PSALM:
         self._cache: Dict = {}
         self._graphs: Dict = {}
         self._plan_cache: Dict = {}
+        self.max_graphs = 8                           # captured input signatures kept alive (oldest dropped first)
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
         self.overlap_streams = False                  # opt-in: pixel decoder on a second HIP stream, concurrent with the LLM
         #                                               (measured r1k: no gain -- the LLM GEMMs already fill the chip)
@@ -926,6 +927,8 @@ class PSALM:
         ent = self._graphs.get(key)
         host = torch.from_numpy(blob)
         if ent is None:                                    # first sighting: eager run (fills caches / workspaces, warms the allocator)
+            while len(self._graphs) >= self.max_graphs:    # every captured graph owns its intermediates (GBs at 1024^2): bound them
+                self._graphs.pop(next(iter(self._graphs)))  # (insertion order = oldest signature first)
             self._graphs[key] = {"seen": 1}
             dv = self._views(host.to(self.device), layout)
             return self._forward_device(images, dv, meta, vp_images=vp_images)
@@ -936,8 +939,12 @@ class PSALM:
             dv = self._views(ent["blob"], layout)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ent["outs"] = self._forward_device(ent["images"], dv, meta, vp_images=ent["vp"])
+            try:
+                with torch.cuda.graph(g):
+                    ent["outs"] = self._forward_device(ent["images"], dv, meta, vp_images=ent["vp"])
+            except Exception:
+                self._graphs.pop(key, None)                # a failed capture must not leave a half-built entry behind
+                raise
             ent["graph"] = g
         ent["images"].copy_(images)
         if vp_images is not None:
