@@ -206,6 +206,11 @@ int psalm_class_softmax(const float* cls, float* probs, void* probsT, int probsT
                         int Kpad, void* stream);
 /* sigmoid(mask)^T padded to Kpad: second operand of class_name_semantic_inference (llava_phi.py:402-406). */
 int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, long HW, int Kpad, void* stream);
+/* class_name_semantic_inference (llava_phi.py:402-406) fused for the bf16 mode: sem[c,p] = sum_q probsT[c,q] * sigmoid(mask[q,p]) in
+ * one pass over the mask logits (no sigmoid^T tensor in HBM).  probsT (C,128) bf16 from psalm_class_softmax; Q <= 128, C <= 160.
+ * mask_score (Q) f32 or NULL: psalm_mask_scores' result from the same read (workspace Q*512*2 floats, else NULL). */
+int psalm_semantic_from_masks(const float* mask, const void* probsT_bf16, float* out, float* mask_score, float* workspace, int Q, int C,
+                              long HW, int Kpad, void* stream);
 /* mask score = sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6) (llava_phi.py:318-320,439-441). workspace Q*64*2 floats. */
 int psalm_mask_scores(const float* mask, float* score, float* workspace, int Q, long HW, void* stream);
 /* topk over Q*C candidates + thing filter + score product (llava_phi.py:407-447, 308-324). */

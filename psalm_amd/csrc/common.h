@@ -112,7 +112,10 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #ifdef PSALM_EMU_BUILD
 #define PSALM_WAIT_VMCNT(N) do { } while (0)          /* the stand-in's copies are synchronous */
 #define PSALM_RAW_BARRIER() __syncthreads()
+#define PSALM_OPAQUE_VGPR(x) do { } while (0)
 #else
+// makes an int look freshly defined to the optimiser (keeps loop-invariant LDS fragment reads from being hoisted into registers)
+#define PSALM_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #define PSALM_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif

@@ -121,6 +121,138 @@ extern "C" int psalm_mask_scores(const float* mask, float* score, float* workspa
     PSALM_LAUNCH_END("psalm_mask_scores");
 }
 
+// ---------------------------------------------------------------- fused semantic inference (bf16 mode)
+// sem[c, p] = sum_q probs[q, c] * sigmoid(mask[q, p])   (class_name_semantic_inference, LP:402-406) in ONE pass over the
+// (Q, HW) fp32 mask logits: a persistent block walks 128-pixel tiles; per tile the logits are read coalesced, squashed, rounded
+// to bf16 and laid down pixel-major in LDS (= the MFMA B operand, k = q contiguous); probsT (C, Kpad) sits in LDS for the whole
+// kernel (A operand); each wave owns 32 pixels x all classes (5 x 32-row MFMA tiles, K = Kpad = 128) and writes whole 128-byte
+// row segments of the (C, HW) fp32 result.  HBM traffic = the compulsory read of the masks + write of the result; replaces the
+// sigmoid-transpose pass (419 MB read + 268 MB write) + the K=128 GEMM over 24576 tiny tiles.
+typedef float pp_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 pp_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NI>                                           // queries per wave: q = wave + 4 i, i < NI (NI = ceil(Q / 4) rounded to 25 / 32)
+__global__ void __launch_bounds__(256, 2) semantic_from_masks_kernel(const float* __restrict__ mask, const bf16_t* __restrict__ probsT,
+                                                                     float* __restrict__ out, float* __restrict__ partial, int Q, int C,
+                                                                     long HW, int ntiles) {
+    constexpr int KP = 128, PITCH = KP + 4;                  // 264-byte rows: conflict-light 2-byte scatter writes, 8-byte aligned reads
+    constexpr int CT = 5;                                    // class tiles of 32 (C <= 160)
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[CT * 32 * PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t Ss[128 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row bases of the logit loads stay in SGPRs
+    for (int e = tid; e < CT * 32 * (KP / 8); e += 256) {    // probsT -> LDS, zero rows beyond C
+        const int c = e / (KP / 8), k8 = (e % (KP / 8)) * 8;
+        psalm_u32x4 v{0, 0, 0, 0};
+        if (c < C) v = *reinterpret_cast<const psalm_u32x4*>(probsT + (long)c * KP + k8);
+        *reinterpret_cast<unsigned long long*>(&Ps[c * PITCH + k8]) = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+        *reinterpret_cast<unsigned long long*>(&Ps[c * PITCH + k8 + 4]) = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    }
+    for (int e = tid; e < 128 * (KP - 4 * NI); e += 256) {   // q columns the staging loop never writes: zero once
+        const int p = e / (KP - 4 * NI), q = 4 * NI + e % (KP - 4 * NI);
+        Ss[p * PITCH + q] = f32_to_bf16(0.f);
+    }
+    float num[NI], den[NI];                                  // per-lane mask-score sums of this wave's queries
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long p0 = (long)t * 128;
+        __syncthreads();                                     // previous tile's MFMA reads are done (and the fills above are visible)
+        // branch-free staging: rows beyond Q re-read row Q-1 (their probsT columns are zero, so the finite values they leave in LDS
+        // vanish in the product; their score sums are never stored); pixels beyond HW re-read pixel HW-1 and are masked to 0
+        const long pa = min(p0 + lane, HW - 1), pb = min(p0 + 64 + lane, HW - 1);
+        const bool va = p0 + lane < HW, vb = p0 + 64 + lane < HW;
+        constexpr int G = NI % 5 == 0 ? NI : 8;              // queries whose logits are fetched together (2 G loads in flight per lane)
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += G) {
+            float ma[G], mb[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {                    // unconditional (clamped) loads, masked afterwards: no branches
+                const float* row = mask + (long)min(wave + 4 * (i0 + g), Q - 1) * HW;
+                ma[g] = row[pa];
+                mb[g] = row[pb];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i = i0 + g, q = wave + 4 * i;
+                const float xa = va ? ma[g] : 0.f, xb = vb ? mb[g] : 0.f;
+                const float sa = sigmoidf_(xa), sb = sigmoidf_(xb);
+                Ss[lane * PITCH + q] = f32_to_bf16(sa);
+                Ss[(64 + lane) * PITCH + q] = f32_to_bf16(sb);
+                num[i] += (xa > 0.f ? sa : 0.f) + (xb > 0.f ? sb : 0.f);
+                den[i] += (xa > 0.f ? 1.f : 0.f) + (xb > 0.f ? 1.f : 0.f);
+            }
+        }
+        __syncthreads();
+        pp_f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        int arow = n * PITCH;                                // probsT fragments are re-read from LDS per tile (160 VGPRs if kept)
+        PSALM_OPAQUE_VGPR(arow);
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            const int ko = 16 * kk + 8 * hi;
+            const unsigned long long* bp = reinterpret_cast<const unsigned long long*>(&Ss[(32 * wave + n) * PITCH + ko]);
+            const unsigned long long b0 = bp[0], b1 = bp[1];
+            const pp_bf16x8 bfrag = __builtin_bit_cast(pp_bf16x8, psalm_u32x4{(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)});
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const unsigned long long* ap = reinterpret_cast<const unsigned long long*>(&Ps[32 * ct * PITCH + arow + ko]);
+                const unsigned long long a0 = ap[0], a1 = ap[1];
+                const pp_bf16x8 afrag = __builtin_bit_cast(pp_bf16x8, psalm_u32x4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)});
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[ct], 0, 0, 0);
+            }
+        }
+        // stores as (scalar row base) + (32-bit lane offset): lane offset = pixel + 4*hi rows, row base = out + cb * HW + p0
+        const bool pv = p0 + 32 * wave + n < HW;
+        const unsigned voff = (unsigned)(32 * wave + n) + (unsigned)(4 * hi) * (unsigned)HW;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cb = 32 * ct + (r & 3) + 8 * (r >> 2);
+                float* rowp = out + (long)cb * HW + p0;
+                if (pv && cb + 4 * hi < C) rowp[voff] = acc[ct][r];
+            }
+    }
+    if (partial) {                                           // (q, block, 2) partial sums -> mask_score_final_kernel (fixed order)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = wave + 4 * i;
+            const float a = wave_sum(num[i]), b = wave_sum(den[i]);
+            if (lane == 0 && q < Q) {
+                partial[((long)q * gridDim.x + blockIdx.x) * 2 + 0] = a;
+                partial[((long)q * gridDim.x + blockIdx.x) * 2 + 1] = b;
+            }
+        }
+    }
+}
+
+// mask (Q, HW) f32 logits; probsT (C, 128) bf16 = softmax probabilities transposed and zero-padded (psalm_class_softmax);
+// out (C, HW) f32.  Q <= 128, C <= 160.  mask_score (Q) f32 or NULL: the per-query mask score of psalm_mask_scores, accumulated from
+// the same read of the logits (workspace: Q * 512 * 2 floats).
+extern "C" int psalm_semantic_from_masks(const float* mask, const void* probsT_bf16, float* out, float* mask_score, float* workspace,
+                                         int Q, int C, long HW, int Kpad, void* stream) {
+    PSALM_CHECK_ARG(Kpad == 128 && Q >= 1 && Q <= 128 && C >= 1 && C <= 160, "psalm_semantic_from_masks: Kpad 128, Q <= 128, C <= 160");
+    PSALM_CHECK_ARG((uintptr_t)probsT_bf16 % 16 == 0, "psalm_semantic_from_masks: probsT must be 16-byte aligned");
+    PSALM_CHECK_ARG(mask_score == nullptr || workspace != nullptr, "psalm_semantic_from_masks: mask_score needs the workspace");
+    PSALM_CHECK_ARG(HW <= (1L << 27), "psalm_semantic_from_masks: HW <= 2^27 (32-bit lane offsets)");
+    if (HW == 0) return 0;
+    const int ntiles = (int)((HW + 127) / 128);
+    const int grid = ntiles < 512 ? ntiles : 512;            // 2 persistent blocks per CU (LDS 76 KB each)
+    if (Q <= 100)
+        hipLaunchKernelGGL(semantic_from_masks_kernel<25>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, (const bf16_t*)probsT_bf16,
+                           out, mask_score ? workspace : nullptr, Q, C, HW, ntiles);
+    else
+        hipLaunchKernelGGL(semantic_from_masks_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, (const bf16_t*)probsT_bf16,
+                           out, mask_score ? workspace : nullptr, Q, C, HW, ntiles);
+    if (mask_score)
+        hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
+    PSALM_LAUNCH_END("psalm_semantic_from_masks");
+}
+
 // ---------------------------------------------------------------- top-k + instance selection (single block)
 // vals (n) = row-major (Q, stride) matrix restricted to the first C columns; picks the k largest (ties: lowest flat
 // index), in descending order.  Then the reference's filtering (LP:417-446):

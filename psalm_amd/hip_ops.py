@@ -482,6 +482,21 @@ class Ops:
         self._check(rc, "psalm_sigmoid_transpose")
         return out
 
+    def semantic_from_masks(self, mask, probsT, want_mask_score=False):
+        """mask (Q,HW) f32 logits, probsT (C,128) bf16 -> (C,HW) f32 = probsT @ sigmoid(mask), one pass over the logits; with
+        want_mask_score also returns mask_scores(mask) accumulated from the same read."""
+        Q, HW = mask.shape
+        C, Kpad = probsT.shape
+        if probsT.dtype != torch.bfloat16 or mask.dtype != torch.float32:
+            raise PsalmHipError("semantic_from_masks: f32 logits, bf16 probsT")
+        out = self.empty(C, HW, dtype=torch.float32)
+        ms = self.empty(Q) if want_mask_score else None
+        ws = self.empty(Q * 512 * 2) if want_mask_score else None
+        rc = self.lib.psalm_semantic_from_masks(self._p(mask), self._p(probsT), self._p(out), self._p(ms) if want_mask_score else None,
+                                                self._p(ws) if want_mask_score else None, Q, C, c_long(HW), Kpad, self._stream())
+        self._check(rc, "psalm_semantic_from_masks")
+        return (out, ms) if want_mask_score else out
+
     def mask_scores(self, mask):
         """mask (Q,HW) f32 -> (Q) f32: sum(sigmoid*[m>0]) / (sum([m>0]) + 1e-6)."""
         Q, HW = mask.shape

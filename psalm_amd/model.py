@@ -815,6 +815,16 @@ class PSALM:
         return self._forward_device(images, dv, meta, stages=stages, postprocess=False, vp_images=vp_images)
 
     # ======================================================================================= post-processing + eval_seg
+    def _semantic(self, mflat, probsT, Kpad, want_mask_score=False):
+        """class_name_semantic_inference (LP:402-406): (C, HW) = probs^T . sigmoid(masks) [+ the per-query mask scores, LP:443-444].
+        bf16 mode: one fused pass over the mask logits (sigmoid -> LDS -> MFMA, score sums on the side); exact mode (or shapes
+        outside the fused kernel's limits): fp32 sigmoid^T + fp32 GEMM + the separate mask-score reduction."""
+        o = self.ops
+        if probsT.dtype == torch.bfloat16 and Kpad == 128 and probsT.shape[0] <= 160:
+            return o.semantic_from_masks(mflat, probsT, want_mask_score=want_mask_score)
+        sem = o.gemm(probsT, o.sigmoid_transpose(mflat, Kpad, self.wdt), out_dtype=torch.float32)
+        return (sem, o.mask_scores(mflat)) if want_mask_score else sem
+
     def _postprocess(self, r, sizes):
         """llava_phi.py:1401-1466 for one image, device side.  r: predictor outputs; sizes: (Hpad, Wpad, crop_h, crop_w,
         out_h, out_w) from _prepare."""
@@ -835,7 +845,7 @@ class PSALM:
             C1 = cls.shape[1]
             Kpad = (Q + 63) // 64 * 64
             probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
-            sem = o.gemm(probsT, o.sigmoid_transpose(mflat, Kpad, self.wdt), out_dtype=torch.float32).view(C1 - 1, mh, mw)   # LP:402-406
+            sem = self._semantic(mflat, probsT, Kpad).view(C1 - 1, mh, mw)                                        # LP:402-406
             res["sem_seg"] = o.resize_planes(sem, height, width, crop=(oh, ow)) if resize_after else sem           # LP:1437-1440
             res["_pending"] = ("semantic",)
             res["mask_pred"] = mp
@@ -854,9 +864,8 @@ class PSALM:
             C1 = cls.shape[1]
             Kpad = (Q + 63) // 64 * 64                                   # K of the semantic GEMM (direct-to-LDS path: K % 64 == 0)
             probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
-            sigT = o.sigmoid_transpose(mflat, Kpad, self.wdt)
-            res["sem_seg"] = o.gemm(probsT, sigT, out_dtype=torch.float32).view(C1 - 1, height, width)       # LP:402-406
-            mscore = o.mask_scores(mflat)
+            sem, mscore = self._semantic(mflat, probsT, Kpad, want_mask_score=True)                          # LP:402-406, 443-444
+            res["sem_seg"] = sem.view(C1 - 1, height, width)
             thing = self._thing_dev(C1 - 1)
             sc, cl, qq, cnt = o.topk_select(probs, C1 - 1, Q, thing, mscore)                                 # LP:407-447
             inst_masks = o.binarize_gather(mp, Q, qq, cnt)

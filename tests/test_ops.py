@@ -328,6 +328,33 @@ def test_topk_select(ops, Q, C, k, thing, sig):
         assert (gc, gq) == (wc, wq) and abs(gs - ws_) < 1e-6
 
 
+@pytest.mark.parametrize("Q,C,HW", [(100, 133, 128 * 3 + 40), (12, 9, 300), (128, 160, 256)])
+def test_semantic_from_masks(ops, Q, C, HW):
+    """fused sigmoid + (probs^T . sigmoid(masks)) on the matrix cores vs float64 on the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(Q + C)
+    mask = torch.randn(Q, HW, generator=g) * 4
+    cls = torch.randn(Q, C + 1, generator=g) * 2
+    d = ops.device
+    probs, probsT, score, label = ops.class_softmax(cls.to(d), 128, probsT_dtype=torch.bfloat16)
+    got, ms = ops.semantic_from_masks(mask.to(d), probsT, want_mask_score=True)
+    got = got.cpu().double()
+    assert torch.equal(ops.semantic_from_masks(mask.to(d), probsT).cpu().double(), got)
+    pos = (mask > 0).double()
+    want_ms = (mask.double().sigmoid() * pos).sum(1) / (pos.sum(1) + 1e-6)                      # LP:443-444
+    assert (ms.cpu().double() - want_ms).abs().max() < 1e-5
+    assert (ops.mask_scores(mask.to(d)).cpu() - ms.cpu()).abs().max() < 1e-5
+    want = probsT.cpu().double()[:, :Q] @ mask.sigmoid().bfloat16().double()
+    assert got.shape == (C, HW)
+    err = (got - want).abs()
+    # the device sigmoid (v_exp based) can land on the other side of a bf16 rounding boundary for a handful of (q, p) pairs: each
+    # flip moves one term by one bf16 ulp (<= 2^-8 * prob), so the MEAN error stays at fp32-accumulation level and the MAX is bounded
+    assert err.mean() <= 2e-6 * want.abs().max()
+    assert err.max() <= 2 ** -7 * probsT.float().max().item() + 1e-5
+    # and against the un-rounded reference formula (LP:402-406): bf16 operand rounding only
+    full = torch.einsum("qc,qp->cp", cls.softmax(-1)[:, :-1].double(), mask.sigmoid().double())
+    assert (got - full).abs().max() <= 2 ** -7 * full.abs().max()
+
+
 def test_im2col_and_convs(ops):
     g = torch.Generator().manual_seed(9)
     img = torch.randn(2, 3, 18, 13, generator=g)
