@@ -88,7 +88,9 @@ int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* W
                       const void* zeros, void* workspace, long workspace_bytes, void* stream);
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
-/* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM. */
+/* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;
+ * 2560 | 2568 | 2569 | 2570 = K loop of the 256x256 configuration: plain 2-buffer loop | 4-phase schedule, copy placement 1 | 2 | 3
+ * (3 = default).  Other codes: experiment switches documented at psalm_gemm_set_tile_policy in csrc/gemm.hip. */
 int psalm_gemm_set_tile_policy(int bm);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -262,8 +262,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // 128 fp8 = the same 128-byte LDS rows, copies and swizzle as the bf16 kernel; only the fragment reads (8 bytes per lane:
 // 16-byte slot kk, half hi) and the matrix instruction (v_mfma_f32_32x32x16_fp8_fp8, 8 k-steps per tile) differ, and the
 // epilogue applies the per-row dequantisation scales.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false>
+// PH8 = true (256 x 256, 2 x 4 waves, BK 64, 2 buffers): the K loop below is replaced by the 4-phases-per-K-tile schedule
+// described at "PH8 schedule" further down -- the two wave rows run one barrier interval apart, so that on every SIMD one wave
+// is in a pure-MFMA segment while its partner reads fragments / issues copies, and copies stay in flight across barriers.
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV && !FP8), "PH8 configuration");
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -281,7 +285,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     static_assert(NS >= 2 && NS <= 4, "ring depth");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = PH8 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;   // PH8: scalar (wave-row dependent barriers)
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     const int bm = (g.row_fast ? tile % g.tiles_m : tile / g.tiles_n) * BM;
@@ -311,9 +316,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             asrc[i] = A + (long)m * g.lda + kbeg + kc * 8;
         }
     }
+    // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
+    // columns of n-tile h of all four wave columns (= "B half h": the rows one phase reads), two copies per wave per half.
+    auto b_chunk = [&](int i) -> int {
+        if constexpr (PH8) { const int e = 2 * wave + (i & 1); return 8 * (e >> 2) + 4 * (i >> 1) + (e & 3); }
+        else return wave + NW * i;
+    };
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int r = (wave + NW * i) * RPC + lrow;
+        const int r = b_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
         bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + kbeg + kc * 8;
     }
@@ -335,7 +346,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * RPC * BK);
         }
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + (wave + NW * i) * RPC * BK);
+        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + b_chunk(i) * RPC * BK);
     };
 
     f32x16 acc[TM][TN];
@@ -356,6 +367,120 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     // with the stage read in step kt-1, which is then refilled with tile kt+NS-1.
     constexpr int LPT = A_CH + B_CH;                             // copy instructions per wave per tile
     const int nk = (kend - kbeg) / BK;
+    if constexpr (PH8) {
+        // ---- PH8 schedule (256 x 256 tile, host guarantees nk >= 2).  A K tile is consumed in 4 phases, one 64 x 32 quadrant of
+        // the wave's 128 x 64 output each (8 MFMAs):   P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
+        // where A-half q = m-tiles {2q, 2q+1} of both wave rows (copies q, q+2 of every wave) and B-half j = n-tile j of all four
+        // wave columns (copies 2j, 2j+1).  A phase is   [ds_read the fragments that change; issue ONE half-tile copy (2 per wave);
+        // lgkmcnt(0)]  barrier  [8 MFMAs at raised priority]  barrier.   Wave row 1 runs one barrier interval behind wave row 0
+        // (one extra barrier before its first phase, one after row 0's last), so each SIMD (waves w, w+4) always has one wave in
+        // the MFMA segment and the other in the read/copy segment.
+        // LDS hazards.  WAR: a half is refilled exactly one phase after its last ds_read; those reads retire (lgkmcnt(0)) before
+        // the reading phase's first barrier, for the lagging row too (its first barrier of phase p is the leading row's second).
+        // RAW: the only wait is vmcnt(6) in P4 -- everything but the 3 most recent halves has landed = all of tile t+1 -- placed
+        // before P4's first barrier; the first read of tile t+1 is one phase later, after a barrier every wave's wait precedes.
+        //   tile t:  P1 refills B0 of the OTHER buffer with tile t+1 (last read: P4 of tile t-1);  P2 / P3 / P4 refill A0 / B1 / A1
+        //   of THIS buffer with tile t+2 (last read: P1 / P2 / P3 of tile t).  Copies never drain inside the loop.
+        bf16x8 af[2][BK / 16], bq[BK / 16];
+        auto read_a = [&](const bf16_t* As_, int q) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[(a_row0 + 32 * (2 * q + i)) * BK + co]));
+            }
+        };
+        auto read_b = [&](const bf16_t* Bs_, int j) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+                bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs_[(b_row0 + 32 * j) * BK + co]));
+            }
+        };
+        // half-tile copies: which = 0 / 1 selects one of the wave's two 1 KiB copies, 2 = both
+        auto stage_a = [&](int buf, int koff, int q, int which = 2) {   // A-half q of tile (koff / BK) -> buffer buf
+            bf16_t* As_ = smem[buf];
+            if (which != 1) psalm_glds16(asrc[q] + koff, As_ + (wave + NW * q) * RPC * BK);
+            if (which != 0) psalm_glds16(asrc[q + 2] + koff, As_ + (wave + NW * (q + 2)) * RPC * BK);
+        };
+        auto stage_b = [&](int buf, int koff, int j, int which = 2) {   // B-half j
+            bf16_t* Bs_ = smem[buf] + BM * BK;
+            if (which != 1) psalm_glds16(bsrc[2 * j] + koff, Bs_ + b_chunk(2 * j) * RPC * BK);
+            if (which != 0) psalm_glds16(bsrc[2 * j + 1] + koff, Bs_ + b_chunk(2 * j + 1) * RPC * BK);
+        };
+        // PH8 == 2: the phase's two copies are issued INSIDE the MFMA segment (after the 2nd and the 6th MFMA: the matrix pipe is
+        // busy with the MFMA just issued while the copy is accepted), not in the read segment -- r01 PMC: the copies' issue stalls
+        // (~80 cycles each behind the other waves' copies) made the read segment ~1.8x the MFMA segment it runs beside.
+        auto mma = [&](int q, int j, auto&& copy) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[2 * q + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq[kk], acc[2 * q + i][j], 0, 0, 0);
+                if (PH8 >= 2 && (kk == 0 || kk == 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    copy(kk >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // PH8 == 3: as 2, and the fragment reads are NOT drained before the phase's first barrier (bare s_barrier; the compiler's own
+        // lgkmcnt wait sits in front of the first MFMA): the LDS latency overlaps the wait for the partner row's MFMA segment.  Safe
+        // only with the late copies of variants 2 / 3: a half is then refilled in the MFMA segment of the phase after its last read,
+        // which the lagging row's readers reach the barrier in front of only after their own MFMA segment (= after their reads retired).
+#define PH8_BAR() do { if constexpr (PH8 == 3) __builtin_amdgcn_s_barrier(); else PSALM_RAW_BARRIER(); } while (0)
+#define PH8_ENTER_MFMA() do { __builtin_amdgcn_sched_barrier(0); PH8_BAR(); __builtin_amdgcn_sched_barrier(0); \
+                              __builtin_amdgcn_s_setprio(1); } while (0)
+#define PH8_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); PH8_BAR(); \
+                              __builtin_amdgcn_sched_barrier(0); } while (0)
+        // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
+        auto tile_phases = [&](int t, int mode) {
+            const int cur = t & 1;
+            const bf16_t* As_ = smem[cur];
+            const bf16_t* Bs_ = smem[cur] + BM * BK;
+            constexpr bool early = PH8 == 1;                     // copies in the read segment (1) or inside the MFMA segment (2)
+            read_b(Bs_, 0);                                      // P1
+            read_a(As_, 0);
+            if (early && mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0);
+            PH8_ENTER_MFMA();
+            mma(0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
+            PH8_LEAVE_MFMA();
+            read_b(Bs_, 1);                                      // P2
+            if (early && mode == 0) stage_a(cur, (t + 2) * BK, 0);
+            PH8_ENTER_MFMA();
+            mma(0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
+            PH8_LEAVE_MFMA();
+            read_a(As_, 1);                                      // P3
+            if (early && mode == 0) stage_b(cur, (t + 2) * BK, 1);
+            PH8_ENTER_MFMA();
+            mma(1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
+            PH8_LEAVE_MFMA();
+            read_b(Bs_, 0);                                      // P4
+            if (early && mode == 0) stage_a(cur, (t + 2) * BK, 1);
+            // everything but the most recent halves has landed = all of tile t+1  (PH8 == 1: 3 halves issued since tile t+1's B0;
+            // PH8 == 2: 2 -- this phase's copies are issued after the wait)
+            if (mode == 0) { if constexpr (early) wait_vmcnt_le<6>(); else wait_vmcnt_le<4>(); }
+            else if (mode == 1) wait_vmcnt_le<0>();
+            PH8_ENTER_MFMA();
+            mma(1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
+            PH8_LEAVE_MFMA();
+        };
+        stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
+        stage_a(1, BK, 0); stage_b(1, BK, 1); stage_a(1, BK, 1);                       // tile 1 except B0 (6 copies)
+        wait_vmcnt_le<6>();
+        PSALM_RAW_BARRIER();
+        if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
+        int t = 0;
+#pragma unroll 1
+        for (; t + 2 < nk; ++t) tile_phases(t, 0);
+        tile_phases(t, 1);
+        tile_phases(t + 1, 2);
+        if (wm == 0) PSALM_RAW_BARRIER();                        // pairs with wave row 1's last barrier
+#undef PH8_ENTER_MFMA
+#undef PH8_LEAVE_MFMA
+#undef PH8_BAR
+    } else {
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk) issue(p, p * BK);
@@ -417,6 +542,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
         }
+    }
     }
     __syncthreads();                                             // all waves done with the operand ring before it is reused
     // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
@@ -748,10 +874,16 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 static int g_tile_policy = 0;
 static long g_skinny_nmax = 4096;    // skinny kernel for M <= 128 and N <= this
 static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
+// 256x256 plain-GEMM tiles run the 4-phases-per-K-tile (PH8) K loop, variant 3 (r01 A/B on MI355X, tools/bench_gemm.py --ph8: Phi w1
+// 74.9 -> 69.4 us, 4096^3 1007 -> 1091 TF/s, 8192^3 1053 -> 1191; bitwise equal to the 2-buffer loop on 360 / 360 repetitions);
+// 0 = the plain 2-buffer loop, 1 / 2 = the other copy placements (psalm_gemm_set_tile_policy 2560 / 2568..2570)
+static int g_ph8 = 3;
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)
     if (bm == 1323 || bm == 1324) { g_ring_depth = bm - 1000; return 0; }      // 128x128, BK 32, ring depth 3 / 4 (tuning)
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
+    if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
+    if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
@@ -858,7 +990,20 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
         else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
     } else {
-        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
+        if (BM == 256 && g_ph8 && fa.k_per_split % 64 == 0 && K % 64 == 0 && fa.k_per_split >= 128 &&
+            (K - (splits - 1) * fa.k_per_split) >= 128) {
+            if (g_ph8 == 1) {
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 1>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 1>), grid, dim3(512), 0, s, fa);
+            } else if (g_ph8 == 2) {
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 2>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 2>), grid, dim3(512), 0, s, fa);
+            } else {
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 3>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 3>), grid, dim3(512), 0, s, fa);
+            }
+        }
+        else if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
         else if (BM == 128 && BN == 64) LAUNCH_GLDS(128, 64, 2, 2, 2, false);
         else if (BM == 128) {
             if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false);

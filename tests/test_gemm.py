@@ -133,6 +133,33 @@ def test_gemm_bk32_ring(ops, policy):
         ops.gemm_tile_policy(1282)
 
 
+@pytest.mark.parametrize("ph8", [2568, 2569, 2570])
+@pytest.mark.parametrize("M,N,K,cd", [(300, 520, 128, "f32"), (257, 256, 192, "bf16"), (520, 300, 256, "f32"), (260, 250, 448, "f32"),
+                                      (200, 256, 1536, "f32")])
+def test_gemm_256_ph8_schedule(ops, M, N, K, cd, ph8):
+    """256x256 tiles with the 4-phases-per-K-tile K loop (wave rows one barrier interval apart, half-tile copies refilled one
+    phase after their last read, counted vmcnt): 2 / 3 / 4 / 7 K tiles = prologue only, one and several steady-state tiles, and the
+    drain; ragged M and N; bias + activation + residual epilogue; the last case is split along K (fp32 slabs).  ph8 = 2568: the
+    half-tile copies are issued in the read segment; 2569: inside the MFMA segment."""
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(DT[cd])
+    want = _ref(a.float(), w.float(), bias, res.float(), H.ACT_GELU, 0)
+    d = ops.device
+    ops.gemm_tile_policy(256)
+    ops.gemm_tile_policy(ph8)
+    try:
+        for _ in range(2):
+            got = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d), H.ACT_GELU, 0, out_dtype=DT[cd]).cpu().double()
+            tol = (2 ** -8 if cd == "bf16" else 4e-6) * want.abs().max().item() + 1e-6
+            assert (got - want).abs().max().item() <= tol
+    finally:
+        ops.gemm_tile_policy(2570)                     # library default
+        ops.gemm_tile_policy(0)
+
+
 def test_gemm_three_stage_ring(ops):
     """128x128 configuration with a 3-deep operand ring (copies of 2 tiles in flight across the barrier, counted vmcnt)."""
     g = torch.Generator().manual_seed(11)

@@ -31,8 +31,68 @@ SHAPES = [  # name, M, N, K, out dtype
 ]
 
 
+PH8_SHAPES = [  # shapes where the 256x256 configuration is selected (or forced) -- A/B of the 4-phase K loop
+    ("phi.w1 [k|v|q|fc1]", 901, 14336, 2048, torch.bfloat16, 0),
+    ("phi.w2 [dense|fc2] forced 256", 901, 2048, 10240, torch.float32, 256),
+    ("pd.fpn-like", 65536, 256, 2304, torch.bfloat16, 0),
+    ("square4096", 4096, 4096, 4096, torch.bfloat16, 0),
+    ("square8192", 8192, 8192, 8192, torch.bfloat16, 0),
+    ("ragged 1000x1800x640", 1000, 1800, 640, torch.float32, 256),
+]
+
+
+def ph8_ab(ops):
+    """Timing A/B (baseline 2-buffer K loop vs PH8) and a race screen: the PH8 kernel accumulates every output element in the same
+    order as the baseline, so its result must be BITWISE equal to the baseline's on every repetition."""
+    res = []
+    for name, M, N, K, cdt, force in PH8_SHAPES:
+        a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+        w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+        bias = torch.randn(N, device="cuda")
+        outs = {}
+        row = {"name": name, "M": M, "N": N, "K": K}
+        for ph8 in (0, 1, 2, 3):
+            ops.gemm_tile_policy(force)
+            ops.gemm_tile_policy(2567 + ph8 if ph8 else 2560)
+            out = torch.empty(M, N, device="cuda", dtype=cdt)
+            for _ in range(3):
+                ops.gemm(a, w, bias, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            e0.record()
+            for _ in range(n):
+                ops.gemm(a, w, bias, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / n * 1e3
+            row[f"us_ph8_{ph8}" if ph8 else "us_base"] = round(us, 1)
+            row[f"TF_ph8_{ph8}" if ph8 else "TF_base"] = round(2.0 * M * N * K / (us * 1e-6) / 1e12, 1)
+            outs[ph8] = out.clone()
+        mism = 0
+        reps = 60
+        for r in range(reps):                       # race screen: fresh output buffer each time, bitwise vs the baseline result
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=cdt)
+            ops.gemm(a, w, bias, out=out)
+            if not torch.equal(out, outs[0]):
+                mism += 1
+        row["bitwise_mismatches"] = f"{mism}/{reps}"
+        row["max_abs_diff"] = max(float((outs[k].float() - outs[0].float()).abs().max()) for k in (1, 2, 3))
+        ops.gemm_tile_policy(2570)                 # library default
+        ops.gemm_tile_policy(0)
+        res.append(row)
+        print(json.dumps(row), flush=True)
+    return res
+
+
 def main():
     ops = get_ops()
+    if "--ph8" in sys.argv:
+        res = ph8_ab(ops)
+        if "--json" in sys.argv:
+            with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+                json.dump(res, f, indent=1)
+        return
     res = []
     policies = [0]
     if "--ab" in sys.argv:
