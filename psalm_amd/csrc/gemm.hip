@@ -874,11 +874,16 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 static int g_tile_policy = 0;
 static long g_skinny_nmax = 4096;    // skinny kernel for M <= 128 and N <= this
 static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
+// operand-ring depth of the 64x128 configuration: 0 = automatic (3 when the K range of a block is >= 1024: with <= 1 block per CU the
+// 2-deep loop is one exposed copy round trip per K step -- r01 A/B: Swin fc2 M4096 N512 K2048 25.4 -> 22.7 us; short-K problems lose
+// to the longer prologue), 2 / 3 / 4 = forced (policy codes 642 / 643 / 644; 640 = automatic)
+static int g_ring64 = 0;
 // 256x256 plain-GEMM tiles run the 4-phases-per-K-tile (PH8) K loop, variant 3 (r01 A/B on MI355X, tools/bench_gemm.py --ph8: Phi w1
 // 74.9 -> 69.4 us, 4096^3 1007 -> 1091 TF/s, 8192^3 1053 -> 1191; bitwise equal to the 2-buffer loop on 360 / 360 repetitions);
 // 0 = the plain 2-buffer loop, 1 / 2 = the other copy placements (psalm_gemm_set_tile_policy 2560 / 2568..2570)
 static int g_ph8 = 3;
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
+    if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
     if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)
     if (bm == 1323 || bm == 1324) { g_ring_depth = bm - 1000; return 0; }      // 128x128, BK 32, ring depth 3 / 4 (tuning)
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
@@ -1012,7 +1017,12 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
             else if (g_ring_depth == 323) LAUNCH_GLDS32(128, 128, 2, 2, 3);
             else LAUNCH_GLDS(128, 128, 2, 2, 2, false);
         }
-        else LAUNCH_GLDS(64, 128, 2, 2, 2, false);
+        else {
+            const int ring = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
+            if (ring == 4) LAUNCH_GLDS(64, 128, 2, 2, 4, false);
+            else if (ring == 3) LAUNCH_GLDS(64, 128, 2, 2, 3, false);
+            else LAUNCH_GLDS(64, 128, 2, 2, 2, false);
+        }
     }
 #undef LAUNCH_GLDS
 #undef LAUNCH_GLDS32

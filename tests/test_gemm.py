@@ -160,6 +160,27 @@ def test_gemm_256_ph8_schedule(ops, M, N, K, cd, ph8):
         ops.gemm_tile_policy(0)
 
 
+@pytest.mark.parametrize("policy", [643, 644])
+def test_gemm_64x128_deep_ring(ops, policy):
+    """64x128 configuration with a 3 / 4-deep operand ring (2 / 3 K tiles of copies in flight across the barrier)."""
+    g = torch.Generator().manual_seed(policy)
+    M, N, K = 150, 200, 448                      # M <= 192 -> 64x128 tiles; 7 K steps: prologue, steady state, drain
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003).bfloat16()
+    bias = torch.randn(N, generator=g)
+    want = a.double() @ w.double().t() + bias.double()
+    d = ops.device
+    ops.gemm_tile_policy(64)
+    ops.gemm_tile_policy(policy)
+    try:
+        for _ in range(2):
+            got = ops.gemm(a.to(d), w.to(d), bias.to(d), out_dtype=torch.float32).cpu().double()
+            assert (got - want).abs().max().item() <= 4e-6 * want.abs().max().item() + 1e-6
+    finally:
+        ops.gemm_tile_policy(640)                      # automatic ring depth
+        ops.gemm_tile_policy(0)
+
+
 def test_gemm_three_stage_ring(ops):
     """128x128 configuration with a 3-deep operand ring (copies of 2 tiles in flight across the barrier, counted vmcnt)."""
     g = torch.Generator().manual_seed(11)

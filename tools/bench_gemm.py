@@ -20,6 +20,7 @@ SHAPES = [  # name, M, N, K, out dtype
     ("swin2.fc1", 4096, 2048, 512, torch.bfloat16),
     ("swin2.fc2", 4096, 512, 2048, torch.float32),
     ("swin3.fc1", 1024, 4096, 1024, torch.bfloat16),
+    ("swin3.fc2", 1024, 1024, 4096, torch.float32),
     ("proj.conv2", 256, 2048, 18432, torch.bfloat16),
     ("pd.value", 21504, 256, 256, torch.bfloat16),
     ("pd.l1", 21504, 1024, 256, torch.bfloat16),
@@ -107,13 +108,26 @@ def main():
         policies = [1282, 128128]
     if "--skinny" in sys.argv:
         policies = [7778, 7777]
+    if "--ring64" in sys.argv:
+        policies = [642, 643, 644]
+    if "--ring128" in sys.argv:
+        policies = [1282, 1283]
     for pol in policies:
       ops.gemm_tile_policy(pol)
       if 1000 < pol < 7000 or pol == 128128:
-          ops.gemm_tile_policy(128)
+          ops.gemm_tile_policy(128 if "--ring128" not in sys.argv else 0)
+      only = None
+      if "--ring64" in sys.argv:
+          only = ("swin2.fc2", "swin2.proj", "swin0.fc2", "pr.mask_einsum", "swin3.fc2", "pr.ffn")
+      if "--ring128" in sys.argv:
+          only = ("swin2.fc1", "swin2.qkv", "swin1.qkv", "pd.l1", "pd.l2", "pd.value", "swin0.qkv", "swin0.fc1", "pr.lvl2.kv", "swin3.fc1")
       print(f"---- tile policy {pol}")
+      if "--ring64" in sys.argv and pol == policies[-1]:
+          pass
       for name, M, N, K, cdt in SHAPES:
           if pol == 256 and M < 256:
+              continue
+          if only is not None and name not in only:
               continue
           a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
           w = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
