@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0         # HBM3E, same guide
 
 
 def main():
@@ -148,6 +149,34 @@ def main():
                                      for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}
         breakdown["_gemm_kernels"] = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 4),
                                           "TFLOPs": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+        # HBM-bound kernels of the path (SURVEY §8d asks for both rooflines): algorithmic bytes per launch from the launch arguments
+        #   semantic_from_masks: read (Q, HW) f32 logits once + write (C, HW) f32                      
+        #   msda_fused: per (b, q): value row in (D*M) + offsets/logits (M*L*P*3 f32) + out row         (compulsory bytes)
+        hbm = {}
+        for name, a, e0, e1 in recs:
+            if name == "psalm_semantic_from_masks":
+                nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_kernel"
+            elif name == "psalm_msda_fused":
+                esz_v, esz_o = (2 if a[1] == 1 else 4), (2 if a[6] == 1 else 4)
+                B_, S_, M_, D_, L_, P_ = a[7], a[8], a[9], a[10], a[11], a[12]
+                nbytes, kn = B_ * S_ * (M_ * D_ * esz_v + M_ * L_ * P_ * 3 * 4 + M_ * D_ * esz_o), "msda_fused8_kernel"
+            else:
+                continue
+            h = hbm.setdefault(kn, [0, 0.0, 0])
+            h[0] += 1
+            h[1] += e0.elapsed_time(e1)
+            h[2] += nbytes
+        hbm_roof = None
+        if hbm:
+            tj = {}
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f).get("kernels", {})
+            hbm_roof = [{"kernel": k, "bound": "hbm", "achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": tj.get(k, {}).get("hbm_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": v[2] // v[0], "launches_per_step": v[0] / nprof,
+                         "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])]
         if kern:
             # dominant kernel = the single-kernel (un-split) GEMM instantiation with the largest share of the step
             cands = {k: v for k, v in kern.items() if " + " not in k} or kern
@@ -169,7 +198,8 @@ def main():
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "share_of_step_ms": round(ms / nprof, 3), "event_pair_overhead_us": round(ev_over * 1e3, 2),
                     "all_bf16_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
-                                       "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof}}
+                                       "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof},
+                    "hbm_bound_kernels": hbm_roof}
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
             with open(args.breakdown, "w") as f:
