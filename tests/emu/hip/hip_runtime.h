@@ -51,10 +51,44 @@ static const int hipMemcpyDeviceToDevice = 3;
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 static const int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 
+// Fiber switch.  glibc's swapcontext saves / restores the signal mask with two system calls per switch, and a block of 256
+// fibers switches thousands of times per barrier-heavy kernel: on x86-64 the switch is therefore a 15-instruction routine that
+// exchanges the callee-saved registers and the stack pointer (weak symbol: the header is compiled into several objects).
+#if defined(__x86_64__)
+#define PSALM_EMU_FAST_SWITCH 1
+extern "C" void psalm_emu_ctx_switch(void** save_sp, void* load_sp);
+__asm__(R"(
+    .text
+    .weak psalm_emu_ctx_switch
+    .type psalm_emu_ctx_switch,@function
+psalm_emu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size psalm_emu_ctx_switch, .-psalm_emu_ctx_switch
+)");
+#endif
+
 namespace emu {
 
 struct Fiber {
+#ifdef PSALM_EMU_FAST_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char* stack = nullptr;
     bool done = false;
     dim3 tid;
@@ -77,12 +111,20 @@ struct Block {
 
 inline Block*& blk() { static thread_local Block* b = nullptr; return b; }
 inline Fiber*& cur() { static thread_local Fiber* f = nullptr; return f; }
+#ifdef PSALM_EMU_FAST_SWITCH
+inline void*& sched() { static thread_local void* sp = nullptr; return sp; }
+#else
 inline ucontext_t& sched() { static thread_local ucontext_t c; return c; }
+#endif
 inline std::vector<char>& smem_buf() { static thread_local std::vector<char> b; return b; }
 inline void* dyn_smem() { return smem_buf().data(); }
 static const size_t STACK = 256 * 1024;
 
+#ifdef PSALM_EMU_FAST_SWITCH
+inline void yield() { psalm_emu_ctx_switch(&cur()->sp, sched()); }
+#else
 inline void yield() { swapcontext(&cur()->ctx, &sched()); }
+#endif
 
 inline void release_checks_on_exit() {
     Block* b = blk();
@@ -99,7 +141,8 @@ inline void release_checks_on_exit() {
 inline void trampoline() {
     blk()->fn();
     release_checks_on_exit();
-    swapcontext(&cur()->ctx, &sched());
+    yield();                      // a finished fiber is never resumed
+    abort();
 }
 
 inline void syncthreads() {
@@ -151,11 +194,21 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, F fn) {
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.stack = stacks[t];
                     b.waves[t / 64].alive++;
+#ifdef PSALM_EMU_FAST_SWITCH
+                    {   // initial frame: six callee-saved slots, then the address `ret` jumps to; rsp % 16 == 8 on entry, as after a call
+                        void** sp = (void**)(((uintptr_t)f.stack + STACK) & ~(uintptr_t)15);
+                        *--sp = nullptr;
+                        *--sp = (void*)(void (*)())trampoline;
+                        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+                        f.sp = sp;
+                    }
+#else
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = STACK;
                     f.ctx.uc_link = &sched();
                     makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
                 }
                 int stalled = 0;
                 for (;;) {
@@ -166,7 +219,11 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, F fn) {
                         if (f.done) continue;
                         any = true;
                         cur() = &f;
+#ifdef PSALM_EMU_FAST_SWITCH
+                        psalm_emu_ctx_switch(&sched(), f.sp);
+#else
                         swapcontext(&sched(), &f.ctx);
+#endif
                     }
                     if (!any) break;
                     if (b.progress == p0) {
