@@ -1,6 +1,8 @@
 """End-to-end host orchestration (psalm_amd.model.PSALM) on a TINY architecture, kernels running in the host
 emulation, against the CPU oracle on the same seeded weights/inputs.  Validates layouts, weight fusion/folding,
 token splicing and the stage wiring without a GPU.  (The full-size model is checked on the GPU: test_e2e_gpu.py.)"""
+import dataclasses
+
 import pytest
 import torch
 
@@ -94,6 +96,27 @@ def test_tiny_eval_seg_postprocess_fp32(task, batch, pad):
             assert _rel(gi.scores, wi.scores) < 2e-3
             assert (gi.pred_masks.cpu() != wi.pred_masks).float().mean() < 1e-3
             assert _rel(g["gt"], w["gt"]) < 1e-5
+
+
+def test_tiny_eval_seg_bf16_mode_fused_paths():
+    """precision="bf16" end to end on the emulator (the mode bench.py measures): bf16 GEMM operands on the direct-to-LDS kernels,
+    MFMA attention kernels, split-K + fused LayerNorm, and -- with 72 queries, i.e. a 128-wide padded K -- the fused
+    sigmoid / semantic / mask-score pass.  Tolerances are bf16-operand level against the fp32 oracle."""
+    cfg = dataclasses.replace(PsalmConfig.tiny("panoptic"), md_queries=72)
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=4, num_classes=9)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="bf16")
+    torch.manual_seed(5)
+    w = O.eval_seg(sd, cfg, **inputs)[0]
+    torch.manual_seed(5)
+    g = model.eval_seg(**inputs)[0]
+    assert _rel(g["mask_pred"], w["mask_pred"]) < 2e-2
+    assert _rel(g["sem_seg"], w["sem_seg"]) < 0.1
+    assert (g["sem_seg"].argmax(0).cpu() == w["sem_seg"].argmax(0)).float().mean() > 0.95
+    assert (g["panoptic_seg"][0].cpu() == w["panoptic_seg"][0]).float().mean() > 0.95
+    gi, wi = g["instances"], w["instances"]
+    assert len(gi.scores) == len(wi.scores)
+    assert (torch.sort(gi.scores.cpu()).values - torch.sort(wi.scores).values).abs().max() < 2e-2
 
 
 def test_tiny_fp8_llm_path_vs_fake_quant_oracle():
