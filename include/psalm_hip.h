@@ -214,6 +214,8 @@ int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, 
 int psalm_ln_mlp3(const float* x, long ldx, const float* gamma, const float* beta, float eps, const void* w0, const float* b0,
                   const void* w1, const float* b1, const void* w2, const float* b2, void* ln_out_bf16, void* out_bf16, int rows, int D,
                   void* stream);
+/* A/B switch of the two kernels below: 1 (default) = weights staged through LDS with coalesced copies, 0 = per-lane fragment loads. */
+int psalm_heads_set_variant(int staged);
 /* Post-norm sub-layer tail of the mask decoder, fused: y = LayerNorm(residual + a.w^T + bias) (attention out-projection + residual +
  * norm, mask2former_transformer_decoder.py:40-50, 99-111).  a (rows,K) bf16; w (D,K) bf16; residual (rows,D) f32 or NULL; outputs as
  * psalm_layernorm3: y f32, y2 = bf16(y) or NULL, y3 = bf16(y + add[row % add_rows]) or NULL.  D in {64,128,256}, K % 16 == 0, K <= 512. */

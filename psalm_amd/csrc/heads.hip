@@ -109,9 +109,121 @@ __global__ void __launch_bounds__(256) ln_mlp3_kernel(const float* __restrict__ 
     }
 }
 
+// Variant with the weights staged through LDS.  The direct fragment loads above touch 32 cache lines per instruction (lane = weight
+// row) and only ceil(rows / 32) CUs issue them; here every wave copies whole 1 KiB pieces (8 weight rows x 64 k, coalesced
+// global_load_lds, the GEMM kernel's XOR-swizzled [rows][64] image) into a 2-deep ring of 64-deep K chunks, and the three layers
+// form ONE chunk stream: the first chunk of layer j+1 is in flight while the last chunk of layer j is being multiplied.
+template <int D>
+__global__ void __launch_bounds__(256) ln_mlp3_staged_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, const bf16_t* __restrict__ w0,
+                                                             const float* __restrict__ b0, const bf16_t* __restrict__ w1,
+                                                             const float* __restrict__ b1, const bf16_t* __restrict__ w2,
+                                                             const float* __restrict__ b2, bf16_t* __restrict__ ln_out,
+                                                             bf16_t* __restrict__ out, int rows) {
+    static_assert(D % 64 == 0 && D <= 256, "hidden width");
+    constexpr int PITCH = D + 8, NT = D / 32, TPW = (NT + 3) / 4;
+    constexpr int NC = D / 64;                               // 64-deep K chunks per layer
+    constexpr int CPW = D / 8 / 4;                           // 1 KiB copies per wave per chunk (D/8 copies of 8 rows)
+    __shared__ __attribute__((aligned(16))) bf16_t act[2][32 * PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t Ws[2][D * 64];
+    const int tid = threadIdx.x, lane = tid & 63, n32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * 32;
+    auto issue = [&](int g) {                                // chunk g of the 3 * NC chunk stream -> ring slot g & 1
+        const int layer = g / NC, c = g % NC;
+        const bf16_t* Wl = layer == 0 ? w0 : (layer == 1 ? w1 : w2);
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int copy = wave + 4 * i, r = copy * 8 + lane / 8;
+            const int kc = (lane % 8) ^ ((r >> 1) & 7);
+            psalm_glds16(Wl + (long)r * D + c * 64 + kc * 8, &Ws[g & 1][copy * 8 * 64]);
+        }
+    };
+    issue(0);                                                // in flight during the LayerNorm
+    constexpr int VPL = (D + 63) / 64;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr, row = r0 + rl;
+        float v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = (row < rows && c < D) ? x[(long)row * ldx + c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D) { const float d = v[i] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D) {
+                const bf16_t o = row < rows ? f32_to_bf16((v[i] - mean) * rstd * gamma[c] + beta[c]) : (bf16_t)0;
+                act[0][rl * PITCH + c] = o;
+                if (row < rows) ln_out[(long)row * D + c] = o;
+            }
+        }
+    }
+    hd_f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int fsw = (n32 >> 1) & 7;
+#pragma unroll 1
+    for (int g = 0; g < 3 * NC; ++g) {
+        const int layer = g / NC, c = g % NC;
+        PSALM_WAIT_VMCNT(0);                                 // this wave's pieces of chunk g have landed ...
+        PSALM_RAW_BARRIER();                                 // ... everyone's have; slot (g+1)&1 is no longer read; previous layer's activations visible
+        if (g + 1 < 3 * NC) issue(g + 1);
+        const bf16_t* in = act[layer & 1];
+        const bf16_t* Wc = Ws[g & 1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const psalm_u32x4 a = *reinterpret_cast<const psalm_u32x4*>(&in[n32 * PITCH + c * 64 + kk * 16 + 8 * hi]);
+            const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (wave + 4 * t < NT) {
+                    const psalm_u32x4 b = *reinterpret_cast<const psalm_u32x4*>(&Wc[((wave + 4 * t) * 32 + n32) * 64 + co]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hd_bf16x8, a), __builtin_bit_cast(hd_bf16x8, b), acc[t], 0, 0, 0);
+                }
+        }
+        if (c == NC - 1) {                                   // layer finished: bias (+ ReLU) -> the other activation buffer / the result
+            const float* bl = layer == 0 ? b0 : (layer == 1 ? b1 : b2);
+            bf16_t* nxt = act[(layer + 1) & 1];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < NT) {
+                    const int col = tile * 32 + n32;
+                    const float bias = bl[col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float yv = acc[t][r] + bias;
+                        if (layer < 2) nxt[rl * PITCH + col] = f32_to_bf16(yv > 0.f ? yv : 0.f);
+                        else if (r0 + rl < rows) out[(long)(r0 + rl) * D + col] = f32_to_bf16(yv);
+                        acc[t][r] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // x (rows, D) f32, row stride ldx;  gamma / beta (D) f32;  w_j (D, D) bf16 row-major (nn.Linear weight), b_j (D) f32;
 // ln_out (rows, D) bf16 = LayerNorm(x) (the operand of the class / SEG / region heads);  out (rows, D) bf16 = W2.relu(W1.relu(W0.ln+b0)+b1)+b2.
 // D in {64, 128, 256}.
+// 1 (default): weights staged through LDS;  0: direct per-lane fragment loads (A/B switch, tools/bench_heads.py)
+static int g_heads_staged = 1;
+extern "C" int psalm_heads_set_variant(int staged) { g_heads_staged = staged ? 1 : 0; return 0; }
+
 extern "C" int psalm_ln_mlp3(const float* x, long ldx, const float* gamma, const float* beta, float eps, const void* w0, const float* b0,
                              const void* w1, const float* b1, const void* w2, const float* b2, void* ln_out_bf16, void* out_bf16,
                              int rows, int D, void* stream) {
@@ -120,11 +232,17 @@ extern "C" int psalm_ln_mlp3(const float* x, long ldx, const float* gamma, const
     if (rows == 0) return 0;
     const dim3 grid((rows + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
-#define HD_LAUNCH(D_) hipLaunchKernelGGL((ln_mlp3_kernel<D_>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (const bf16_t*)w0, b0, \
-                                         (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)ln_out_bf16, (bf16_t*)out_bf16, rows)
-    if (D == 256) HD_LAUNCH(256);
-    else if (D == 128) HD_LAUNCH(128);
-    else HD_LAUNCH(64);
+#define HD_LAUNCH(KERN_, D_) hipLaunchKernelGGL((KERN_<D_>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (const bf16_t*)w0, b0, \
+                                               (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)ln_out_bf16, (bf16_t*)out_bf16, rows)
+    if (g_heads_staged) {
+        if (D == 256) HD_LAUNCH(ln_mlp3_staged_kernel, 256);
+        else if (D == 128) HD_LAUNCH(ln_mlp3_staged_kernel, 128);
+        else HD_LAUNCH(ln_mlp3_staged_kernel, 64);
+    } else {
+        if (D == 256) HD_LAUNCH(ln_mlp3_kernel, 256);
+        else if (D == 128) HD_LAUNCH(ln_mlp3_kernel, 128);
+        else HD_LAUNCH(ln_mlp3_kernel, 64);
+    }
 #undef HD_LAUNCH
     PSALM_LAUNCH_END("psalm_ln_mlp3");
 }
@@ -236,6 +354,113 @@ __global__ void __launch_bounds__(256) linear_res_ln_kernel(const bf16_t* __rest
     }
 }
 
+// LDS-staged weights (see ln_mlp3_staged_kernel): 64-deep K chunks of the (D, K) weight matrix in a 2-deep ring; K % 64 == 0.
+// The fp32 pre-norm rows reuse the ring's memory after the last chunk.
+template <int D>
+__global__ void __launch_bounds__(256) linear_res_ln_staged_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ w,
+                                                                   const float* __restrict__ bias, const float* __restrict__ res, long ldr,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float eps, float* __restrict__ y, bf16_t* __restrict__ y2,
+                                                                   const float* __restrict__ add, int add_rows, bf16_t* __restrict__ y3,
+                                                                   int rows, int K) {
+    static_assert(D % 64 == 0 && D <= 256, "output width");
+    constexpr int NT = D / 32, TPW = (NT + 3) / 4, CPW = D / 8 / 4, SP = D + 4, KMAX = 512;
+    static_assert(32 * SP * 4 <= 2 * D * 64 * 2, "pre-norm rows must fit in the weight ring");
+    __shared__ __attribute__((aligned(16))) bf16_t As[32 * (KMAX + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t Ws[2][D * 64];
+    const int AP = K + 8;
+    const int tid = threadIdx.x, lane = tid & 63, n32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * 32, nc = K / 64;
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int copy = wave + 4 * i, r = copy * 8 + lane / 8;
+            const int kc = (lane % 8) ^ ((r >> 1) & 7);
+            psalm_glds16(w + (long)r * K + c * 64 + kc * 8, &Ws[c & 1][copy * 8 * 64]);
+        }
+    };
+    issue(0);
+    for (int e = tid; e < 32 * (K / 8); e += 256) {          // operand rows -> LDS (rows beyond `rows`: zeros)
+        const int rl = e / (K / 8), c8 = (e % (K / 8)) * 8;
+        psalm_u32x4 v{0, 0, 0, 0};
+        if (r0 + rl < rows) v = *reinterpret_cast<const psalm_u32x4*>(a + (long)(r0 + rl) * lda + c8);
+        *reinterpret_cast<psalm_u32x4*>(&As[rl * AP + c8]) = v;
+    }
+    hd_f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int fsw = (n32 >> 1) & 7;
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+        PSALM_WAIT_VMCNT(0);
+        PSALM_RAW_BARRIER();                                 // chunk c landed for everyone (and, c == 0, the operand rows are in LDS)
+        if (c + 1 < nc) issue(c + 1);
+        const bf16_t* Wc = Ws[c & 1];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const psalm_u32x4 af = *reinterpret_cast<const psalm_u32x4*>(&As[n32 * AP + c * 64 + kk * 16 + 8 * hi]);
+            const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (wave + 4 * t < NT) {
+                    const psalm_u32x4 b = *reinterpret_cast<const psalm_u32x4*>(&Wc[((wave + 4 * t) * 32 + n32) * 64 + co]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hd_bf16x8, af), __builtin_bit_cast(hd_bf16x8, b), acc[t], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();                                         // every wave is done reading the ring: it now holds the pre-norm rows
+    float* S = reinterpret_cast<float*>(&Ws[0][0]);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < NT) {
+            const int col = tile * 32 + n32;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float rv = (res && r0 + rl < rows) ? res[(long)(r0 + rl) * ldr + col] : 0.f;
+                S[rl * SP + col] = acc[t][r] + bv + rv;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int VPL = (D + 63) / 64;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr, row = r0 + rl;
+        if (row >= rows) break;
+        float v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = c < D ? S[rl * SP + c] : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D) { const float d = v[i] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D) {
+                const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+                y[(long)row * D + c] = o;
+                if (y2) y2[(long)row * D + c] = f32_to_bf16(o);
+                if (y3) y3[(long)row * D + c] = f32_to_bf16(o + add[(long)(row % add_rows) * D + c]);
+            }
+        }
+    }
+}
+
 // a (rows,K) bf16 row stride lda;  w (D,K) bf16 (nn.Linear weight);  bias (D) f32 or NULL;  residual (rows,D) f32 row stride ldr or NULL;
 // y (rows,D) f32 = LayerNorm(residual + a.w^T + bias);  y2 (rows,D) bf16 or NULL;  y3 (rows,D) bf16 = y + add[row % add_rows] or NULL
 // (add (add_rows,D) f32).  D in {64,128,256}, K % 16 == 0, K <= 512.
@@ -253,7 +478,16 @@ extern "C" int psalm_linear_res_ln(const void* a_bf16, long lda, const void* w_b
 #define HD_LAUNCH(D_) hipLaunchKernelGGL((linear_res_ln_kernel<D_>), grid, dim3(256), shmem, s, (const bf16_t*)a_bf16, lda, (const bf16_t*)w_bf16, \
                                          bias, residual, ldr, gamma, beta, eps, y, (bf16_t*)y2_bf16, add, add_rows > 0 ? add_rows : 1,       \
                                          (bf16_t*)y3_bf16, rows, K)
-    if (D == 256) HD_LAUNCH(256);
+    if (g_heads_staged && K % 64 == 0) {
+#define HD_LAUNCH_S(D_) hipLaunchKernelGGL((linear_res_ln_staged_kernel<D_>), grid, dim3(256), 0, s, (const bf16_t*)a_bf16, lda,             \
+                                           (const bf16_t*)w_bf16, bias, residual, ldr, gamma, beta, eps, y, (bf16_t*)y2_bf16, add,           \
+                                           add_rows > 0 ? add_rows : 1, (bf16_t*)y3_bf16, rows, K)
+        if (D == 256) HD_LAUNCH_S(256);
+        else if (D == 128) HD_LAUNCH_S(128);
+        else HD_LAUNCH_S(64);
+#undef HD_LAUNCH_S
+    }
+    else if (D == 256) HD_LAUNCH(256);
     else if (D == 128) HD_LAUNCH(128);
     else HD_LAUNCH(64);
 #undef HD_LAUNCH

@@ -48,7 +48,7 @@ class _ProfiledLib:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
         if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version",
-                                                         "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
+                                                         "psalm_gemm_set_tile_policy", "psalm_heads_set_variant") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -481,6 +481,10 @@ class Ops:
         rc = self.lib.psalm_sigmoid_transpose(self._p(mask), self._p(out), _dt(out), Q, c_long(HW), Kpad, self._stream())
         self._check(rc, "psalm_sigmoid_transpose")
         return out
+
+    def heads_variant(self, staged: bool):
+        """A/B switch of ln_mlp3 / linear_res_ln: weights staged through LDS (default) or per-lane fragment loads."""
+        self._check(self.lib.psalm_heads_set_variant(1 if staged else 0), "psalm_heads_set_variant")
 
     def ln_mlp3(self, x, gamma, beta, ws, bs, eps=1e-5):
         """x (rows,D) f32 -> (LayerNorm(x) bf16, MLP3(LayerNorm(x)) bf16): decoder_norm + mask_embed in one launch.
