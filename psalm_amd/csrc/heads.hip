@@ -9,6 +9,116 @@
 typedef float hd_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 hd_bf16x8 __attribute__((ext_vector_type(8)));
 
+// LayerNorm of the block's 32 rows straight from global memory (8 rows per wave, a lane holds D / 64 values of a row; D % 64 == 0):
+// bf16 result to the LDS activation image and to ln_out.  All loads are unconditional (row index clamped) and issued up front --
+// a `row < rows ? x[..] : 0` per element compiles to a branch + s_waitcnt vmcnt(0) per load, i.e. 32 serialized L2 round trips.
+// Same arithmetic as layernorm_vec_kernel (two-pass variance).
+template <int D>
+__device__ __forceinline__ void head_ln_rows(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, bf16_t* __restrict__ act0, int pitch,
+                                             bf16_t* __restrict__ ln_out, int r0, int rows, int wave, int lane) {
+    static_assert(D % 64 == 0, "hidden width");
+    constexpr int VPL = D / 64;
+    float g[VPL], b[VPL], v[8][VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { g[i] = gamma[i * 64 + lane]; b[i] = beta[i * 64 + lane]; }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float* xr = x + (long)min(r0 + wave * 8 + rr, rows - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[rr][i] = xr[i * 64 + lane];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr, row = r0 + rl;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[rr][i];
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float d = v[rr][i] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            const bf16_t o = row < rows ? f32_to_bf16((v[rr][i] - mean) * rstd * g[i] + b[i]) : (bf16_t)0;
+            act0[rl * pitch + c] = o;
+            if (row < rows) ln_out[(long)row * D + c] = o;
+        }
+    }
+}
+
+// LayerNorm of the 32 pre-norm fp32 rows held in LDS (S, pitch SP), outputs as psalm_layernorm3.  The `add` rows are fetched for all 8
+// rows of the wave before the statistics (unconditional, clamped row), so the global round trip overlaps the reductions.
+template <int D>
+__device__ __forceinline__ void head_ln_from_lds(const float* S, int SP, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float eps, float* __restrict__ y, bf16_t* __restrict__ y2, const float* __restrict__ add,
+                                                 int add_rows, bf16_t* __restrict__ y3, int r0, int rows, int wave, int lane) {
+    static_assert(D % 64 == 0, "output width");
+    constexpr int VPL = D / 64;
+    float g[VPL], b[VPL], av[8][VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { g[i] = gamma[i * 64 + lane]; b[i] = beta[i * 64 + lane]; }
+    if (y3) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float* ar = add + (long)(min(r0 + wave * 8 + rr, rows - 1) % add_rows) * D;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) av[rr][i] = ar[i * 64 + lane];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr, row = r0 + rl;
+        float v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { v[i] = S[rl * SP + i * 64 + lane]; s += v[i]; }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / D + eps);
+        if (row < rows) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = i * 64 + lane;
+                const float o = (v[i] - mean) * rstd * g[i] + b[i];
+                y[(long)row * D + c] = o;
+                if (y2) y2[(long)row * D + c] = f32_to_bf16(o);
+                if (y3) y3[(long)row * D + c] = f32_to_bf16(o + av[rr][i]);
+            }
+        }
+    }
+}
+
+// accumulators + bias + residual -> the fp32 pre-norm rows in LDS.  The residual values of all the wave's tiles are fetched first
+// (unconditional, clamped row), then added: one round trip instead of one per element.
+template <int D, int TPW>
+__device__ __forceinline__ void head_store_prenorm(const hd_f32x16 (&acc)[TPW], const float* __restrict__ bias, const float* __restrict__ res,
+                                                   long ldr, float* S, int SP, int r0, int rows, int wave, int n32, int hi) {
+    constexpr int NT = D / 32;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < NT) {
+            const int col = tile * 32 + n32;
+            const float bv = bias ? bias[col] : 0.f;
+            float rv[16];
+            if (res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = res[(long)min(r0 + (r & 3) + 8 * (r >> 2) + 4 * hi, rows - 1) * ldr + col];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * hi) * SP + col] = acc[t][r] + bv + rv[r];
+        }
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) ln_mlp3_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, const bf16_t* __restrict__ w0,
@@ -16,7 +126,7 @@ __global__ void __launch_bounds__(256) ln_mlp3_kernel(const float* __restrict__ 
                                                       const float* __restrict__ b1, const bf16_t* __restrict__ w2,
                                                       const float* __restrict__ b2, bf16_t* __restrict__ ln_out,
                                                       bf16_t* __restrict__ out, int rows) {
-    static_assert(D % 32 == 0 && D <= 256, "hidden width");
+    static_assert(D % 64 == 0 && D <= 256, "hidden width");
     constexpr int PITCH = D + 8;                             // 16-byte aligned rows, 16 consecutive rows on 16 distinct 16-byte slots
     constexpr int NT = D / 32;                               // 32-column output tiles per layer
     constexpr int TPW = (NT + 3) / 4;                        // tiles per wave
@@ -25,36 +135,7 @@ __global__ void __launch_bounds__(256) ln_mlp3_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) bf16_t act[2][32 * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
     const int r0 = blockIdx.x * 32;
-    // ---- LayerNorm of this block's 32 rows (8 per wave; a lane holds D / 64 values of the row), same arithmetic as layernorm_vec_kernel
-    constexpr int VPL = (D + 63) / 64;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int rl = wave * 8 + rr, row = r0 + rl;
-        float v[VPL];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            v[i] = (row < rows && c < D) ? x[(long)row * ldx + c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) { const float d = v[i] - mean; q += d * d; }
-        }
-        const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) {
-                const bf16_t o = row < rows ? f32_to_bf16((v[i] - mean) * rstd * gamma[c] + beta[c]) : (bf16_t)0;
-                act[0][rl * PITCH + c] = o;
-                if (row < rows) ln_out[(long)row * D + c] = o;
-            }
-        }
-    }
+    head_ln_rows<D>(x, ldx, gamma, beta, eps, act[0], PITCH, ln_out, r0, rows, wave, lane);   // decoder_norm -> act[0], ln_out
     __syncthreads();
     // ---- three layers
     const bf16_t* W[3] = {w0, w1, w2};
@@ -140,35 +221,7 @@ __global__ void __launch_bounds__(256) ln_mlp3_staged_kernel(const float* __rest
         }
     };
     issue(0);                                                // in flight during the LayerNorm
-    constexpr int VPL = (D + 63) / 64;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int rl = wave * 8 + rr, row = r0 + rl;
-        float v[VPL];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            v[i] = (row < rows && c < D) ? x[(long)row * ldx + c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) { const float d = v[i] - mean; q += d * d; }
-        }
-        const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) {
-                const bf16_t o = row < rows ? f32_to_bf16((v[i] - mean) * rstd * gamma[c] + beta[c]) : (bf16_t)0;
-                act[0][rl * PITCH + c] = o;
-                if (row < rows) ln_out[(long)row * D + c] = o;
-            }
-        }
-    }
+    head_ln_rows<D>(x, ldx, gamma, beta, eps, act[0], PITCH, ln_out, r0, rows, wave, lane);
     hd_f32x16 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
@@ -260,7 +313,7 @@ __global__ void __launch_bounds__(256) linear_res_ln_kernel(const bf16_t* __rest
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             float* __restrict__ y, bf16_t* __restrict__ y2, const float* __restrict__ add,
                                                             int add_rows, bf16_t* __restrict__ y3, int rows, int K) {
-    static_assert(D % 32 == 0 && D <= 256, "output width");
+    static_assert(D % 64 == 0 && D <= 256, "output width");
     constexpr int NT = D / 32, TPW = (NT + 3) / 4;
     constexpr int SP = D + 4;                                // fp32 row pitch of the pre-norm rows
     HIP_DYNAMIC_SHARED(unsigned char, smem_raw)
@@ -306,52 +359,9 @@ __global__ void __launch_bounds__(256) linear_res_ln_kernel(const bf16_t* __rest
             }
         }
     }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = wave + 4 * t;
-        if (tile < NT) {
-            const int col = tile * 32 + n32;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float rv = (res && r0 + rl < rows) ? res[(long)(r0 + rl) * ldr + col] : 0.f;
-                S[rl * SP + col] = acc[t][r] + bv + rv;
-            }
-        }
-    }
+    head_store_prenorm<D, TPW>(acc, bias, res, ldr, S, SP, r0, rows, wave, n32, hi);
     __syncthreads();
-    constexpr int VPL = (D + 63) / 64;
-    for (int rr = 0; rr < 8; ++rr) {                         // LayerNorm, 8 rows per wave (arithmetic of layernorm_vec_kernel)
-        const int rl = wave * 8 + rr, row = r0 + rl;
-        if (row >= rows) break;
-        float v[VPL];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            v[i] = c < D ? S[rl * SP + c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) { const float d = v[i] - mean; q += d * d; }
-        }
-        const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) {
-                const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-                y[(long)row * D + c] = o;
-                if (y2) y2[(long)row * D + c] = f32_to_bf16(o);
-                if (y3) y3[(long)row * D + c] = f32_to_bf16(o + add[(long)(row % add_rows) * D + c]);
-            }
-        }
-    }
+    head_ln_from_lds<D>(S, SP, gamma, beta, eps, y, y2, add, add_rows, y3, r0, rows, wave, lane);
 }
 
 // LDS-staged weights (see ln_mlp3_staged_kernel): 64-deep K chunks of the (D, K) weight matrix in a 2-deep ring; K % 64 == 0.
@@ -413,52 +423,9 @@ __global__ void __launch_bounds__(256) linear_res_ln_staged_kernel(const bf16_t*
     }
     __syncthreads();                                         // every wave is done reading the ring: it now holds the pre-norm rows
     float* S = reinterpret_cast<float*>(&Ws[0][0]);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = wave + 4 * t;
-        if (tile < NT) {
-            const int col = tile * 32 + n32;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float rv = (res && r0 + rl < rows) ? res[(long)(r0 + rl) * ldr + col] : 0.f;
-                S[rl * SP + col] = acc[t][r] + bv + rv;
-            }
-        }
-    }
+    head_store_prenorm<D, TPW>(acc, bias, res, ldr, S, SP, r0, rows, wave, n32, hi);
     __syncthreads();
-    constexpr int VPL = (D + 63) / 64;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int rl = wave * 8 + rr, row = r0 + rl;
-        if (row >= rows) break;
-        float v[VPL];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            v[i] = c < D ? S[rl * SP + c] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s) / D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) { const float d = v[i] - mean; q += d * d; }
-        }
-        const float rstd = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = i * 64 + lane;
-            if (c < D) {
-                const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-                y[(long)row * D + c] = o;
-                if (y2) y2[(long)row * D + c] = f32_to_bf16(o);
-                if (y3) y3[(long)row * D + c] = f32_to_bf16(o + add[(long)(row % add_rows) * D + c]);
-            }
-        }
-    }
+    head_ln_from_lds<D>(S, SP, gamma, beta, eps, y, y2, add, add_rows, y3, r0, rows, wave, lane);
 }
 
 // a (rows,K) bf16 row stride lda;  w (D,K) bf16 (nn.Linear weight);  bias (D) f32 or NULL;  residual (rows,D) f32 row stride ldr or NULL;
