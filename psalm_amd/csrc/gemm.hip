@@ -23,6 +23,7 @@
 // blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (sharing the A row-panel) are placed on the
 // same XCD (block b runs on XCD b % 8) so the panel is fetched into that XCD's L2 once.
 #include "common.h"
+#include <type_traits>
 
 #define ACT_NONE 0
 #define ACT_RELU 1
@@ -85,16 +86,31 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x16& 
     const bool do_act = act != ACT_NONE && col >= g.act_col_start;
     TC* C = (TC*)g.C;
     const TC* R = (const TC*)g.res;
+    // residual / per-row bias of all 16 rows fetched up front, unconditionally (row clamped): inside the `row < g.M` guard each
+    // load became its own branch + s_waitcnt vmcnt(0), 16 serialized round trips per tile (r01 ISA audit)
+    float rv[16], rb[16];
+    if (R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = ldf(R + (long)min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), g.M - 1) * g.ldr + col);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    }
+    if (brow && g.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[r] = g.bias[min(row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), g.M - 1)];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[r] = b;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.M) {
-            float v = acc[r] + (brow && g.bias ? g.bias[row] : b);
-            if (do_act && !post) v = apply_act(v, act);
-            if (R) v += ldf(R + (long)row * g.ldr + col);
-            if (do_act && post) v = apply_act(v, act);
-            stf(C + (long)row * g.ldc + col, v);
-        }
+        float v = acc[r] + rb[r];
+        if (do_act && !post) v = apply_act(v, act);
+        v += rv[r];
+        if (do_act && post) v = apply_act(v, act);
+        if (row < g.M) stf(C + (long)row * g.ldc + col, v);
     }
 }
 
@@ -653,19 +669,27 @@ __global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kb = 0; kb < per; kb += 8) {                        // chunks of 8 k-steps: 16 independent 16-byte loads per lane
-        u32x4_s fa_[8], fb_[8];
+    // Chunks of CH k-steps with NO per-load guard: a guarded load (`if (kb + i < per) load`) compiles to a branch and an
+    // s_waitcnt vmcnt(0) per load -- r01 ISA audit: 48 of this kernel's 49 loads were serialized that way, i.e. the "all loads of a
+    // chunk in flight together" design was not what ran.  Full chunks of 8, then of 4 (K = 256: exactly one), then single steps.
+    int kb = 0;
+    auto chunk = [&](auto CHT) {
+        constexpr int CH = decltype(CHT)::value;
+        u32x4_s fa_[CH], fb_[CH];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (kb + i < per) {
-                fa_[i] = *reinterpret_cast<const u32x4_s*>(A + (long)(k0 + kb + i) * 16);
-                fb_[i] = *reinterpret_cast<const u32x4_s*>(W + (long)(k0 + kb + i) * 16);
-            }
+        for (int i = 0; i < CH; ++i) {
+            fa_[i] = *reinterpret_cast<const u32x4_s*>(A + (long)(k0 + kb + i) * 16);
+            fb_[i] = *reinterpret_cast<const u32x4_s*>(W + (long)(k0 + kb + i) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // all 2 CH loads issued before the first MFMA waits on one
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (kb + i < per)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]), __builtin_bit_cast(bf16x8, fb_[i]), acc, 0, 0, 0);
-    }
+        for (int i = 0; i < CH; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]), __builtin_bit_cast(bf16x8, fb_[i]), acc, 0, 0, 0);
+        kb += CH;
+    };
+    while (kb + 8 <= per) chunk(std::integral_constant<int, 8>{});
+    if (kb + 4 <= per) chunk(std::integral_constant<int, 4>{});
+    while (kb < per) chunk(std::integral_constant<int, 1>{});
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave - 1][r * 64 + lane] = acc[r];

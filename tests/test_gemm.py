@@ -160,6 +160,25 @@ def test_gemm_256_ph8_schedule(ops, M, N, K, cd, ph8):
         ops.gemm_tile_policy(0)
 
 
+@pytest.mark.parametrize("K", [64, 192, 256, 320, 512, 832, 2048])
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_gemm_skinny_k_chunking(ops, K, cd):
+    """M <= 128 skinny kernel: every lane's K range is walked in unguarded chunks of 8, then 4, then single MFMA steps
+    (K / 64 = 1, 3, 4, 5, 8, 13, 32 steps per wave cover all combinations); residual + activation epilogue with batched loads."""
+    g = torch.Generator().manual_seed(K)
+    M, N = 100, 96
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(DT[cd])
+    want = _ref(a.float(), w.float(), bias, res.float(), H.ACT_RELU, 0)
+    d = ops.device
+    assert ops.gemm_describe(M, N, K, True, True)[0] == 2            # really the skinny path
+    got = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d), H.ACT_RELU, 0, out_dtype=DT[cd]).cpu().double()
+    tol = (2 ** -8 if cd == "bf16" else 4e-6) * want.abs().max().item() + 1e-6
+    assert (got - want).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("policy", [643, 644])
 def test_gemm_64x128_deep_ring(ops, policy):
     """64x128 configuration with a 3 / 4-deep operand ring (2 / 3 K tiles of copies in flight across the barrier)."""
