@@ -715,12 +715,19 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
     const TC* R = (const TC*)g.res;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     const bool full = (c0 + 3 < g.N) && (g.N % 4 == 0);
-    for (int z = 0; z < splits; ++z) {
-        const float* p = slab + ((long)z * g.M + row) * g.N + c0;
-        if (full) {
-            const f32x4_g t = *reinterpret_cast<const f32x4_g*>(p);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-        } else {
+    if (full) {                                                  // 4 slabs per round trip (unconditional loads, clamped z, masked add)
+        for (int z0 = 0; z0 < splits; z0 += 4) {
+            f32x4_g t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                t[k] = *reinterpret_cast<const f32x4_g*>(slab + ((long)min(z0 + k, splits - 1) * g.M + row) * g.N + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (z0 + k < splits) { v[0] += t[k].x; v[1] += t[k].y; v[2] += t[k].z; v[3] += t[k].w; }
+        }
+    } else {
+        for (int z = 0; z < splits; ++z) {
+            const float* p = slab + ((long)z * g.M + row) * g.N + c0;
             for (int i = 0; i < 4; ++i) if (c0 + i < g.N) v[i] += p[i];
         }
     }
@@ -741,7 +748,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
 // layer's input_layernorm): one block per output row sums the slabs, applies bias / activation / residual, writes the fp32
 // row AND its LayerNorm (the next GEMM's A operand) -- one pass over the row instead of reduce + a separate LN launch.
 // N % 4 == 0, N <= 8192.
-template <typename TL>
+// NV = 4-column vectors per thread (N <= 1024 * NV).  Every global load is unconditional (column / slab index clamped, the value
+// masked afterwards) and the slab reads go in groups of 4 slabs x NV vectors: guarded loads inside the runtime z loop had compiled
+// to one s_waitcnt vmcnt(0) round trip per load (r01 ISA audit: 72 of 72), i.e. ~(splits + 3) * NV dependent L2 / HBM latencies
+// per block.  The per-element summation order (z ascending) is unchanged.
+template <typename TL, int NV>
 __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const float* __restrict__ slab, int splits,
                                                                const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
                                                                float ln_eps, TL* __restrict__ ln_out, long ld_ln) {
@@ -751,33 +762,64 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
     const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
     float* C = (float*)g.C;
     const float* R = (const float*)g.res;
-    constexpr int MAXV = 8;                                       // 8 x 4 x 256 = 8192 columns
-    f32x4_g v[MAXV];
+    int c0[NV], cc[NV];                                          // this thread's columns / clamped copy for the loads
+    f32x4_g a[NV], bi[NV], ga[NV], be[NV];
+    float rr[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        c0[i] = (tid + 256 * i) * 4;
+        cc[i] = min(c0[i], g.N - 4);
+        a[i] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+        ga[i] = *reinterpret_cast<const f32x4_g*>(ln_gamma + cc[i]);
+        be[i] = *reinterpret_cast<const f32x4_g*>(ln_beta + cc[i]);
+        bi[i] = g.bias ? f32x4_g{g.bias[cc[i]], g.bias[cc[i] + 1], g.bias[cc[i] + 2], g.bias[cc[i] + 3]} : f32x4_g{0.f, 0.f, 0.f, 0.f};
+    }
+    if (R) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[i][k] = R[(long)row * g.ldr + cc[i] + k];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[i][k] = 0.f;
+    }
+    for (int z0 = 0; z0 < splits; z0 += 4) {
+        f32x4_g t[NV][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* sp = slab + ((long)min(z0 + k, splits - 1) * g.M + row) * g.N;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t[i][k] = *reinterpret_cast<const f32x4_g*>(sp + cc[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (z0 + k < splits) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { a[i].x += t[i][k].x; a[i].y += t[i][k].y; a[i].z += t[i][k].z; a[i].w += t[i][k].w; }
+            }
+    }
+    f32x4_g v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c0 = (tid + 256 * i) * 4;
-        if (c0 < g.N) {
-            f32x4_g a{0.f, 0.f, 0.f, 0.f};
-            for (int z = 0; z < splits; ++z) {
-                const f32x4_g t = *reinterpret_cast<const f32x4_g*>(slab + ((long)z * g.M + row) * g.N + c0);
-                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-            }
-            float x[4] = {a.x, a.y, a.z, a.w};
+    for (int i = 0; i < NV; ++i) {
+        float x[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+        const float bb[4] = {bi[i].x, bi[i].y, bi[i].z, bi[i].w};
+        const bool valid = c0[i] < g.N;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int col = c0 + k;
-                float y = x[k] + (g.bias ? g.bias[col] : 0.f);
-                const bool do_act = act != ACT_NONE && col >= g.act_col_start;
-                if (do_act && !post) y = apply_act(y, act);
-                if (R) y += R[(long)row * g.ldr + col];
-                if (do_act && post) y = apply_act(y, act);
-                x[k] = y;
-                sum += y;
-            }
-            v[i] = f32x4_g{x[0], x[1], x[2], x[3]};
-            *reinterpret_cast<f32x4_g*>(C + (long)row * g.ldc + c0) = v[i];
+        for (int k = 0; k < 4; ++k) {
+            const int col = c0[i] + k;
+            float y = x[k] + bb[k];
+            const bool do_act = act != ACT_NONE && col >= g.act_col_start;
+            if (do_act && !post) y = apply_act(y, act);
+            y += rr[i][k];
+            if (do_act && post) y = apply_act(y, act);
+            x[k] = y;
+            sum += valid ? y : 0.f;
         }
+        v[i] = f32x4_g{x[0], x[1], x[2], x[3]};
+        if (valid) *reinterpret_cast<f32x4_g*>(C + (long)row * g.ldc + c0[i]) = v[i];
     }
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
@@ -785,8 +827,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
     const float mean = (red[0] + red[1] + red[2] + red[3]) / g.N;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if ((tid + 256 * i) * 4 < g.N) {
+    for (int i = 0; i < NV; ++i)
+        if (c0[i] < g.N) {
             const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
             q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
@@ -795,15 +837,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
     __syncthreads();
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / g.N + ln_eps);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c0 = (tid + 256 * i) * 4;
-        if (c0 < g.N) {
-            const f32x4_g ga = *reinterpret_cast<const f32x4_g*>(ln_gamma + c0), be = *reinterpret_cast<const f32x4_g*>(ln_beta + c0);
-            TL* o = ln_out + (long)row * ld_ln + c0;
-            stf(o + 0, (v[i].x - mean) * rstd * ga.x + be.x);
-            stf(o + 1, (v[i].y - mean) * rstd * ga.y + be.y);
-            stf(o + 2, (v[i].z - mean) * rstd * ga.z + be.z);
-            stf(o + 3, (v[i].w - mean) * rstd * ga.w + be.w);
+    for (int i = 0; i < NV; ++i) {
+        if (c0[i] < g.N) {
+            TL* o = ln_out + (long)row * ld_ln + c0[i];
+            stf(o + 0, (v[i].x - mean) * rstd * ga[i].x + be[i].x);
+            stf(o + 1, (v[i].y - mean) * rstd * ga[i].y + be[i].y);
+            stf(o + 2, (v[i].z - mean) * rstd * ga[i].z + be[i].z);
+            stf(o + 3, (v[i].w - mean) * rstd * ga[i].w + be[i].w);
         }
     }
 }
@@ -1054,12 +1094,15 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
 #undef LAUNCH_GLDS8
     if (splits > 1) {
         if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
-            if (ln->dtype == PSALM_F32)
-                hipLaunchKernelGGL((splitk_reduce_ln_kernel<float>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, ln->gamma,
-                                   ln->beta, ln->eps, (float*)ln->out, ln->ld);
-            else
-                hipLaunchKernelGGL((splitk_reduce_ln_kernel<bf16_t>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, ln->gamma,
-                                   ln->beta, ln->eps, (bf16_t*)ln->out, ln->ld);
+#define RLN_LAUNCH(TL_, NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<TL_, NV_>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
+                                                ln->gamma, ln->beta, ln->eps, (TL_*)ln->out, ln->ld)
+            const int nv = N <= 1024 ? 1 : (N <= 2048 ? 2 : (N <= 4096 ? 4 : 8));       // 4-column vectors per thread
+            if (ln->dtype == PSALM_F32) {
+                if (nv == 1) RLN_LAUNCH(float, 1); else if (nv == 2) RLN_LAUNCH(float, 2); else if (nv == 4) RLN_LAUNCH(float, 4); else RLN_LAUNCH(float, 8);
+            } else {
+                if (nv == 1) RLN_LAUNCH(bf16_t, 1); else if (nv == 2) RLN_LAUNCH(bf16_t, 2); else if (nv == 4) RLN_LAUNCH(bf16_t, 4); else RLN_LAUNCH(bf16_t, 8);
+            }
+#undef RLN_LAUNCH
             PSALM_LAUNCH_END("psalm_gemm_ln");
         }
         const long n4 = (N + 3) / 4;

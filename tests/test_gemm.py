@@ -217,7 +217,7 @@ def test_gemm_three_stage_ring(ops):
         ops.gemm_tile_policy(1282)
 
 
-@pytest.mark.parametrize("M,N,K", [(70, 256, 1024), (130, 512, 128), (200, 2048, 2048)])
+@pytest.mark.parametrize("M,N,K", [(70, 256, 1024), (130, 512, 128), (200, 2048, 2048), (40, 4096, 1024), (33, 8192, 1024), (50, 1028, 1024)])
 def test_gemm_ln_fused(ops, M, N, K):
     """psalm_gemm_ln: C = a.w^T + bias + residual (fp32) and LayerNorm(C) from one call -- fused into the split-K reduction
     when the problem is split (cases 1 and 3), a GEMM + LayerNorm launch otherwise (case 2)."""
