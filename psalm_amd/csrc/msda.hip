@@ -66,28 +66,36 @@ __device__ __forceinline__ void msda_sample(const TV* __restrict__ vbase, int Hl
 
 // 8 channels per lane (16-byte bf16 / 2 x 16-byte fp32 corner reads): half the load instructions and half the redundant
 // per-(query, head) softmax / location arithmetic of the 4-channel mapping.  Used by the fused kernel when D % 8 == 0.
+// Branch-free form: the four corner addresses are clamped into the level (always loadable) and validity (sample inside the padded
+// image, corner inside the image) is folded into the corner weights -- the arithmetic on valid corners is the expression of the
+// reference kernel (ms_deform_im2col_bilinear, ms_deform_im2col_cuda.cuh:38-89), invalid corners contribute an exact 0.  With the
+// `if (corner valid) load` form every one of the 48 corner fetches of a (query, head) compiled to its own branch + s_waitcnt vmcnt(0):
+// a chain of 48 dependent L2 round trips per lane (r01 ISA audit), which is what bounded the kernel, not bandwidth.
 template <typename TV>
-__device__ __forceinline__ void msda_sample8(const TV* __restrict__ vbase, int Hl, int Wl, int row_stride, float loc_x,
-                                             float loc_y, float wgt, float* acc) {
+struct MsdaTaps8 {
+    const TV* p[4];
+    float w[4];
+};
+template <typename TV>
+__device__ __forceinline__ MsdaTaps8<TV> msda_taps8(const TV* __restrict__ vbase, int Hl, int Wl, int row_stride, float loc_x, float loc_y) {
     const float h_im = loc_y * Hl - 0.5f;
     const float w_im = loc_x * Wl - 0.5f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        const float lh = h_im - h_low, lw = w_im - w_low;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
-        const TV* p00 = vbase + ((long)h_low * Wl + w_low) * row_stride;
-        float v1[8], v2[8], v3[8], v4[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { v1[k] = 0.f; v2[k] = 0.f; v3[k] = 0.f; v4[k] = 0.f; }
-        if (h0 && w0) ld8(p00, v1);
-        if (h0 && w1) ld8(p00 + row_stride, v2);
-        if (h1 && w0) ld8(p00 + (long)Wl * row_stride, v3);
-        if (h1 && w1) ld8(p00 + (long)(Wl + 1) * row_stride, v4);
-        const float w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += wgt * (w1c * v1[k] + w2c * v2[k] + w3c * v3[k] + w4c * v4[k]);
-    }
+    const bool inb = h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+    const int h_low = (int)floorf(inb ? h_im : 0.f), w_low = (int)floorf(inb ? w_im : 0.f);
+    const float lh = h_im - h_low, lw = w_im - w_low;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
+    const int ha = max(h_low, 0), hb = min(h_low + 1, Hl - 1), wa = max(w_low, 0), wb = min(w_low + 1, Wl - 1);
+    MsdaTaps8<TV> t;
+    t.p[0] = vbase + ((long)ha * Wl + wa) * row_stride;
+    t.p[1] = vbase + ((long)ha * Wl + wb) * row_stride;
+    t.p[2] = vbase + ((long)hb * Wl + wa) * row_stride;
+    t.p[3] = vbase + ((long)hb * Wl + wb) * row_stride;
+    t.w[0] = (inb && h0 && w0) ? hh * hw : 0.f;
+    t.w[1] = (inb && h0 && w1) ? hh * lw : 0.f;
+    t.w[2] = (inb && h1 && w0) ? lh * hw : 0.f;
+    t.w[3] = (inb && h1 && w1) ? lh * lw : 0.f;
+    return t;
 }
 
 template <typename TV, typename TO, int L, int P>
@@ -128,15 +136,31 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
         float acc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll
+        constexpr int PB = (P % 2 == 0) ? 2 : 1;                  // sampling points whose 4 * PB corner fetches are in flight together
+#pragma unroll 1                                                   // (unrolled, the tap set-up of all L*P samples is hoisted: 256 VGPRs, 1 wave/SIMD)
         for (int l = 0; l < L; ++l) {
             const TV* vl = vb + (long)lv.start[l] * row_stride;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const int i = l * P + p;
-                const float lx = ref_x + offp[2 * i] / lv.W[l];
-                const float ly = ref_y + offp[2 * i + 1] / lv.H[l];
-                msda_sample8<TV>(vl, lv.H[l], lv.W[l], row_stride, lx, ly, lg[i] * inv, acc);
+            for (int p0 = 0; p0 < P; p0 += PB) {
+                MsdaTaps8<TV> tp[PB];
+                float v[PB][4][8];
+#pragma unroll
+                for (int pp = 0; pp < PB; ++pp) {
+                    const int i = l * P + p0 + pp;
+                    const float lx = ref_x + offp[2 * i] / lv.W[l];
+                    const float ly = ref_y + offp[2 * i + 1] / lv.H[l];
+                    tp[pp] = msda_taps8<TV>(vl, lv.H[l], lv.W[l], row_stride, lx, ly);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ld8(tp[pp].p[c], v[pp][c]);
+                }
+#pragma unroll
+                for (int pp = 0; pp < PB; ++pp) {
+                    const float wgt = lg[l * P + p0 + pp] * inv;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        acc[k] += wgt * (tp[pp].w[0] * v[pp][0][k] + tp[pp].w[1] * v[pp][1][k] + tp[pp].w[2] * v[pp][2][k] +
+                                         tp[pp].w[3] * v[pp][3][k]);
+                }
             }
         }
         st8(out + (((long)b * Lq + q) * M + m) * D + g * 8, acc);
