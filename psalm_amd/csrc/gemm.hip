@@ -602,10 +602,25 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                         Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = v;
                     }
         }
+        // residual rows of all NIT store iterations fetched BEFORE the barrier (unconditional, row clamped), so their round trip
+        // overlaps the LDS transposition; inside the store loop (behind `row < M`) each one was a separate vmcnt(0) wait -- 8 (BM 128)
+        // or 4 (BM 64) dependent latencies per tile.  Only for the <= 128x128 configurations (the 256x256 kernels have no registers
+        // to spare: 253-255 VGPRs).
+        constexpr int NIT = ROWS_E / RPI;
+        constexpr bool PREF = BM * BN <= 128 * 128;
+        float rpre[PREF ? NIT : 1][8];
+        const bool use_pref = PREF && R != nullptr && !split && fa.vec_store && col0 < g.N;
+        if constexpr (PREF) {
+            if (use_pref) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    load8_f32(R + (long)min(bm + ep * ROWS_E + it * RPI + tid / TPR, g.M - 1) * g.ldr + col0, rpre[it]);
+            }
+        }
         __syncthreads();
         if (col0 >= g.N) continue;
-#pragma unroll 2
-        for (int it = 0; it < ROWS_E / RPI; ++it) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPI + tid / TPR;
             const int row = bm + ep * ROWS_E + rl;
             if (row >= g.M) break;
@@ -625,7 +640,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             }
             float rres[8];
             if (R) {
-                if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
+                if (PREF && use_pref) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) rres[c] = rpre[PREF ? it : 0][c];
+                }
+                else if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
                 else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) rres[c] = col0 + c < g.N ? ldf(R + (long)row * g.ldr + col0 + c) : 0.f;
