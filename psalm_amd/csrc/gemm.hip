@@ -593,13 +593,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        float v = acc[i][j][r];
-                        if constexpr (FP8) {                      // dequantise: per-row scale of A x per-row scale of W
-                            const int gr = min(bm + (EP == 1 ? 0 : ep * ROWS_E) + row, g.M - 1);
-                            const int gc = min(bn + wn * (BN / WN) + j * 32 + n32, g.N - 1);
-                            v *= fa.a_scale[gr] * fa.w_scale[gc];
-                        }
-                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = v;
+                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];   // (fp8: dequantised in the store loop below)
                     }
         }
         // residual rows of all NIT store iterations fetched BEFORE the barrier (unconditional, row clamped), so their round trip
@@ -607,6 +601,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // or 4 (BM 64) dependent latencies per tile.  Only for the <= 128x128 configurations (the 256x256 kernels have no registers
         // to spare: 253-255 VGPRs).
         constexpr int NIT = ROWS_E / RPI;
+        // fp8: per-row dequantisation scales -- a_scale of this thread's NIT rows and w_scale of its 8 columns, fetched once here
+        // (in the accumulator -> LDS pass they were 2 loads per accumulator element: 256 per lane, and spilled)
+        float asc[FP8 ? NIT : 1], wsc[8];
+        if constexpr (FP8) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) asc[it] = fa.a_scale[min(bm + ep * ROWS_E + it * RPI + tid / TPR, g.M - 1)];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wsc[c] = fa.w_scale[min(col0 + c, g.N - 1)];
+        }
         constexpr bool PREF = BM * BN <= 128 * 128;
         float rpre[PREF ? NIT : 1][8];
         const bool use_pref = PREF && R != nullptr && !split && fa.vec_store && col0 < g.N;
@@ -627,11 +630,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
             const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if constexpr (FP8) {                                  // dequantise: per-row scale of A x per-row scale of W
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] *= asc[FP8 ? it : 0] * wsc[c];
+            }
             if (split) {
                 float* dst = P + (long)row * g.N + col0;
                 if (fa.vec_store) {
-                    reinterpret_cast<f32x4_g*>(dst)[0] = v0;
-                    reinterpret_cast<f32x4_g*>(dst)[1] = v1;
+                    reinterpret_cast<f32x4_g*>(dst)[0] = f32x4_g{v[0], v[1], v[2], v[3]};
+                    reinterpret_cast<f32x4_g*>(dst)[1] = f32x4_g{v[4], v[5], v[6], v[7]};
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];

@@ -257,7 +257,7 @@ def test_quantize_rows_fp8_matches_torch_e4m3(ops):
 
 
 @pytest.mark.parametrize("M,N,K,cd,split", [(100, 200, 256, "bf16", False), (300, 130, 128, "f32", False), (70, 260, 2048, "f32", True),
-                                            (520, 300, 512, "bf16", False)])
+                                            (520, 300, 512, "bf16", False), (70, 256, 2048, "f32", True), (90, 512, 1024, "bf16", True)])
 def test_gemm_fp8(ops, M, N, K, cd, split):
     """e4m3 x e4m3 MFMA GEMM with per-row scales vs float64 on the de-quantised operands (exact products, fp32 accumulation)."""
     g = torch.Generator().manual_seed(M + K)
