@@ -14,8 +14,8 @@
 //   * consecutive threads walk (head, q) in the order the value/out tensors are laid out, so the
 //     output store is a dense 16 B/lane stream and neighbouring queries (neighbouring pixels) hit
 //     the same L2 lines of `value`; the whole value tensor (22 MB fp32 at 1024^2) is L2/MALL resident;
-//   * the (l,p) loop is fully unrolled for L*P <= 16 so all 4*L*P corner loads of a thread are
-//     independent and in flight together (latency hiding by ILP, ~48 loads/lane).
+//   * corner fetches are unconditional (clamped addresses, validity in the weights), so the loads of a sampling point -- and, in the
+//     8-channel kernel, of two points -- are in flight together; the rest of the latency is hidden by occupancy (4-8 waves/SIMD).
 //   * FUSED variant (used by the pixel decoder): takes the raw outputs of the fused
 //     [sampling_offsets | attention_weights] projection and computes the softmax over L*P and the
 //     sampling locations in-kernel (ops/modules/ms_deform_attn.py:101-110), so the (B,Lq,M,L,P,2)
@@ -40,28 +40,31 @@ struct MsdaLevels {
     int H[MSDA_MAX_LEVELS], W[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
 };
 
+// Branch-free: corner addresses clamped into the level (always loadable), validity of the sample / of each corner folded into the
+// corner weight (an invalid corner contributes an exact 0, as in the reference) -- a guarded `valid ? ld4(p) : 0` compiles to a branch
+// and an s_waitcnt vmcnt(0) per corner, which chains all corner fetches of a lane one after the other.
 template <typename TV>
 __device__ __forceinline__ void msda_sample(const TV* __restrict__ vbase, int Hl, int Wl, int row_stride, float loc_x,
                                             float loc_y, float wgt, f32x4_s& acc) {
     const float h_im = loc_y * Hl - 0.5f;
     const float w_im = loc_x * Wl - 0.5f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        const float lh = h_im - h_low, lw = w_im - w_low;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
-        const f32x4_s z{0.f, 0.f, 0.f, 0.f};
-        const TV* p00 = vbase + ((long)h_low * Wl + w_low) * row_stride;
-        f32x4_s v1 = (h0 && w0) ? ld4(p00) : z;
-        f32x4_s v2 = (h0 && w1) ? ld4(p00 + row_stride) : z;
-        f32x4_s v3 = (h1 && w0) ? ld4(p00 + (long)Wl * row_stride) : z;
-        f32x4_s v4 = (h1 && w1) ? ld4(p00 + (long)(Wl + 1) * row_stride) : z;
-        const float w1c = hh * hw, w2c = hh * lw, w3c = lh * hw, w4c = lh * lw;
-        acc.x += wgt * (w1c * v1.x + w2c * v2.x + w3c * v3.x + w4c * v4.x);
-        acc.y += wgt * (w1c * v1.y + w2c * v2.y + w3c * v3.y + w4c * v4.y);
-        acc.z += wgt * (w1c * v1.z + w2c * v2.z + w3c * v3.z + w4c * v4.z);
-        acc.w += wgt * (w1c * v1.w + w2c * v2.w + w3c * v3.w + w4c * v4.w);
-    }
+    const bool inb = h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+    const int h_low = (int)floorf(inb ? h_im : 0.f), w_low = (int)floorf(inb ? w_im : 0.f);
+    const float lh = h_im - h_low, lw = w_im - w_low;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
+    const int ha = max(h_low, 0), hb = min(h_low + 1, Hl - 1), wa = max(w_low, 0), wb = min(w_low + 1, Wl - 1);
+    const f32x4_s v1 = ld4(vbase + ((long)ha * Wl + wa) * row_stride);
+    const f32x4_s v2 = ld4(vbase + ((long)ha * Wl + wb) * row_stride);
+    const f32x4_s v3 = ld4(vbase + ((long)hb * Wl + wa) * row_stride);
+    const f32x4_s v4 = ld4(vbase + ((long)hb * Wl + wb) * row_stride);
+    const float w1c = (inb && h0 && w0) ? hh * hw : 0.f, w2c = (inb && h0 && w1) ? hh * lw : 0.f;
+    const float w3c = (inb && h1 && w0) ? lh * hw : 0.f, w4c = (inb && h1 && w1) ? lh * lw : 0.f;
+    const float wg = inb ? wgt : 0.f;
+    acc.x += wg * (w1c * v1.x + w2c * v2.x + w3c * v3.x + w4c * v4.x);
+    acc.y += wg * (w1c * v1.y + w2c * v2.y + w3c * v3.y + w4c * v4.y);
+    acc.z += wg * (w1c * v1.z + w2c * v2.z + w3c * v3.z + w4c * v4.z);
+    acc.w += wg * (w1c * v1.w + w2c * v2.w + w3c * v3.w + w4c * v4.w);
 }
 
 // 8 channels per lane (16-byte bf16 / 2 x 16-byte fp32 corner reads): half the load instructions and half the redundant
