@@ -596,10 +596,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                         Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];   // (fp8: dequantised in the store loop below)
                     }
         }
-        // residual rows of all NIT store iterations fetched BEFORE the barrier (unconditional, row clamped), so their round trip
-        // overlaps the LDS transposition; inside the store loop (behind `row < M`) each one was a separate vmcnt(0) wait -- 8 (BM 128)
-        // or 4 (BM 64) dependent latencies per tile.  Only for the <= 128x128 configurations (the 256x256 kernels have no registers
-        // to spare: 253-255 VGPRs).
         constexpr int NIT = ROWS_E / RPI;
         // fp8: per-row dequantisation scales -- a_scale of this thread's NIT rows and w_scale of its 8 columns, fetched once here
         // (in the accumulator -> LDS pass they were 2 loads per accumulator element: 256 per lane, and spilled)
@@ -610,29 +606,22 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
             for (int c = 0; c < 8; ++c) wsc[c] = fa.w_scale[min(col0 + c, g.N - 1)];
         }
-        constexpr bool PREF = BM * BN <= 128 * 128;
-        float rpre[PREF ? NIT : 1][8];
-        const bool use_pref = PREF && R != nullptr && !split && fa.vec_store && col0 < g.N;
-        if constexpr (PREF) {
-            if (use_pref) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it)
-                    load8_f32(R + (long)min(bm + ep * ROWS_E + it * RPI + tid / TPR, g.M - 1) * g.ldr + col0, rpre[it]);
-            }
-        }
         __syncthreads();
         if (col0 >= g.N) continue;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        // one store iteration (rows it * RPI + tid / TPR of the pass); false = past the last row of the matrix.  `itc` indexes the fp8
+        // row-scale registers and must be a compile-time constant there (fully unrolled caller); bf16 / fp32 kernels keep the compact
+        // 2x-unrolled loop (a full unroll, tried with a residual prefetch, doubles the code of every instantiation -- 2.4 -> 4.7 MB of
+        // ISA; unmeasured, and the instruction-cache footprint was judged the larger risk).
+        auto store_it = [&](int it, int itc) -> bool {
             const int rl = it * RPI + tid / TPR;
             const int row = bm + ep * ROWS_E + rl;
-            if (row >= g.M) break;
+            if (row >= g.M) return false;
             const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
             const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if constexpr (FP8) {                                  // dequantise: per-row scale of A x per-row scale of W
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] *= asc[FP8 ? it : 0] * wsc[c];
+                for (int c = 0; c < 8; ++c) v[c] *= asc[itc] * wsc[c];
             }
             if (split) {
                 float* dst = P + (long)row * g.N + col0;
@@ -643,15 +632,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];
                 }
-                continue;
+                return true;
             }
             float rres[8];
             if (R) {
-                if (PREF && use_pref) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) rres[c] = rpre[PREF ? it : 0][c];
-                }
-                else if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
+                if (fa.vec_store) load8_f32(R + (long)row * g.ldr + col0, rres);
                 else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) rres[c] = col0 + c < g.N ? ldf(R + (long)row * g.ldr + col0 + c) : 0.f;
@@ -673,6 +658,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                 for (int c = 0; c < 8; ++c) if (col0 + c < g.N) stf(dst + c, v[c]);
             }
+            return true;
+        };
+        if constexpr (FP8) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (!store_it(it, it)) break;
+        } else {
+#pragma unroll 2
+            for (int it = 0; it < NIT; ++it)
+                if (!store_it(it, 0)) break;
         }
     }
 }
