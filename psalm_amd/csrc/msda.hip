@@ -142,7 +142,15 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
         constexpr int PB = (P % 2 == 0) ? 2 : 1;                  // sampling points whose 4 * PB corner fetches are in flight together
 #pragma unroll 1                                                   // (unrolled, the tap set-up of all L*P samples is hoisted: 256 VGPRs, 1 wave/SIMD)
         for (int l = 0; l < L; ++l) {
-            const TV* vl = vb + (long)lv.start[l] * row_stride;
+            // The level table is read with CONSTANT kernarg offsets and selected on `l`: indexing the by-value struct with the
+            // rolled loop counter compiled (ROCm 7.2, gfx950) to `s_load_dword sX, s[base+3+4l], 0x1d` -- an unaligned SGPR base
+            // plus an unaligned immediate; the scalar memory unit drops the low two bits of each separately, so W[l] / start[l]
+            // came back from the wrong slot (garbage geometry -> wild corner addresses -> GPU memory fault, r01 round end).
+            int Hl = lv.H[0], Wl = lv.W[0], sl = lv.start[0];
+#pragma unroll
+            for (int j = 1; j < L; ++j)
+                if (l == j) { Hl = lv.H[j]; Wl = lv.W[j]; sl = lv.start[j]; }
+            const TV* vl = vb + (long)sl * row_stride;
 #pragma unroll
             for (int p0 = 0; p0 < P; p0 += PB) {
                 MsdaTaps8<TV> tp[PB];
@@ -150,9 +158,9 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
 #pragma unroll
                 for (int pp = 0; pp < PB; ++pp) {
                     const int i = l * P + p0 + pp;
-                    const float lx = ref_x + offp[2 * i] / lv.W[l];
-                    const float ly = ref_y + offp[2 * i + 1] / lv.H[l];
-                    tp[pp] = msda_taps8<TV>(vl, lv.H[l], lv.W[l], row_stride, lx, ly);
+                    const float lx = ref_x + offp[2 * i] / Wl;
+                    const float ly = ref_y + offp[2 * i + 1] / Hl;
+                    tp[pp] = msda_taps8<TV>(vl, Hl, Wl, row_stride, lx, ly);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) ld8(tp[pp].p[c], v[pp][c]);
                 }
@@ -272,7 +280,7 @@ extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int6
                                   const int64_t* level_start_host, const float* sampling_loc, const float* attn_weight,
                                   void* out, int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream) {
     PSALM_CHECK_ARG(D % 4 == 0 && D > 0, "psalm_msda_forward: head dim must be a multiple of 4");
-    MsdaLevels lv;
+    MsdaLevels lv = {};
     int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
     PSALM_CHECK_ARG(rc != -1, "psalm_msda_forward: too many levels (max 8)");
     PSALM_CHECK_ARG(rc == 0, "psalm_msda_forward: sum(H_l*W_l) != S");
@@ -292,7 +300,7 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
                                 int B, int S, int M, int D, int L, int P, void* stream) {
     PSALM_CHECK_ARG(D % 4 == 0 && D > 0, "psalm_msda_fused: head dim must be a multiple of 4");
     PSALM_CHECK_ARG(L == 3 && P == 4, "psalm_msda_fused: specialised for L=3 levels, P=4 points (PSALM pixel decoder)");
-    MsdaLevels lv;
+    MsdaLevels lv = {};
     int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
     PSALM_CHECK_ARG(rc == 0, "psalm_msda_fused: bad level table");
     const int block = 256;

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 from typing import Optional, Sequence
 
@@ -24,6 +25,9 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_NEW = 0, 1, 2, 3
 ACT_POST_RESIDUAL = 16
 ACT_BIAS_ROW = 32
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+_DEBUG_SYNC = os.environ.get("PSALM_DEBUG_SYNC", "0") not in ("", "0")
 
 
 class PsalmHipError(RuntimeError):
@@ -53,6 +57,15 @@ class _ProfiledLib:
 
         def call(*args):
             rec = self.records
+            if _DEBUG_SYNC:
+                # PSALM_DEBUG_SYNC=1: name every launch before it is issued and synchronise after it, so that a GPU memory
+                # fault (which aborts the process asynchronously) is attributable: the last "launch" line without "ok".
+                sys.stderr.write(f"[psalm launch] {name}\n"); sys.stderr.flush()
+                rc = fn(*args)
+                if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()
+                sys.stderr.write(f"[psalm ok] {name}\n"); sys.stderr.flush()
+                return rc
             if rec is None:
                 return fn(*args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
