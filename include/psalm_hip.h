@@ -86,6 +86,18 @@ int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, const void* W
 int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* Wt, int Cout, int ksize, int stride, int pad,
                       const float* bias, const void* residual, long ldr, void* out, int c_dtype, long ldc, int act,
                       const void* zeros, void* workspace, long workspace_bytes, void* stream);
+/* Split-f16 ("X3") fp32-class GEMM on the f16 matrix cores -- the arithmetic of precision="f16x3", the mode that meets the reference's
+ * fp32 results (torch fp32 nn.Linear / F.conv2d / einsum on the CPU path: llava_phi.py:1350-1398 and everything below it) to the north
+ * star's tolerance at ~1/3 of the f16 MFMA rate instead of the fp32 MFMA's 1/16.
+ * psalm_split_f16: x (rows,K) f32 -> out (rows, 2*Kp) f16 = [hi | lo], Kp = ceil64(K), x*s = hi + lo with s a per-row power of two
+ *   (row max in [2^13,2^14)); inv_scale[row] = 1/s.   K % 8 == 0, 16-byte aligned rows.
+ * psalm_gemm_x3: C = act(A.W^T + bias) + residual, C / residual fp32, from split operands A2 (M,2Kp) / W2 (N,2Kp) + their scales:
+ *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo, fp32 accumulate, scales in the epilogue; tiles / split-K as psalm_gemm. */
+int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream);
+int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                  const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
+                  void* workspace, long workspace_bytes, void* stream);
+
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;

@@ -34,6 +34,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct alignas(16) u32x4_s { unsigned x, y, z, w; };
 struct alignas(16) f32x4_g { float x, y, z, w; };
 
@@ -250,6 +251,9 @@ struct GemmFastArgs {
     // fp8 (OCP e4m3) operands (FP8 kernels): per-row dequantisation scales of A (M) and W (N); acc * a_scale[m] * w_scale[n]
     const float* a_scale;
     const float* w_scale;
+    // split-f16 ("X3") operands: A / W rows are [hi (Kp) | lo (Kp)] f16 (psalm_split_f16); the K loop runs over the 3 Kp-long products
+    // hi.hi + lo.hi + hi.lo, i.e. logical k in [0, 3Kp) reads A column (k < 2Kp ? k : k - 2Kp) and W column (k < Kp ? k : k - Kp)
+    int x3_kp;
 };
 
 // Tile configurations (BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32x16 MFMA tiles):
@@ -281,9 +285,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // PH8 = true (256 x 256, 2 x 4 waves, BK 64, 2 buffers): the K loop below is replaced by the 4-phases-per-K-tile schedule
 // described at "PH8 schedule" further down -- the two wave rows run one barrier interval apart, so that on every SIMD one wave
 // is in a pure-MFMA segment while its partner reads fragments / issues copies, and copies stay in flight across barriers.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0>
+// X3 = true: split-f16 operands (see GemmFastArgs::x3_kp): same 16-bit element traffic, copies and swizzle as the bf16 kernel; the K-tile
+// source columns are remapped, the matrix instruction is v_mfma_f32_32x32x16_f16 and the epilogue applies the per-row power-of-two
+// scales of A and W (as the fp8 variant does).  An fp32-class GEMM (22-bit operands, fp32 accumulate) at 1/3 of the f16 MFMA rate.
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, bool X3 = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV && !FP8), "PH8 configuration");
+    static_assert(!X3 || (BK == 64 && !CONV && !FP8), "split-f16 variant: 64-deep K tiles, plain GEMM");
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             asrc[i] = A + (long)b * fa.cH * fa.cW * fa.cC + kc * 8;           // + ((y*W + x)*C + c0) per K tile
         } else {
             ay[i] = ax[i] = 0;
-            asrc[i] = A + (long)m * g.lda + kbeg + kc * 8;
+            asrc[i] = A + (long)m * g.lda + (X3 ? 0 : kbeg) + kc * 8;
         }
     }
     // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
@@ -342,8 +350,21 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int i = 0; i < B_CH; ++i) {
         const int r = b_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
-        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + kbeg + kc * 8;
+        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + (X3 ? 0 : kbeg) + kc * 8;
     }
+    // operand column of the K tile at offset koff of this block's K range (identity except for the split-f16 variant)
+    auto x3_acol = [&](int koff) -> int {
+        if constexpr (X3) { const int k = kbeg + koff; return k < 2 * fa.x3_kp ? k : k - 2 * fa.x3_kp; }
+        else return koff;
+    };
+    auto x3_wcol = [&](int koff) -> int {
+        if constexpr (X3) { const int k = kbeg + koff; return k < fa.x3_kp ? k : k - fa.x3_kp; }
+        else return koff;
+    };
+    auto mma16 = [&](const bf16x8& a_, const bf16x8& b_, const f32x16& c_) -> f32x16 {
+        if constexpr (X3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0);
+    };
     auto issue = [&](int buf, int koff) {
         bf16_t* As = smem[buf];
         bf16_t* Bs = smem[buf] + BM * BK;
@@ -358,11 +379,13 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 psalm_glds16(src, As + (wave + NW * i) * RPC * BK);
             }
         } else {
+            const int ka = x3_acol(koff);
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + koff, As + (wave + NW * i) * RPC * BK);
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + ka, As + (wave + NW * i) * RPC * BK);
         }
+        const int kw = x3_wcol(koff);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + koff, Bs + b_chunk(i) * RPC * BK);
+        for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + kw, Bs + b_chunk(i) * RPC * BK);
     };
 
     f32x16 acc[TM][TN];
@@ -417,13 +440,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // half-tile copies: which = 0 / 1 selects one of the wave's two 1 KiB copies, 2 = both
         auto stage_a = [&](int buf, int koff, int q, int which = 2) {   // A-half q of tile (koff / BK) -> buffer buf
             bf16_t* As_ = smem[buf];
-            if (which != 1) psalm_glds16(asrc[q] + koff, As_ + (wave + NW * q) * RPC * BK);
-            if (which != 0) psalm_glds16(asrc[q + 2] + koff, As_ + (wave + NW * (q + 2)) * RPC * BK);
+            const int ka = x3_acol(koff);
+            if (which != 1) psalm_glds16(asrc[q] + ka, As_ + (wave + NW * q) * RPC * BK);
+            if (which != 0) psalm_glds16(asrc[q + 2] + ka, As_ + (wave + NW * (q + 2)) * RPC * BK);
         };
         auto stage_b = [&](int buf, int koff, int j, int which = 2) {   // B-half j
             bf16_t* Bs_ = smem[buf] + BM * BK;
-            if (which != 1) psalm_glds16(bsrc[2 * j] + koff, Bs_ + b_chunk(2 * j) * RPC * BK);
-            if (which != 0) psalm_glds16(bsrc[2 * j + 1] + koff, Bs_ + b_chunk(2 * j + 1) * RPC * BK);
+            const int kw = x3_wcol(koff);
+            if (which != 1) psalm_glds16(bsrc[2 * j] + kw, Bs_ + b_chunk(2 * j) * RPC * BK);
+            if (which != 0) psalm_glds16(bsrc[2 * j + 1] + kw, Bs_ + b_chunk(2 * j + 1) * RPC * BK);
         };
         // PH8 == 2: the phase's two copies are issued INSIDE the MFMA segment (after the 2nd and the 6th MFMA: the matrix pipe is
         // busy with the MFMA just issued while the copy is accepted), not in the read segment -- r01 PMC: the copies' issue stalls
@@ -433,7 +458,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             for (int kk = 0; kk < BK / 16; ++kk) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    acc[2 * q + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq[kk], acc[2 * q + i][j], 0, 0, 0);
+                    acc[2 * q + i][j] = mma16(af[i][kk], bq[kk], acc[2 * q + i][j]);
                 if (PH8 >= 2 && (kk == 0 || kk == 2)) {
                     __builtin_amdgcn_sched_barrier(0);
                     copy(kk >> 1);
@@ -556,7 +581,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j]);
         }
     }
     }
@@ -599,8 +624,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         constexpr int NIT = ROWS_E / RPI;
         // fp8: per-row dequantisation scales -- a_scale of this thread's NIT rows and w_scale of its 8 columns, fetched once here
         // (in the accumulator -> LDS pass they were 2 loads per accumulator element: 256 per lane, and spilled)
-        float asc[FP8 ? NIT : 1], wsc[8];
-        if constexpr (FP8) {
+        float asc[(FP8 || X3) ? NIT : 1], wsc[8];
+        if constexpr (FP8 || X3) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) asc[it] = fa.a_scale[min(bm + ep * ROWS_E + it * RPI + tid / TPR, g.M - 1)];
 #pragma unroll
@@ -619,7 +644,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
             const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if constexpr (FP8) {                                  // dequantise: per-row scale of A x per-row scale of W
+            if constexpr (FP8 || X3) {                            // dequantise: per-row scale of A x per-row scale of W
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] *= asc[itc] * wsc[c];
             }
@@ -660,7 +685,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             }
             return true;
         };
-        if constexpr (FP8) {
+        if constexpr (FP8 || X3) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (!store_it(it, it)) break;
@@ -678,8 +703,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 // for 4 blocks of work); this one has NO staging and NO K-loop barrier: a block owns one 32x32 output tile, its 4 wavefronts
 // split K four ways, every lane pulls its MFMA fragments straight from global / L2 with 16-byte loads (all loads of a chunk in
 // flight together), the 4 partial tiles meet once in LDS, and the epilogue is applied from registers.
-template <typename TC>
-__global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g) {
+// X3 = true: split-f16 operands ([hi | lo] f16 rows of 2 kp columns, per-row scales; see GemmFastArgs::x3_kp): g.K = 3 kp.
+struct SkinnyX3 { const float* a_scale; const float* w_scale; int kp; };
+template <typename TC, bool X3 = false>
+__global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g, SkinnyX3 x3) {
     __shared__ float part[3][32 * 32];                           // partial tiles of waves 1..3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
     const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
@@ -699,13 +726,20 @@ __global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g) {
         u32x4_s fa_[CH], fb_[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            fa_[i] = *reinterpret_cast<const u32x4_s*>(A + (long)(k0 + kb + i) * 16);
-            fb_[i] = *reinterpret_cast<const u32x4_s*>(W + (long)(k0 + kb + i) * 16);
+            long ka = (long)(k0 + kb + i) * 16, kw = ka;
+            if constexpr (X3) {                                  // 16-deep k-step -> operand columns (kp % 64 == 0: never straddles)
+                if (ka >= 2 * x3.kp) ka -= 2 * x3.kp;
+                if (kw >= x3.kp) kw -= x3.kp;
+            }
+            fa_[i] = *reinterpret_cast<const u32x4_s*>(A + ka);
+            fb_[i] = *reinterpret_cast<const u32x4_s*>(W + kw);
         }
         __builtin_amdgcn_sched_barrier(0);                       // all 2 CH loads issued before the first MFMA waits on one
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]), __builtin_bit_cast(bf16x8, fb_[i]), acc, 0, 0, 0);
+        for (int i = 0; i < CH; ++i) {
+            if constexpr (X3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa_[i]), __builtin_bit_cast(f16x8, fb_[i]), acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]), __builtin_bit_cast(bf16x8, fb_[i]), acc, 0, 0, 0);
+        }
         kb += CH;
     };
     while (kb + 8 <= per) chunk(std::integral_constant<int, 8>{});
@@ -719,6 +753,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_skinny_kernel(GemmArgs g) {
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += part[0][r * 64 + lane] + part[1][r * 64 + lane] + part[2][r * 64 + lane];
+        if constexpr (X3) {                                      // per-row scales of A (this lane's 16 rows) and W (its column)
+            const float ws = x3.w_scale[min(bn + n32, g.N - 1)];
+            float as_[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) as_[r] = x3.a_scale[min(bm + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= as_[r] * ws;
+        }
         epilogue_store<TC>(g, acc, bm, bn + n32, lane);
     }
 }
@@ -1034,7 +1076,7 @@ extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, in
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 
 static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s,
-                       const LnEpilogue* ln = nullptr, bool fp8 = false) {
+                       const LnEpilogue* ln = nullptr, bool fp8 = false, bool x3 = false) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
@@ -1071,7 +1113,16 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
-    if (fp8) {
+    if (x3) {                                                     // split-f16 variant: fp32 output (or fp32 split-K slabs) only
+#define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_) \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
+        if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
+        else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
+        else if (BM == 128) LAUNCH_X3(128, 128, 2, 2, 2, 0);
+        else if ((g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2)) >= 3) LAUNCH_X3(64, 128, 2, 2, 3, 0);
+        else LAUNCH_X3(64, 128, 2, 2, 2, 0);
+#undef LAUNCH_X3
+    } else if (fp8) {
         if (BM == 256) LAUNCH_GLDS8(256, 256, 2, 4);
         else if (BM == 128) LAUNCH_GLDS8(128, 128, 2, 2);
         else LAUNCH_GLDS8(64, 128, 2, 2);
@@ -1161,6 +1212,7 @@ extern "C" int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, co
     fa.cH = H; fa.cW = W; fa.cC = Cin; fa.cK = ksize; fa.cS = stride; fa.cP = pad; fa.cHo = Ho; fa.cWo = Wo;
     fa.zeros = (const bf16_t*)zeros;
     fa.a_scale = fa.w_scale = nullptr;
+    fa.x3_kp = 0;
     return launch_fast(g, fa, true, c_dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1189,8 +1241,8 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         // ---- skinny path: latency-bound GEMMs of the predictor (measured r1x: ~3 us vs ~10 us per launch)
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
-        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g);
+        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float>), grid, dim3(256), 0, s, g, SkinnyX3{nullptr, nullptr, 0});
+        else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g, SkinnyX3{nullptr, nullptr, 0});
         PSALM_LAUNCH_END("psalm_gemm");
     }
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
@@ -1199,6 +1251,7 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
         fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
         fa.zeros = nullptr;
         fa.a_scale = fa.w_scale = nullptr;
+    fa.x3_kp = 0;
         return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, s);
     }
 
@@ -1259,6 +1312,7 @@ extern "C" int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W
     fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
     fa.zeros = nullptr;
     fa.a_scale = fa.w_scale = nullptr;
+    fa.x3_kp = 0;
     LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, ln_dtype, ld_ln};
     return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, &ln);
 }
@@ -1331,5 +1385,103 @@ extern "C" int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, co
     fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
     fa.zeros = nullptr;
     fa.a_scale = a_scale; fa.w_scale = w_scale;
+    fa.x3_kp = 0;
     return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, nullptr, true);
+}
+
+// ------------------------------------------------------------------------------------------- split-f16 ("X3") path
+// fp32-class GEMMs on the f16 matrix cores.  Plain bf16 operands (8 mantissa bits) cannot meet the reference's fp32 results to the
+// north star's tolerance (mask IoU within 1e-3, identical labels): the masked-attention feedback of the mask decoder
+// (mask2former_transformer_decoder.py:754-760, `sigmoid(mask) < 0.5` decides which keys a query may see) turns operand rounding into
+// label flips; an operand-mantissa sweep on MI355X (tools/exp_bits.py, profiles/r02b_*) puts the threshold between 15 and 17 bits.
+// A 22-bit operand is carried as TWO f16 values:  x * s = hi + lo,  hi = f16(x s),  lo = f16(x s - hi)  (both conversions round to
+// nearest even; the subtraction is exact in fp32), with one power-of-two scale s per row that places the row's absolute maximum in
+// [2^13, 2^14) -- inside f16's range with headroom, and small elements lose nothing that matters: lo goes subnormal only for
+// |x| < 2^-16 amax, an absolute error below 2^-38 amax.  The product  A . W^T = sa sw (Ahi.Whi + Alo.Whi + Ahi.Wlo) + O(2^-22)
+// is then ONE f16 GEMM over a 3x longer K panel, accumulated in fp32 by the MFMA, with the scales applied in the epilogue.
+//
+// psalm_split_f16: x (rows, K) f32, row stride ldx  ->  out (rows, 2 Kp) f16 = [hi (Kp) | lo (Kp)], Kp = K rounded up to 64 (pad
+// columns zero), row stride ldo (elements), and inv_scale (rows) = 1 / s (a power of two; 1 for an all-zero row).  One wavefront / row.
+__global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
+                                                        float* __restrict__ inv_scale, int rows, int K, int Kp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float amax = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        float v[8];
+        load8_f32(xr + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+    }
+    amax = wave_max(amax);
+    // s = 2^(13 - floor(log2 amax)), exponent clamped so that s and 1/s stay normal fp32 numbers
+    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);        // all-zero (or non-finite) row: leave it unscaled
+    const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+    if (lane == 0) inv_scale[row] = inv;
+    unsigned short* orow = out + row * ldo;
+    for (int c = lane * 8; c < Kp; c += 512) {
+        float v[8];
+        if (c < K) load8_f32(xr + c, v);                         // K % 8 == 0: a vector is entirely inside or outside the row
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = v[2 * k] * sc, a1 = v[2 * k + 1] * sc;
+            const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+            const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+            hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        *reinterpret_cast<u32x4_s*>(orow + c) = u32x4_s{hw[0], hw[1], hw[2], hw[3]};
+        *reinterpret_cast<u32x4_s*>(orow + Kp + c) = u32x4_s{lw[0], lw[1], lw[2], lw[3]};
+    }
+}
+
+extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream) {
+    if (rows == 0) return 0;
+    const int Kp = (K + 63) / 64 * 64;
+    PSALM_CHECK_ARG(K > 0 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0, "psalm_split_f16: K % 8 == 0, 16-byte aligned input rows");
+    PSALM_CHECK_ARG((uintptr_t)out % 16 == 0 && (ldo * 2) % 16 == 0 && ldo >= 2L * Kp, "psalm_split_f16: output rows of >= 2*ceil64(K) f16, 16-byte aligned");
+    hipLaunchKernelGGL(split_f16_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)out, ldo,
+                       inv_scale, rows, K, Kp);
+    PSALM_LAUNCH_END("psalm_split_f16");
+}
+
+// C = act((A . W^T) + bias) + residual from split-f16 operands:  A2 (M, 2 Kp) / W2 (N, 2 Kp) f16 [hi | lo] with row strides lda / ldw
+// (elements) and per-row scales a_scale (M) / w_scale (N) as written by psalm_split_f16;  Kp % 64 == 0.  C / residual fp32.
+// Same tile selection, split-K and epilogue as psalm_gemm (on a K range of 3 Kp); M <= 128 problems take the skinny kernel.
+extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                             const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
+                             int act_col_start, void* workspace, long workspace_bytes, void* stream) {
+    if (M == 0 || N == 0) return 0;
+    PSALM_CHECK_ARG(Kp > 0 && Kp % 64 == 0, "psalm_gemm_x3: Kp must be a positive multiple of 64");
+    PSALM_CHECK_ARG((uintptr_t)A2 % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)W2 % 16 == 0 && (ldw * 2) % 16 == 0 && lda >= 2L * Kp && ldw >= 2L * Kp,
+                    "psalm_gemm_x3: 16-byte aligned operand rows of >= 2*Kp f16");
+    PSALM_CHECK_ARG(a_scale && w_scale, "psalm_gemm_x3: scales required");
+    GemmArgs g;
+    g.A = A2; g.W = W2; g.bias = bias; g.res = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = 3 * Kp; g.act = act; g.act_col_start = act_col_start;
+    g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+        const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
+        PSALM_LAUNCH_END("psalm_gemm_x3");
+    }
+    GemmFastArgs fa;
+    fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
+    fa.zeros = nullptr;
+    fa.a_scale = a_scale; fa.w_scale = w_scale;
+    fa.x3_kp = Kp;
+    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, nullptr, false, true);
 }

@@ -24,6 +24,16 @@ def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple
     t0 = time.perf_counter()
     total = 0
     by_dtype = {}
+    W = {}                                   # flat name -> tensor view of the prepared weights (split-f16 weights = two tensors)
+    for k, v in model.w.items():
+        if hasattr(v, "inv_scale"):          # hip_ops.SplitF16 (precision="f16x3")
+            W[k + "#f16"], W[k + "#inv_scale"] = v.t, v.inv_scale
+        else:
+            W[k] = v
+
+    class _M:                                # the bucket code below reads `model.w[k]`
+        w = W
+    model = _M
     for k in sorted(model.w):
         by_dtype.setdefault(model.w[k].dtype, []).append(k)
     for dt, keys in by_dtype.items():

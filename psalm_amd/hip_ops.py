@@ -83,6 +83,23 @@ class _ProfiledLib:
             setattr(self._cdll, k, v)
 
 
+class SplitF16:
+    """A matrix in split-f16 form (psalm_split_f16): `t` (rows, 2*Kp) float16 = [hi | lo], `inv_scale` (rows,) float32, logical
+    shape (rows, K).  Either operand of `Ops.gemm` may be one; in the "f16x3" mode GEMM weights are kept in this form."""
+    __slots__ = ("t", "inv_scale", "K", "Kp")
+
+    def __init__(self, t, inv_scale, K):
+        self.t, self.inv_scale, self.K, self.Kp = t, inv_scale, K, t.shape[1] // 2
+
+    @property
+    def shape(self):
+        return (self.t.shape[0], self.K)
+
+    @property
+    def dtype(self):
+        return torch.float32                      # the values it stands for
+
+
 class Ops:
     def __init__(self, lib_path: str = DEFAULT_LIB):
         if not os.path.exists(lib_path):
@@ -99,6 +116,7 @@ class Ops:
         self.device = torch.device("cpu") if self.is_emu else torch.device("cuda", torch.cuda.current_device())
         self.lib_path = lib_path
         self._ws = {}                      # cached kernel workspaces (device buffers owned by this binding)
+        self.x3 = False                    # True: float32 x float32 GEMMs run in split-f16 arithmetic (precision="f16x3")
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -152,6 +170,8 @@ class Ops:
         """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  `a`, `out`, `residual` may be row-strided 2-D views
         (last dim contiguous).  w.dtype selects the arithmetic: bfloat16 -> bf16 MFMA / fp32 accumulate,
         float32 -> exact fp32 MFMA."""
+        if isinstance(a, SplitF16) or isinstance(w, SplitF16) or (self.x3 and a.dtype == torch.float32 and w.dtype == torch.float32):
+            return self.gemm_x3(a, w, bias, residual, act, act_col_start, out, out_dtype)
         if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1]:
             raise PsalmHipError(f"gemm shape mismatch {tuple(a.shape)} x {tuple(w.shape)}")
         M, K = a.shape
@@ -170,6 +190,42 @@ class Ops:
                                  self._pv(out), _dt(out), c_long(out.stride(0)), M, N, K, act, act_col_start,
                                  self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm")
+        return out
+
+    def split_f16(self, x):
+        """x (rows,K) float32 (row-strided view) -> SplitF16: x * s = hi + lo in float16 with a per-row power-of-two scale."""
+        if isinstance(x, SplitF16):
+            return x
+        if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+            raise PsalmHipError("split_f16: 2-D float32 input with a contiguous last dimension")
+        rows, K = x.shape
+        Kp = (K + 63) // 64 * 64
+        t = self.empty(rows, 2 * Kp, dtype=torch.float16)
+        inv = self.empty(rows, dtype=torch.float32)
+        rc = self.lib.psalm_split_f16(self._pv(x), c_long(x.stride(0)), self._p(t), c_long(2 * Kp), self._p(inv), rows, K, self._stream())
+        self._check(rc, "psalm_split_f16")
+        return SplitF16(t, inv, K)
+
+    def gemm_x3(self, a, w, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=None):
+        """gemm() on split-f16 operands (float32 tensors are split on the fly): fp32-class result on the f16 matrix cores."""
+        a, w = self.split_f16(a), self.split_f16(w)
+        if a.K != w.K:
+            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        M, N = a.t.shape[0], w.t.shape[0]
+        if out is None:
+            if out_dtype not in (None, torch.float32):
+                raise PsalmHipError("gemm_x3: float32 output only")
+            out = self.empty(M, N, dtype=torch.float32)
+        for t in (out,) + ((residual,) if residual is not None else ()):
+            if t.dtype != torch.float32 or t.stride(-1) != 1 or tuple(t.shape) != (M, N):
+                raise PsalmHipError("gemm_x3: float32 (M,N) output / residual with a contiguous last dimension")
+        if bias is not None and (bias.dtype != torch.float32 or bias.numel() != (M if act & ACT_BIAS_ROW else N)):
+            raise PsalmHipError("gemm bias must be float32 (N,) -- or (M,) with ACT_BIAS_ROW")
+        rc = self.lib.psalm_gemm_x3(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
+                                    self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
+                                    c_long(residual.stride(0) if residual is not None else 0), self._pv(out), c_long(out.stride(0)),
+                                    M, N, act, act_col_start, self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_gemm_x3")
         return out
 
     def gemm_ln(self, a, w, bias, residual, gamma, beta, eps=1e-5, ln_dtype=torch.bfloat16, act=ACT_NONE):

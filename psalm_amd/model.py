@@ -12,6 +12,12 @@ Precision modes
             residual streams, LayerNorm/GroupNorm/softmax statistics, sampling offsets, mask and class logits fp32.
     "fp32": weights and activations fp32, GEMMs on the exact fp32 MFMA -- structural parity mode against the fp32
             CPU reference (differences are summation-order round-off only).
+    "f16x3": the qualifying fast mode.  "fp32" with every GEMM in split-f16 arithmetic (psalm_split_f16 / psalm_gemm_x3): each fp32
+            operand is carried as two f16 values (22 mantissa bits, per-row power-of-two scale) and the product is one f16 MFMA GEMM
+            over the 3x longer panel hi.hi + lo.hi + hi.lo with fp32 accumulation.  bf16 operands do NOT meet the north star's parity
+            bar on this network (the mask decoder's thresholded attention-mask feedback amplifies operand rounding into label flips;
+            measured threshold between 15 and 17 operand bits, tools/exp_bits.py); this mode does, at 3 f16 MFMA passes instead of
+            the fp32 MFMA's 16x lower rate.  Activations, norms, softmax and the attention kernels are those of "fp32".
     "fp8" : "bf16" with the Phi projections (q/k/v/fc1 and dense/fc2, 88 % of the model's FLOPs) on v_mfma_f32_32x32x16_fp8_fp8:
             OCP e4m3fn weights with per-output-row scales (quantised once), activations quantised per token row on the fly
             (BASELINE.json configs[4]; an extension -- the reference has no fp8 path).
@@ -77,13 +83,14 @@ def default_region_point_sampler(nonzero: torch.Tensor, n: int) -> torch.Tensor:
 class PSALM:
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
                  precision: str = "bf16", use_graphs: bool = False):
-        if precision not in ("bf16", "fp32", "fp8"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+        if precision not in ("bf16", "fp32", "fp8", "f16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3' or 'fp8'")
         self.cfg = cfg
         self.ops = ops if ops is not None else H.get_ops()        # raises without GPU + libpsalm_hip.so
         self.precision = precision
         self.llm_fp8 = precision == "fp8"             # Phi projections on e4m3 MFMA (per-row scales); everything else as "bf16"
-        self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16   # weight / GEMM-operand dtype
+        self.x3 = precision == "f16x3"                # fp32 activations, GEMM operands in split-f16 form (hip_ops.SplitF16)
+        self.wdt = torch.float32 if precision in ("fp32", "f16x3") else torch.bfloat16   # weight / GEMM-operand dtype
         self.fuse_heads = False                                               # see predictor()
         self.adt = self.wdt                                                     # GEMM-feeding activation dtype
         self.device = self.ops.device
@@ -106,7 +113,11 @@ class PSALM:
         return t if t.data_ptr() % 16 == 0 else t.clone()
 
     def _W(self, t):                      # GEMM weight
-        return self._aligned(t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device))
+        t = self._aligned(t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device))
+        return self.ops.split_f16(t) if self.x3 else t      # f16x3: split once at load time ([hi | lo] f16 + per-row scales)
+
+    def _wop(self, t):                    # an ACTIVATION used as the W operand of a GEMM (mask features, class embeddings, ...)
+        return self.ops.split_f16(t) if self.x3 and t is not None else t
 
     def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
         return self._aligned(t.detach().to(torch.float32).contiguous().to(self.device))
@@ -126,7 +137,7 @@ class PSALM:
 
         # ---- Phi decoder.  Fused GEMM 1 rows: [k | v | q | fc1]  (attention output later overwrites the q columns, so
         # [attn | gelu(fc1)] is one contiguous K panel for fused GEMM 2 = [dense | fc2] with the two biases summed).
-        w["embed"] = Fp(sd["model.embed_tokens.weight"]) if self.precision == "fp32" else \
+        w["embed"] = Fp(sd["model.embed_tokens.weight"]) if self.wdt == torch.float32 else \
             sd["model.embed_tokens.weight"].detach().to(torch.bfloat16).to(self.device)
         w["seg_query"] = Fp(sd["seg_query"])
         for i in range(cfg.num_layers):
@@ -146,7 +157,7 @@ class PSALM:
                 w[f"llm{i}.w2"] = W(w2)
             w[f"llm{i}.b1"] = Fp(torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"],
                                             sd[p + "mlp.fc1.bias"]], 0))
-            w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"] + sd[p + "mlp.fc2.bias"])
+            w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"].float() + sd[p + "mlp.fc2.bias"].float())
             norm(f"llm{i}.ln", p + "input_layernorm")
         norm("llm.final", "model.final_layernorm")
 
@@ -177,10 +188,10 @@ class PSALM:
         # ---- projector (BasicBlock with eval BatchNorm folded; conv weights to (Cout, ky, kx, Cin))
         pj = "model.mm_projector.layer1.0."
 
-        def bn_fold(conv_w, bn):
-            scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
-            shift = sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale
-            return conv_w * scale.view(-1, 1, 1, 1), shift
+        def bn_fold(conv_w, bn):                       # in fp32 whatever the checkpoint dtype (bf16 would lose the 1e-5 eps)
+            scale = sd[bn + ".weight"].float() / torch.sqrt(sd[bn + ".running_var"].float() + 1e-5)
+            shift = sd[bn + ".bias"].float() - sd[bn + ".running_mean"].float() * scale
+            return conv_w.float() * scale.view(-1, 1, 1, 1), shift
 
         def conv_mat(cw):
             return cw.permute(0, 2, 3, 1).reshape(cw.shape[0], -1)
@@ -585,6 +596,8 @@ class PSALM:
         fused_head = self.fuse_heads and self.adt == torch.bfloat16 and self.wdt == torch.bfloat16 and D in (64, 128, 256)
         fused_tail = mfma and fused_head and D <= 512
 
+        mf_w = self._wop(mf)                                        # f16x3: the mask features are split once for the 10 head passes
+
         def mask_head(out):
             if fused_head:                                          # decoder_norm + the 3 mask_embed layers in one launch (10x per image)
                 dec, me = o.ln_mlp3(out, w["pr.dn.g"], w["pr.dn.b"], [w[f"pr.mask_embed{j}.w"] for j in range(3)],
@@ -592,7 +605,7 @@ class PSALM:
             else:
                 dec = o.layernorm(out, w["pr.dn.g"], w["pr.dn.b"], out_dtype=self.adt)
                 me = mlp(dec, "mask_embed", 3, self.adt)
-            return dec, o.gemm(me, mf, out_dtype=torch.float32)     # (Q, H2*W2) fp32 mask logits
+            return dec, o.gemm(me, mf_w, out_dtype=torch.float32)   # (Q, H2*W2) fp32 mask logits
 
         if mfma:
             Qp = (Q + 7) // 8 * 8
@@ -645,12 +658,12 @@ class PSALM:
         res = {"pred_masks": masks.view(Q, H2, W2), "pred_class_name_logits": None, "pred_SEG_logits": None,
                "pred_region_logits": None}
         if class_emb is not None:
-            res["pred_class_name_logits"] = o.gemm(mlp(dec, "CLASS_proj", 2, self.adt), class_emb, out_dtype=torch.float32)
+            res["pred_class_name_logits"] = o.gemm(mlp(dec, "CLASS_proj", 2, self.adt), self._wop(class_emb), out_dtype=torch.float32)
         if SEG_emb is not None:
-            res["pred_SEG_logits"] = o.gemm(mlp(dec, "SEG_proj", 2, self.adt), SEG_emb, out_dtype=torch.float32)
+            res["pred_SEG_logits"] = o.gemm(mlp(dec, "SEG_proj", 2, self.adt), self._wop(SEG_emb), out_dtype=torch.float32)
         if region_emb is not None:     # einsum 'kd,ld->kl' (TD:744): (k, Q)
             res["pred_region_logits"] = o.gemm(region_emb.to(self.adt) if region_emb.dtype != self.adt else region_emb,
-                                               mlp(dec, "REGION_proj", 2, self.wdt), out_dtype=torch.float32)
+                                               self._wop(mlp(dec, "REGION_proj", 2, self.wdt)), out_dtype=torch.float32)
         return res
 
     # ======================================================================================= host preparation
@@ -840,7 +853,7 @@ class PSALM:
         o = self.ops
         if probsT.dtype == torch.bfloat16 and Kpad == 128 and probsT.shape[0] <= 160:
             return o.semantic_from_masks(mflat, probsT, want_mask_score=want_mask_score)
-        sem = o.gemm(probsT, o.sigmoid_transpose(mflat, Kpad, self.wdt), out_dtype=torch.float32)
+        sem = o.gemm(probsT, self._wop(o.sigmoid_transpose(mflat, Kpad, self.wdt)), out_dtype=torch.float32)
         return (sem, o.mask_scores(mflat)) if want_mask_score else sem
 
     def _postprocess(self, r, sizes):

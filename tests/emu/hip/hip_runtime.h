@@ -406,6 +406,18 @@ inline emu::f32x16_t emu_mfma_32x32x16_fp8_fp8(long a, long b, emu::f32x16_t c, 
     emu::AB8F m{a, b};
     return emu::mfma<32, 8, emu::AB8F, emu::f32x16_t, 16>(m, c, emu::ga8f, emu::gb8f);
 }
+namespace emu {
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+struct AB8H { f16x8_t a, b; };
+inline float ga8h(const AB8H& x, int j) { return (float)x.a[j]; }
+inline float gb8h(const AB8H& x, int j) { return (float)x.b[j]; }
+}  // namespace emu
+// v_mfma_f32_32x32x16_f16: same fragment layout as the bf16 form, IEEE half operands, fp32 accumulate
+inline emu::f32x16_t emu_mfma_32x32x16_f16(emu::f16x8_t a, emu::f16x8_t b, emu::f32x16_t c, int, int, int) {
+    emu::AB8H m{a, b};
+    return emu::mfma<32, 8, emu::AB8H, emu::f32x16_t, 16>(m, c, emu::ga8h, emu::gb8h);
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_mfma_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8 emu_mfma_32x32x16_fp8_fp8
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16

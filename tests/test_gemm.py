@@ -283,3 +283,90 @@ def test_gemm_fp8(ops, M, N, K, cd, split):
     # and the quantisation error itself is the expected e4m3 level (3 mantissa bits), i.e. the path is usable
     full = torch.relu(a.double() @ w.double().t() + bias.double()) + res.double()
     assert (want - full).abs().max() / full.abs().max() < 0.12
+
+
+# ------------------------------------------------------------------------------------------- split-f16 ("X3") fp32-class GEMM
+def _split_ref(x):
+    """psalm_split_f16 restated with torch: per-row power-of-two scale, hi = f16(x s), lo = f16(x s - hi)."""
+    amax = x.abs().amax(1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp(min=1e-30)))
+    s = torch.where(amax > 0, torch.exp2(13 - e), torch.ones_like(amax))
+    xs = x * s
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    return hi, lo, 1.0 / s
+
+
+@pytest.mark.parametrize("rows,K", [(5, 64), (37, 200), (9, 8), (130, 1096)])
+def test_split_f16(ops, rows, K):
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g) * torch.exp2(torch.randint(-30, 30, (rows, 1), generator=g).float())
+    x[0, :] = 0.0                                   # all-zero row: unscaled
+    x[min(1, rows - 1), K // 2] = 0.0
+    sp = ops.split_f16(x.to(ops.device))
+    Kp = (K + 63) // 64 * 64
+    assert sp.t.shape == (rows, 2 * Kp) and sp.K == K and sp.Kp == Kp
+    hi, lo, inv = _split_ref(x)
+    t = sp.t.cpu()
+    assert torch.equal(t[:, :K], hi) and torch.equal(t[:, Kp:Kp + K], lo)
+    assert (t[:, K:Kp] == 0).all() and (t[:, Kp + K:] == 0).all()
+    assert torch.equal(sp.inv_scale.cpu(), inv.view(-1))
+    # reconstruction: 22-bit operand (hi + lo) / s == x to 2^-21 of the row maximum
+    rec = (t[:, :K].double() + t[:, Kp:Kp + K].double()) * sp.inv_scale.cpu().double()[:, None]
+    assert ((rec - x.double()).abs() <= 2.0 ** -21 * x.abs().amax(1, keepdim=True).double() + 1e-300).all()
+
+
+X3_CASES = [
+    # M, N, K, bias, res, act, policy          (policy: forced tile height of the direct-to-LDS kernel, 0 = automatic)
+    (100, 72, 64, True, True, H.ACT_RELU, 0),          # skinny kernel (M <= 128)
+    (33, 40, 200, True, False, H.ACT_NONE, 0),         # ... K padded to 256 per part
+    (128, 256, 512, False, True, H.ACT_GELU, 0),       # ... multi-chunk K
+    (300, 260, 128, True, True, H.ACT_GELU, 128),
+    (300, 260, 128, True, True, H.ACT_GELU, 64),
+    (300, 520, 192, True, True, H.ACT_GELU_NEW, 256),  # 256x256 phased K loop (9 K tiles incl. the hi/lo part boundaries)
+    (257, 256, 64, True, False, H.ACT_NONE, 256),      # 3 K tiles: prologue + drain only
+    (270, 300, 1088, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 128),   # split-K slabs (scaled partials) + reduce
+    (200, 130, 704, False, False, H.ACT_NONE, 64),     # 64x128 with the 3-deep ring (K range >= 1024)
+]
+
+
+@pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy", X3_CASES)
+def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy):
+    """fp32-class accuracy from f16 matrix instructions: error vs the float64 product of the UNROUNDED fp32 operands within a few
+    2^-22 of sum_k |a||w| (the exact-fp32 MFMA kernel sits at ~2^-24 of it; a bf16 GEMM at 2^-9)."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())
+    w = (torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003) * torch.exp2(torch.randint(-6, 6, (N, 1), generator=g).float())
+    bias = torch.randn(N, generator=g) if has_bias else None
+    res = torch.randn(M, N, generator=g) if has_res else None
+    want = _ref(a, w, bias, res, act, 0)
+    mag = (a.abs().double() @ w.abs().double().t())
+    d = ops.device
+    ops.gemm_tile_policy(policy)
+    try:
+        wsp = ops.split_f16(w.to(d))                                  # weights are split once; activations on the fly
+        got = ops.gemm(a.to(d), wsp, bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()
+        got2 = ops.gemm_x3(a.to(d), w.to(d), bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()
+    finally:
+        ops.gemm_tile_policy(0)
+    assert torch.equal(got, got2)
+    tol = 6 * 2.0 ** -22 * mag + 4e-7 * want.abs() + 1e-6           # operand split 3 x 2^-22, fp32 accumulation / epilogue round-off
+    bad = (got - want).abs() > tol * (8 if act & 15 else 1)
+    assert not bad.any(), f"max err {(got - want).abs().max().item()} rel-to-mag {((got - want).abs() / mag.clamp(min=1e-30)).max().item()}"
+
+
+def test_gemm_x3_flag_routes_fp32_gemms(ops):
+    """Ops.x3 = True (precision='f16x3'): float32 x float32 gemm() calls run in split-f16 arithmetic; bf16 GEMMs are untouched."""
+    g = torch.Generator().manual_seed(3)
+    a, w = torch.randn(70, 96, generator=g), torch.randn(50, 96, generator=g)
+    d = ops.device
+    want = ops.gemm_x3(a.to(d), w.to(d)).cpu()
+    exact = ops.gemm(a.to(d), w.to(d)).cpu()
+    ops.x3 = True
+    try:
+        got = ops.gemm(a.to(d), w.to(d)).cpu()
+        gb = ops.gemm(a.bfloat16().to(d), w.bfloat16().to(d), out_dtype=torch.float32).cpu()
+    finally:
+        ops.x3 = False
+    assert torch.equal(got, want)
+    assert (got - exact).abs().max() < 1e-4 and (gb - exact).abs().max() > 1e-3

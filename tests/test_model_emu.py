@@ -162,3 +162,24 @@ def test_tiny_eval_video_vs_oracle():
     torch.manual_seed(5)
     b_ = model.forward_logits(**{k: v for k, v in kw.items() if k != "vp_images"})[0]
     assert (a["pred_region_logits"] - b_["pred_region_logits"]).abs().max() > 1e-3 * a["pred_region_logits"].abs().max()
+
+
+def test_tiny_eval_seg_f16x3_mode():
+    """precision="f16x3" (the qualifying fast mode: every GEMM in split-f16 arithmetic, everything else as the exact-fp32 mode) end to
+    end on the emulator: fp32-class agreement with the oracle, i.e. the tolerances of the fp32-mode tests, not the bf16 mode's."""
+    cfg = PsalmConfig.tiny("panoptic")
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=4, num_classes=9)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
+    torch.manual_seed(5)
+    w = O.eval_seg(sd, cfg, **inputs)[0]
+    torch.manual_seed(5)
+    g = model.eval_seg(**inputs)[0]
+    assert _rel(g["mask_pred"], w["mask_pred"]) < 1e-4
+    assert _rel(g["sem_seg"], w["sem_seg"]) < 1e-4
+    assert (g["sem_seg"].argmax(0).cpu() == w["sem_seg"].argmax(0)).float().mean() >= 0.999
+    assert torch.equal(g["panoptic_seg"][0].cpu(), w["panoptic_seg"][0])
+    assert g["panoptic_seg"][1] == w["panoptic_seg"][1]
+    gi, wi = g["instances"], w["instances"]
+    assert len(gi.scores) == len(wi.scores)
+    assert (torch.sort(gi.scores.cpu()).values - torch.sort(wi.scores).values).abs().max() < 1e-4
