@@ -221,6 +221,155 @@ __global__ void __launch_bounds__(QT) causal_attention_kernel(const T* __restric
     }
 }
 
+// ---- fp32 matrix-core form (exact-fp32 products: v_mfma_f32_32x32x2_f32), used for fp32 buffers (precision "fp32" / "f16x3").
+// The per-thread VALU kernel above spends an LDS read per FMA (27 ms of an 88 ms fp32-mode image, r02 breakdown); here a wavefront
+// owns 32 queries of one (batch, head) and walks 32-key tiles:
+//   S^T (32 keys x 32 q)  = K_tile . Q^T      32 MFMAs  (A = K rows from LDS, B = the wave's Q, resident in 32 VGPRs)
+//   O^T (64 d  x 32 q)   += V_tile^T . P^T    32 MFMAs  (A = V^T from LDS, B = P straight from the S accumulators)
+// "Swapped" products: a lane owns ONE query column of S^T / O^T, so the online-softmax statistics (max, sum, rescale) are lane-local
+// plus one exchange with the partner lane 32 away (the two k-halves), and P never leaves registers: the accumulator layout of S^T
+// (lane (q, hi) holds keys (r&3) + 8(r>>2) + 4hi, r = 0..15) is used as the key order of the second product -- step r contracts keys
+// {.. + 0, .. + 4}; V^T is read from LDS in the same order.  Likewise the first product contracts head dims in the order
+// d = 32 hi + s (step s = 0..31), so both K fragments and V^T fragments are contiguous 16-byte LDS reads.
+// Block = 4 wavefronts = 128 consecutive queries sharing the K / V tiles (RoPE applied to K while staging; V transposed while staging).
+template <int HD, int ROT>
+__global__ void __launch_bounds__(256) causal_attention_f32_mfma_kernel(const float* __restrict__ base, long ld, int q_off, int k_off,
+                                                                        int v_off, float* out, long ldo, int o_off,
+                                                                        const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                                        const unsigned char* __restrict__ key_mask, int L, int heads,
+                                                                        float scale) {
+    static_assert(HD == 64 && ROT == 32, "Phi-1.5 geometry");
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int KT = 32, KS = HD + 4, VS = KT + 4, half = ROT / 2;   // padded LDS row strides (floats): conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float Ks[KT * KS];           // [key][d]
+    __shared__ __attribute__((aligned(16))) float Vt[HD * VS];           // [d][key]
+    __shared__ unsigned char Ms[KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const long tok0 = (long)b * L;
+    const int q0 = qt * 128 + wave * 32;                                 // this wave's first query
+    const int qi = q0 + n32;                                             // this lane's query column
+    // ---- Q: lane (q, hi) holds (RoPE'd, scaled) Q[q][32 hi + s], s = 0..31
+    float qv[32];
+    {
+        const float* p = base + (tok0 + min(qi, L - 1)) * ld + q_off + h * HD + 32 * hi;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const psalm_f32x4 t = *reinterpret_cast<const psalm_f32x4*>(p + c);
+            qv[c] = t.x; qv[c + 1] = t.y; qv[c + 2] = t.z; qv[c + 3] = t.w;
+        }
+        if (hi == 0) {                                                   // rotary dims 0..31 live entirely in the hi = 0 lanes
+            const float* cs = cosT + (long)min(qi, L - 1) * ROT;
+            const float* sn = sinT + (long)min(qi, L - 1) * ROT;
+#pragma unroll
+            for (int c = 0; c < half; ++c) {
+                const float x1 = qv[c], x2 = qv[c + half];
+                qv[c] = x1 * cs[c] - x2 * sn[c];
+                qv[c + half] = x2 * cs[c + half] + x1 * sn[c + half];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) qv[c] *= scale;
+    }
+    f32x16 o0, o1;                                                       // O^T d-tiles 0 / 1: rows d = 32 t + (r&3) + 8(r>>2) + 4hi, column q
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const int last_q = min(L - 1, qt * 128 + 127);
+    const int ntiles = last_q / KT + 1;                                  // key tiles the block's last query can see
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                                                 // everyone done with the previous tile
+        {   // ---- stage K (RoPE) and V^T: thread -> key tid/8, head dims 8 (tid%8) .. +7
+            const int r = tid >> 3, c0 = (tid & 7) * 8;
+            const int kj = min(kt * KT + r, L - 1);
+            const float* p = base + (tok0 + kj) * ld;
+            float kv[8], vv[8], ko[8];
+            ld8(p + k_off + h * HD + c0, kv);
+            ld8(p + v_off + h * HD + c0, vv);
+            if (c0 < ROT) {
+                ld8(p + k_off + h * HD + (c0 < half ? c0 + half : c0 - half), ko);
+                const float* cs = cosT + (long)kj * ROT + c0;
+                const float* sn = sinT + (long)kj * ROT + c0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kv[i] = kv[i] * cs[i] + (c0 < half ? -ko[i] : ko[i]) * sn[i];
+            }
+            *reinterpret_cast<psalm_f32x4*>(&Ks[r * KS + c0]) = psalm_f32x4{kv[0], kv[1], kv[2], kv[3]};
+            *reinterpret_cast<psalm_f32x4*>(&Ks[r * KS + c0 + 4]) = psalm_f32x4{kv[4], kv[5], kv[6], kv[7]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(c0 + i) * VS + r] = vv[i];
+            if (tid < KT) { const int kk = kt * KT + tid; Ms[tid] = kk < L ? key_mask[(long)b * L + kk] : 0; }
+        }
+        __syncthreads();
+        if (kt * KT > min(q0 + 31, L - 1)) continue;                     // tile entirely above this wave's diagonal (wave-uniform)
+        // ---- S^T = K . Q^T
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        {
+            const float* kp = &Ks[n32 * KS + 32 * hi];
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const psalm_f32x4 kf = *reinterpret_cast<const psalm_f32x4*>(kp + c);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qv[c], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qv[c + 1], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qv[c + 2], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv[c + 3], sacc, 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax of this lane's query column (16 of its 32 keys here, the other 16 in lane ^ 32)
+        float mc = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = (kt * KT + j <= qi) && Ms[j];
+            sacc[r] = ok ? sacc[r] : -3.0e38f;
+            mc = fmaxf(mc, sacc[r]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(m - mn);                              // m = mn = -3e38 (nothing visible yet): exp(0) = 1, harmless
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
+            sacc[r] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32);
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // ---- O^T += V^T . P^T   (step r contracts keys (r&3) + 8(r>>2) + {0, 4}: exactly what lane (q, hi) holds in sacc[r])
+        {
+            const float* v0 = &Vt[n32 * VS + 4 * hi];
+            const float* v1 = &Vt[(32 + n32) * VS + 4 * hi];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const psalm_f32x4 a0 = *reinterpret_cast<const psalm_f32x4*>(v0 + 8 * g);
+                const psalm_f32x4 a1 = *reinterpret_cast<const psalm_f32x4*>(v1 + 8 * g);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, sacc[4 * g], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, sacc[4 * g], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, sacc[4 * g + 1], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, sacc[4 * g + 1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, sacc[4 * g + 2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, sacc[4 * g + 2], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, sacc[4 * g + 3], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, sacc[4 * g + 3], o1, 0, 0, 0);
+            }
+        }
+    }
+    if (qi < L) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        float* op = out + (tok0 + qi) * ldo + o_off + h * HD + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                    // rows d = 8g + 4hi + {0..3} of each d-tile: one 16-byte store
+            *reinterpret_cast<psalm_f32x4*>(op + 8 * g) = psalm_f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            *reinterpret_cast<psalm_f32x4*>(op + 32 + 8 * g) = psalm_f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+        }
+    }
+}
+
 extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,
                                       int o_off, const float* cos_table, const float* sin_table,
                                       const unsigned char* key_mask, int B, int L, int heads, int head_dim, int rot,
@@ -229,6 +378,13 @@ extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q
     PSALM_CHECK_ARG(rot == 32, "psalm_causal_attention: rotary dim must be 32 (Phi-1.5: 0.5 * 64)");
     if (B == 0 || L == 0) return 0;
     const float scale = 1.0f / sqrtf((float)head_dim);
+    if (dtype == PSALM_F32 && ld % 4 == 0 && ldo % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && o_off % 4 == 0 &&
+        (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {          // fp32 matrix-core kernel (16-byte accesses)
+        hipLaunchKernelGGL((causal_attention_f32_mfma_kernel<64, 32>), dim3(cdiv(L, 128), heads, B), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)qkv, ld, q_off, k_off, v_off, (float*)out, ldo, o_off, cos_table, sin_table, key_mask, L,
+                           heads, scale);
+        PSALM_LAUNCH_END("psalm_causal_attention");
+    }
     PSALM_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((causal_attention_kernel<T, 64, 32, 128>), dim3(cdiv(L, 128), heads, B), dim3(128), 0,
                            (hipStream_t)stream, (const T*)qkv, ld, q_off, k_off, v_off, (T*)out, ldo, o_off, cos_table,

@@ -159,7 +159,7 @@ def _rope_tables(L, rot, theta=10000.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1)])
+@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1), (2, 300, 2), (1, 129, 1)])   # 300: three 128-query blocks, ragged last
 def test_causal_attention(ops, dtype, B, L, heads):
     hd, rot = 64, 32
     H = heads * hd
