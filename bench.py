@@ -5,8 +5,14 @@
 A "step" is one full `eval_seg` on one synthetic 1024x1024 COCO-panoptic-shaped image per GPU: Swin-B -> projector ->
 24-layer Phi-1.5 over image + 134 class-name groups + 100 seg queries -> MSDeformAttn pixel decoder -> 9-layer masked
 decoder -> semantic / instance / panoptic post-processing at full resolution.  Random-init weights of the reference
-architecture (seeded), bf16 MFMA GEMMs with fp32 accumulation.  Images are independent, so N GPUs = N replicas of the
-weights (one RCCL broadcast at start-up) each processing its own image: weak scaling, no data-path collective.
+architecture (seeded).  Images are independent, so N GPUs = N replicas of the weights (one RCCL broadcast at start-up)
+each processing its own image: weak scaling, no data-path collective.  `--gpus N` with N > 1 and no torchrun environment
+re-launches itself as N ranks under torch.distributed.run (127.0.0.1 rendezvous).
+
+Default precision = "f16x3": the mode that MEETS the north star's parity bar (mask IoU within 1e-3 of the fp32 CPU reference,
+identical labels) -- every GEMM in split-f16 arithmetic on the f16 matrix cores (fp32-class operands, fp32 accumulate), exact-fp32
+norms / softmax / attention.  The bf16 mode is ~2.2x faster but does not meet that bar on this network, so it is
+reported as a side line (`other_modes`), never as `value`.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel -- the un-split bf16 MFMA GEMM instantiation with the
 largest share of the step -- from HIP events (on the launch stream) around every C-ABI launch in extra, instrumented eager steps
@@ -27,6 +33,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0         # HBM3E, same guide
+# HBM bytes per launch per kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload (tools/gpu_profile.sh ->
+# tools/make_traffic_json.py); the file of the current round if present, else the previous round's (bf16 kernels only)
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"))
+                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json"))
 
 
 def main():
@@ -35,20 +45,45 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32", "fp8"])
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 side-line measurement (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # stand-alone multi-GPU launch: one rank per GPU under torch.distributed.run (the driver's own launch line sets WORLD_SIZE
+        # and skips this); HSA_ENABLE_IPC_MODE_LEGACY=0 is required for RCCL's dmabuf IPC on this stack
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or without torchrun)")
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        # keep each rank's host threads on its own slice of the cores (contiguous slices follow the NUMA layout of the 2-socket hosts)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // world)
+            os.sched_setaffinity(0, set(cores[local_rank * per:(local_rank + 1) * per]) or set(cores))
+        except OSError:
+            pass
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # N ranks build their (seeded) weights concurrently on the host
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
 
     from psalm_amd.config import PsalmConfig
     from psalm_amd.dist import broadcast_weights
@@ -58,8 +93,10 @@ def main():
     cfg = PsalmConfig(seg_task="panoptic")
     sd = make_state_dict(cfg, seed=0)
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
+    bcast = None
     if world > 1:
         nbytes, secs = broadcast_weights(model, src=0)          # RCCL over xGMI, one-off
+        bcast = {"bytes": int(nbytes), "seconds": round(secs, 4), "GB_per_s": round(nbytes / max(secs, 1e-9) / 1e9, 1)}
     inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
     inputs["images"] = inputs["images"].cuda()                  # inputs resident in HBM before the timed region
 
@@ -121,11 +158,16 @@ def main():
                 B_, H_, W_, Cin, Cout, ks, st, pd_ = a[1], a[2], a[3], a[4], a[6], a[7], a[8], a[9]
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
                 geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
+            x3 = name == "psalm_gemm_x3"
+            if x3:                                                               # split-f16 GEMM: the kernel's K range is 3*Kp
+                geo = (a[12], a[13], 3 * a[6], True, False, ",x3")
             if geo is not None:
                 M, N, K, a_bf16, c_bf16, tag = geo
                 path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True)
-                if path == 2 and name == "psalm_gemm":
-                    kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}>"
+                if x3:
+                    K = a[6]                                                      # ALGORITHMIC flops: 2 M N K of the fp32 product it stands for
+                if path == 2 and name in ("psalm_gemm", "psalm_gemm_x3"):
+                    kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}{tag}>"
                 elif path == 1 or path == 2:
                     if path == 2:                             # psalm_gemm_ln has no skinny variant: it takes the tiled path
                         BM, BN, splits = (64, 128, 1)
@@ -169,7 +211,7 @@ def main():
         hbm_roof = None
         if hbm:
             tj = {}
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            tpath = TRAFFIC_JSON
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f).get("kernels", {})
@@ -186,18 +228,22 @@ def main():
             all_ms = sum(v[1] for v in kern.values())
             all_fl = sum(v[2] for v in kern.values())
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")     # rocprofv3 --pmc passes of this same workload
+            tpath = TRAFFIC_JSON     # rocprofv3 --pmc passes of this same workload
             if os.path.exists(tpath):                                            # (tools/gpu_final.sh + tools/make_traffic_json.py)
                 with open(tpath) as f:
                     tj = json.load(f).get("kernels", {})
                 if kname in tj:
                     traffic = tj[kname].get("hbm_bytes_per_launch")
+            is_x3 = ",x3" in kname
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues 3 f16 "
+                             "MFMA products per algorithmic product (hi.hi + lo.hi + hi.lo), see `mfma_issue`") if is_x3 else None,
+                    "mfma_issue": {"TFLOPs": round(3 * ach, 1), "frac_of_f16_peak": round(3 * ach / PEAK_BF16_TFLOPS, 4)} if is_x3 else None,
                     "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "share_of_step_ms": round(ms / nprof, 3), "event_pair_overhead_us": round(ev_over * 1e3, 2),
-                    "all_bf16_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
+                    "all_mfma_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
                                        "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof},
                     "hbm_bound_kernels": hbm_roof}
         if args.breakdown:
@@ -208,26 +254,52 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle, one image of the same workload
     cpu = None
     parity = None
+    side = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import psalm_oracle as O
         cores = min(os.cpu_count() or 1, 64)
         torch.set_num_threads(cores)
         cin = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
-        t1 = time.perf_counter()
-        want = O.eval_seg(sd, cfg, **cin)
-        tc = time.perf_counter() - t1
+        O.eval_seg(sd, cfg, **make_inputs(cfg, "panoptic", size=256, batch=1, seed=rank))   # warm-up (thread pool, allocator) on a small image
+        tcs = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            want = O.eval_seg(sd, cfg, **cin)
+            tcs.append(time.perf_counter() - t1)
+        tc = sorted(tcs)[1]
         cpu = {"value": round(1.0 / tc, 4), "unit": "images/s", "cores": cores, "kind": "port",
-               "sample": f"1 image, {args.size}x{args.size} panoptic, full model, fp32, single cold run ({tc:.1f} s)"}
-        g, w_ = out[0], want[0]
-        gm, wm = g["mask_pred"].cpu() > 0, w_["mask_pred"] > 0
-        inter = (gm & wm).flatten(1).sum(1).float()
-        union = (gm | wm).flatten(1).sum(1).float()
-        iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
-        parity = {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
-                  "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
-                  "semantic_argmax_agreement": round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6),
-                  "panoptic_id_agreement": round(float((g["panoptic_seg"][0].cpu() == w_["panoptic_seg"][0]).float().mean()), 6),
-                  "panoptic_segments": [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]}
+               "sample": f"1 image, {args.size}x{args.size} panoptic, full model, fp32; warm-up on a 256x256 image, then median of 3 timed runs "
+                         f"({', '.join(f'{t:.1f}' for t in tcs)} s)"}
+        def parity_of(g, w_):
+            gm, wm = g["mask_pred"].cpu() > 0, w_["mask_pred"] > 0
+            inter = (gm & wm).flatten(1).sum(1).float()
+            union = (gm | wm).flatten(1).sum(1).float()
+            iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
+            return {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
+                    "mask_logit_rel_err": float(f"{((g['mask_pred'].cpu() - w_['mask_pred']).abs().max() / w_['mask_pred'].abs().max()).item():.3e}"),
+                    "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
+                    "semantic_argmax_agreement": round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6),
+                    "panoptic_id_agreement": round(float((g["panoptic_seg"][0].cpu() == w_["panoptic_seg"][0]).float().mean()), 6),
+                    "panoptic_segments": [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]}
+        parity = parity_of(out[0], want[0])
+        parity["meets_north_star_bar"] = bool(parity["mask_iou_mean"] >= 0.999 and parity["semantic_argmax_agreement"] >= 0.999)
+        if not args.no_side_modes and args.precision != "bf16":
+            # side line: the bf16 fast mode on the same image (NOT `value`: it does not meet the parity bar on this network)
+            del model, out
+            torch.cuda.empty_cache()
+            mb = PSALM(cfg, sd, precision="bf16", use_graphs=not args.eager)
+            for _ in range(2 + args.warmup):
+                ob = mb.eval_seg(**inputs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ob = mb.eval_seg(**inputs)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - t1
+            pb = parity_of(ob[0], want[0])
+            pb["meets_north_star_bar"] = bool(pb["mask_iou_mean"] >= 0.999 and pb["semantic_argmax_agreement"] >= 0.999)
+            side = {"bf16": {"value": round(args.steps / tb, 3), "unit": "images/s", "ms_per_step": round(tb / args.steps * 1e3, 3),
+                             "parity_vs_cpu_oracle": pb}}
 
     if rank == 0:
         L = None
@@ -235,11 +307,11 @@ def main():
             "metric": "images/sec at 1024x1024 COCO-panoptic inference", "value": round(world * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
+            "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},
-            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": side, "weight_broadcast": bcast,
         }
         print(json.dumps(line))
     if world > 1:

@@ -20,9 +20,9 @@ and only as the checker.  The product (`psalm_amd/`) never imports it.
 
 PINNING: this oracle is checked against golden vectors produced by running the *reference code
 itself* in the authoring container (tests/golden/make_golden.py -> tests/golden/*.npz; see
-tests/test_oracle_golden.py).  The reference's only own known-answer test on this path
+tests/test_4_oracle_golden.py).  The reference's only own known-answer test on this path
 (OPS/test.py:24-63, MSDA forward vs the grid_sample formula) is reproduced in
-tests/test_msda_oracle.py.
+tests/test_3_msda.py.
 
 Differences from the reference kept on purpose (each is value-preserving):
   * the Swin tower is evaluated once and its features reused (the reference evaluates it twice on

@@ -11,8 +11,8 @@ Runs only in the authoring container (needs /root/reference; see ref_shim.py).  
 
     python tests/golden/make_golden.py [case ...]
 
-The fixtures are what pins oracle/psalm_oracle.py (tests/test_oracle_golden.py) and, on the GPU
-box where /root/reference does not exist, the HIP path (tests/test_e2e_gpu.py).
+The fixtures are what pins oracle/psalm_oracle.py (tests/test_4_oracle_golden.py) and, on the GPU
+box where /root/reference does not exist, the HIP path (tests/test_9_e2e_gpu.py).
 """
 import os
 import sys

@@ -1,6 +1,6 @@
 """End-to-end host orchestration (psalm_amd.model.PSALM) on a TINY architecture, kernels running in the host
 emulation, against the CPU oracle on the same seeded weights/inputs.  Validates layouts, weight fusion/folding,
-token splicing and the stage wiring without a GPU.  (The full-size model is checked on the GPU: test_e2e_gpu.py.)"""
+token splicing and the stage wiring without a GPU.  (The full-size model is checked on the GPU: test_9_e2e_gpu.py.)"""
 import dataclasses
 
 import pytest

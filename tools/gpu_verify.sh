@@ -1,6 +1,6 @@
 # Full verification pass: per-kernel files first (each in its own process), then whole-model tests, smoke, bench.
 mkdir -p gpurun_out/verify
-for f in test_abi test_ops test_gemm test_msda test_builder test_e2e_gpu; do
+for f in test_1_ops test_2_gemm test_3_msda test_7_builder test_9_e2e_gpu; do
   timeout 600 python -m pytest tests/$f.py -m gpu -q -x -p no:cacheprovider > gpurun_out/verify/$f.log 2>&1
   echo "$f rc=$? $(grep -E 'passed|failed|error' gpurun_out/verify/$f.log | tail -1)"
 done
