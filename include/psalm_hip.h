@@ -98,6 +98,15 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);
 
+/* Eval-time image pre-processing on the device: replaces detectron2 `T.ResizeShortestEdge` (= Pillow
+ * `Image.resize(BILINEAR)` on uint8) + `T.FixedSizeCrop` + `(image - pixel_mean) / pixel_std` of
+ * psalm/model/datasets_mapper/coco_panoptic_mapper.py:60-91,134-163.  img (H,W,3) u8 RGB -> out (3,S,S) f32, pad_mask (S,S) u8 (1 = pad).
+ * (nh,nw): resized extent; bounds_* / kk_*: Pillow's fixed-point coefficient tables per output column / row (psalm_amd/preprocess.py),
+ * NULL for an axis whose size does not change; tmp: H*nw*3 bytes of scratch; mean / std: HOST arrays of 3.  Bit-identical to Pillow. */
+int psalm_image_preprocess(const unsigned char* img, int H, int W, float* out, unsigned char* pad_mask, int S, int nh, int nw,
+                           const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v,
+                           unsigned char* tmp, const float* mean3_host, const float* std3_host, void* stream);
+
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;

@@ -260,3 +260,90 @@ extern "C" int psalm_region_pool(const float* tokens, const int* img_of_region, 
     hipLaunchKernelGGL(region_pool_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, tokens, img_of_region, pts, out, h, w, C, n);
     PSALM_LAUNCH_END("psalm_region_pool");
 }
+
+// ---------------------------------------------------------------- image pre-processing
+// The reference's eval-time input pipeline (coco_panoptic_mapper.py:60-91,134-163): detectron2 ResizeShortestEdge -> Pillow
+// `Image.resize(..., BILINEAR)` on the uint8 image, FixedSizeCrop -> pad bottom/right with 128, then (x - mean) / std in fp32.
+// Pillow's resampler (src/libImaging/Resample.c, 8 bits per channel) is a separable antialiasing filter in FIXED POINT:
+//   coefficients  k = (int)(0.5 + w * 2^22)  (w: normalised triangle weights over a support that grows with the down-scale factor),
+//   horizontal pass  t = clip8((2^21 + sum_x in[x] * k[x]) >> 22)  rounded to uint8, then the vertical pass the same way on t.
+// Both passes are restated here with the same integer arithmetic, so the result is BIT-identical to Pillow (tests/test_8_preprocess.py);
+// the coefficient tables (outSize x ksize int32 + bounds) are computed on the host exactly as precompute_coeffs / normalize_coeffs_8bpc
+// do (double arithmetic) and ride in the call's blob.  A pass whose size does not change is skipped, as ImagingResample does.
+//   resample_h: in (H, W, 3) u8 -> tmp (H, nw, 3) u8        resample_v_pad_norm: tmp (H, nw, 3) u8 -> out (3, S, S) f32 + padding mask
+__global__ void __launch_bounds__(256) pil_resample_h_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ tmp,
+                                                             const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                             int H, int W, int nw) {
+    const long total = (long)H * nw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % nw), y = (int)(i / nw);
+        const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
+        const int* k = kk + (long)xx * ksize;
+        const unsigned char* p = in + ((long)y * W + xmin) * 3;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int x = 0; x < xmax; ++x) {
+            const int kv = k[x];
+            s0 += p[3 * x] * kv; s1 += p[3 * x + 1] * kv; s2 += p[3 * x + 2] * kv;
+        }
+        unsigned char* o = tmp + i * 3;
+        o[0] = (unsigned char)min(max(s0 >> 22, 0), 255);
+        o[1] = (unsigned char)min(max(s1 >> 22, 0), 255);
+        o[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
+    }
+}
+
+__global__ void __launch_bounds__(256) pil_resample_v_pad_norm_kernel(const unsigned char* __restrict__ tmp, float* __restrict__ out,
+                                                                      unsigned char* __restrict__ pad_mask, const int* __restrict__ bounds,
+                                                                      const int* __restrict__ kk, int ksize, int Hin, int nh, int nw, int S,
+                                                                      float m0, float m1, float m2, float d0, float d1, float d2,
+                                                                      int vertical) {
+    const long total = (long)S * S;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int xx = (int)(i % S), yy = (int)(i / S);
+        int v0 = 128, v1 = 128, v2 = 128;                        // FixedSizeCrop pad value
+        const bool inside = yy < nh && xx < nw;
+        if (inside) {
+            if (vertical) {
+                const int ymin = bounds[2 * yy], ymax = bounds[2 * yy + 1];
+                const int* k = kk + (long)yy * ksize;
+                int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+                for (int y = 0; y < ymax; ++y) {
+                    const unsigned char* p = tmp + ((long)(ymin + y) * nw + xx) * 3;
+                    const int kv = k[y];
+                    s0 += p[0] * kv; s1 += p[1] * kv; s2 += p[2] * kv;
+                }
+                v0 = min(max(s0 >> 22, 0), 255); v1 = min(max(s1 >> 22, 0), 255); v2 = min(max(s2 >> 22, 0), 255);
+            } else {
+                const unsigned char* p = tmp + ((long)yy * nw + xx) * 3;
+                v0 = p[0]; v1 = p[1]; v2 = p[2];
+            }
+        }
+        out[i] = ((float)v0 - m0) / d0;                          // (image - pixel_mean) / pixel_std, coco_panoptic_mapper.py:158
+        out[total + i] = ((float)v1 - m1) / d1;
+        out[2 * total + i] = ((float)v2 - m2) / d2;
+        pad_mask[i] = inside ? 0 : 1;
+    }
+}
+
+// img (H,W,3) u8 RGB -> out (3,S,S) f32 normalised, pad_mask (S,S) u8 (1 = padding).  (nh, nw): the resized extent (<= S).
+// bounds_h / kk_h: nw x {2, ksize_h} int32 (ignored when nw == W); bounds_v / kk_v: nh x {2, ksize_v} (ignored when nh == H);
+// tmp: >= H * nw * 3 bytes of scratch (unused when nw == W).  mean / std: host arrays of 3.
+extern "C" int psalm_image_preprocess(const unsigned char* img, int H, int W, float* out, unsigned char* pad_mask, int S, int nh, int nw,
+                                      const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v,
+                                      unsigned char* tmp, const float* mean3_host, const float* std3_host, void* stream) {
+    PSALM_CHECK_ARG(H > 0 && W > 0 && nh > 0 && nw > 0 && nh <= S && nw <= S, "psalm_image_preprocess: bad geometry");
+    const bool horiz = nw != W, vert = nh != H;
+    PSALM_CHECK_ARG(!horiz || (bounds_h && kk_h && tmp && ksize_h > 0), "psalm_image_preprocess: horizontal tables / scratch missing");
+    PSALM_CHECK_ARG(!vert || (bounds_v && kk_v && ksize_v > 0), "psalm_image_preprocess: vertical tables missing");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned char* src = img;
+    if (horiz) {
+        const long total = (long)H * nw;
+        hipLaunchKernelGGL(pil_resample_h_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, tmp, bounds_h, kk_h, ksize_h, H, W, nw);
+        src = tmp;
+    }
+    const long tot = (long)S * S;
+    hipLaunchKernelGGL(pil_resample_v_pad_norm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, out, pad_mask, bounds_v, kk_v,
+                       ksize_v, H, nh, nw, S, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], vert ? 1 : 0);
+    PSALM_LAUNCH_END("psalm_image_preprocess");
+}

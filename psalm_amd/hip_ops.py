@@ -487,6 +487,34 @@ class Ops:
         self._check(rc, "psalm_patch_im2col")
         return out
 
+    def image_preprocess(self, img, nh, nw, S, mean, std):
+        """img (H,W,3) uint8 RGB on the device -> (image (3,S,S) float32 normalised, padding_mask (S,S) bool): Pillow-bilinear resize to
+        (nh, nw) (bit-identical to PIL / detectron2 ResizeShortestEdge), pad bottom/right with 128, (x - mean) / std."""
+        from .preprocess import pil_bilinear_tables
+        if img.dim() != 3 or img.shape[2] != 3 or img.dtype != torch.uint8:
+            raise PsalmHipError("image_preprocess: (H,W,3) uint8 image expected")
+        H, W = int(img.shape[0]), int(img.shape[1])
+        key = ("pp_tables", H, W, nh, nw)
+        tb = self._ws.get(key)
+        if tb is None:
+            if len([k for k in self._ws if isinstance(k, tuple) and k[0] == "pp_tables"]) > 64:
+                for k in [k for k in self._ws if isinstance(k, tuple) and k[0] == "pp_tables"]:
+                    del self._ws[k]
+            bh, kh, ksh = pil_bilinear_tables(W, nw) if nw != W else (None, None, 0)
+            bv, kv, ksv = pil_bilinear_tables(H, nh) if nh != H else (None, None, 0)
+            dev = lambda a: torch.from_numpy(a).to(self.device) if a is not None else None
+            tb = self._ws[key] = (dev(bh), dev(kh), ksh, dev(bv), dev(kv), ksv)
+        bh, kh, ksh, bv, kv, ksv = tb
+        out = self.empty(3, S, S, dtype=torch.float32)
+        pm = self.empty(S, S, dtype=torch.uint8)
+        tmp = self.empty(H * nw * 3, dtype=torch.uint8) if nw != W else None
+        m = (c_float * 3)(*[float(v) for v in mean.reshape(-1)])
+        d = (c_float * 3)(*[float(v) for v in std.reshape(-1)])
+        rc = self.lib.psalm_image_preprocess(self._p(img), H, W, self._p(out), self._p(pm), S, nh, nw, self._p(bh), self._p(kh), ksh,
+                                             self._p(bv), self._p(kv), ksv, self._p(tmp), m, d, self._stream())
+        self._check(rc, "psalm_image_preprocess")
+        return out, pm.view(torch.bool)
+
     def im2col_nhwc(self, x, B, H, W, k, stride, pad):
         C = x.shape[-1]
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1

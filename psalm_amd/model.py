@@ -80,7 +80,22 @@ def default_region_point_sampler(nonzero: torch.Tensor, n: int) -> torch.Tensor:
     return torch.randperm(m)[:n]
 
 
+class _VisionTower:
+    """What `model.get_vision_tower()` hands the reference's builder (psalm/model/builder.py:57-65): `.image_processor` -- the dict
+    of the three dataset mappers (llava_phi.py:66-69) -- and a `.to(...)` that the builder calls to move the tower."""
+    is_loaded = True
+
+    def __init__(self, image_processor):
+        self.image_processor = image_processor
+
+    def to(self, *args, **kwargs):
+        return self
+
+
 class PSALM:
+    # The default is the mode that meets the reference's fp32 results to the north star's tolerance; "bf16" is the faster, looser mode.
+    DEFAULT_PRECISION = "f16x3"
+
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
                  precision: str = "bf16", use_graphs: bool = False):
         if precision not in ("bf16", "fp32", "fp8", "f16x3"):
@@ -105,7 +120,78 @@ class PSALM:
         #                                               (measured r1k: no gain -- the LLM GEMMs already fill the chip)
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
+        self.config = None                            # LlavaConfig when built by from_pretrained (llava_phi.py:34)
+        self.image_processor = None                   # dict of pre-processors, set by from_pretrained / load_pretrained_model
+        self.training = False
         self._prepare_weights(state_dict)
+
+    # ======================================================================================= nn.Module / HF surface the eval scripts touch
+    def to(self, *args, **kwargs):
+        """`model.to(dtype=torch.float32, device=device)` (psalm/eval/panoptic_segmentation.py:127 and siblings).  The weights already
+        live on this binding's device in the layout `precision` chose, so: the device must be that device (there is no CPU path), a
+        floating dtype is accepted and has no effect -- the arithmetic is selected by `precision`, whose default meets fp32 parity."""
+        dev = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                dev = a
+        if dev is not None:
+            dev = torch.device(dev)
+            if dev.type != self.device.type:
+                raise H.PsalmHipError(f"PSALM.to({dev}): this model runs on {self.device} only (hand-written gfx950 kernels, no CPU fallback)")
+        dt = kwargs.get("dtype", next((a for a in args if isinstance(a, torch.dtype)), None))
+        if dt is not None and not dt.is_floating_point:
+            raise TypeError(f"PSALM.to(dtype={dt}): floating dtype expected")
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("psalm_amd.PSALM is the inference path (eval_seg / eval_video); training is out of scope")
+        return self
+
+    def float(self):
+        return self
+
+    def half(self):
+        return self
+
+    def bfloat16(self):
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda")
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def get_model(self):                              # llava_phi.py:484
+        return self
+
+    def get_vision_tower(self):                       # llava_phi.py:72; consumed at psalm/model/builder.py:57-65
+        return _VisionTower(self.image_processor)
+
+    @classmethod
+    def from_pretrained(cls, model_path, mask_decoder_cfg=None, *, precision: Optional[str] = None, use_graphs: bool = True, ops=None,
+                        seg_task: Optional[str] = None, **hf_kwargs):
+        """`PSALM.from_pretrained(model_path, mask_decoder_cfg=mask_cfg, **kwargs)` (psalm/model/builder.py:54): Hugging Face checkpoint
+        directory -> model.  `mask_decoder_cfg`: the (attribute-style) mask YAML the reference passes, or None for the released
+        defaults.  The Hugging Face loader keywords the reference passes (torch_dtype, device_map, low_cpu_mem_usage ...) are accepted
+        and ignored; bitsandbytes quantisation is rejected.  `precision`, `use_graphs`, `ops`, `seg_task` are extensions."""
+        from . import builder as B
+        from .config import load_mask_config
+        if hf_kwargs.get("load_in_8bit") or hf_kwargs.get("load_in_4bit") or hf_kwargs.get("quantization_config") is not None:
+            raise NotImplementedError("bitsandbytes 8/4-bit loading is a CUDA feature of the reference loader; not available on this path")
+        mask_cfg = mask_decoder_cfg if mask_decoder_cfg is not None else load_mask_config(None)
+        task = seg_task or mask_cfg.MODEL.MASK_FORMER.SEG_TASK
+        cfg = B.config_from_hf(model_path, mask_cfg, task)
+        model = cls(cfg, B.read_checkpoint(model_path), ops=ops, precision=precision or cls.DEFAULT_PRECISION, use_graphs=use_graphs)
+        model.config = B.hf_config(model_path)
+        m = mask_cfg.MODEL
+        proc = B.ImagePreprocessor(mask_cfg.INPUT.IMAGE_SIZE, m.PIXEL_MEAN, m.PIXEL_STD, device=None)
+        model.image_processor = {"panoptic": proc, "instance": proc, "semantic": proc}             # llava_phi.py:66-69
+        return model
 
     # ======================================================================================= weights
     @staticmethod
