@@ -23,11 +23,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         if not (value.is_contiguous() and sampling_loc.is_contiguous() and attn_weight.is_contiguous()):
             raise RuntimeError("value / sampling_loc / attn_weight tensor has to be contiguous")
         ops = get_ops()
-        shapes = spatial_shapes.tolist()          # host copy of a (L,2) tensor: one small D2H per call
-        starts = level_start_index.tolist()
         dt = value.dtype
-        out = ops.msda_forward(value if dt in (torch.float32, torch.bfloat16) else value.float(), shapes, starts,
-                               sampling_loc.float(), attn_weight.float())
+        # the level table stays on the device, as in the reference op (ms_deform_attn_cuda.cu:64-75): no host copy / D2H sync on the seam
+        out = ops.msda_forward_dev(value if dt in (torch.float32, torch.bfloat16) else value.float(),
+                                   spatial_shapes.to(torch.int64), level_start_index.to(torch.int64),
+                                   sampling_loc.float(), attn_weight.float())
         return out.to(dt)
     except Exception:
         if os.environ.get("PSALM_MSDA_STRICT"):

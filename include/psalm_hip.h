@@ -35,6 +35,13 @@ const char* psalm_backend(void); /* "hip-gfx950" */
 int psalm_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
                        const int64_t* level_start_host, const float* sampling_loc, const float* attn_weight, void* out,
                        int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+/* Same op with the level table in DEVICE memory -- the reference's own convention (spatial_shapes / level_start_index are CUDA int64
+ * tensors, ms_deform_attn.h:25-44; read by the kernel, ms_deform_im2col_cuda.cuh:261-265): fully asynchronous, no host copy.  This is
+ * the entry the `MultiScaleDeformableAttention` plugin module binds. */
+int psalm_msda_forward_dev(const void* value, int value_dtype, const int64_t* spatial_shapes_dev, const int64_t* level_start_dev,
+                           const float* sampling_loc, const float* attn_weight, void* out, int out_dtype, int B, int S, int M, int D,
+                           int L, int Lq, int P, void* stream);
+
 
 /* The same gather with MSDeformAttn.forward's location/softmax arithmetic fused in
  * (OPS/modules/ms_deform_attn.py:101-110): offsets_logits (B,S,M*L*P*3) f32 is the output of the
@@ -106,6 +113,24 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
 int psalm_image_preprocess(const unsigned char* img, int H, int W, float* out, unsigned char* pad_mask, int S, int nh, int nw,
                            const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v,
                            unsigned char* tmp, const float* mean3_host, const float* std3_host, void* stream);
+
+/* Evaluator-facing outputs on the device (csrc/evalout.hip): the host arithmetic of the reference's evaluators moved next
+ * to the data, so that compact results cross PCIe instead of ~1 GB of fp32 masks per image.
+ *   psalm_semantic_labels      `output["sem_seg"].argmax(dim=0)`                      panoptic_evaluation.py:125   sem (C,HW) f32 -> labels (HW) i32
+ *   psalm_confusion_accumulate `np.bincount((C+1)*pred + gt)`, gt == ignore -> C      panoptic_evaluation.py:129-134  conf (C+1,C+1) i64 += ...
+ *   psalm_panoptic_rgb         panopticapi `id2rgb(panoptic_img)`                     panoptic_evaluation.py:204   ids (HW) i32 -> (HW,3) u8
+ *   psalm_mask_rle_count/_emit pycocotools `mask.encode(np.asfortranarray(m))` run boundaries (column-major positions where the pixel
+ *                              differs from its predecessor)                           region_segmentation.py:282   masks (n,H,W) f32|u8
+ *       count: col_cnt / col_off (n,W) i32 scratch, total (n) i32;  emit: base (n) i64 = exclusive prefix of total (host), out i32
+ *   psalm_iou_counts           intersectionAndUnionGPU(pred, gt, K=2, ignore 255)      referring_segmentation.py:101-113
+ *       per pair p: counts[p] = [I0,I1,O0,O1,T0,T1] i64 (accumulated: zero the buffer first); union = O + T - I                        */
+int psalm_semantic_labels(const float* sem, int* labels, int C, long HW, void* stream);
+int psalm_confusion_accumulate(const int* pred, const int* gt, long n, int num_classes, int ignore_label, long long* conf, void* stream);
+int psalm_panoptic_rgb(const int* ids, unsigned char* rgb, long n, void* stream);
+int psalm_mask_rle_count(const void* masks, int dtype_is_u8, int n, int H, int W, int* col_cnt, int* col_off, int* total, void* stream);
+int psalm_mask_rle_emit(const void* masks, int dtype_is_u8, int n, int H, int W, const int* col_off, const long* base, int* out, void* stream);
+int psalm_iou_counts(const void* pred, int pred_is_u8, const unsigned char* tgt, const int* pred_idx, const int* tgt_idx, int npairs, long HW,
+                     long long* counts_zeroed, void* stream);
 
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);

@@ -97,6 +97,121 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
     for (int c = 0; c < HD; ++c) stf(op + c, o[c] * inv);
 }
 
+// ---- fp32 matrix-core form (v_mfma_f32_16x16x4_f32: exact fp32 products), used for fp32 buffers with 12x12 windows.
+// One wavefront per (window, head): N = 144 tokens = 9 tiles of 16.  Swapped products, as in the causal kernel below:
+//   S^T (16 keys x 16 q) = K_tile . Q^T    8 MFMAs (head dim 32 = 8 steps of 4; lane (n, kk) contracts d = 8 kk + s in step s, so its
+//                                          K and Q fragments are 8 consecutive floats)
+//   the WHOLE score column block of a 16-query tile (9 key tiles x 4 registers) stays in registers: exact two-pass softmax, the
+//   statistics of a query live in the 4 lanes {q, q+16, q+32, q+48} (two xor-shuffles);
+//   O^T (16 d x 16 q)   += V_tile^T . P^T   4 MFMAs per key tile and d-tile, P straight from the score registers: step r contracts the
+//                                          keys 4 kk + r that lane (q, kk) holds in register r; V is read un-transposed from LDS.
+// K / V rows are padded to 36 floats: the 16-byte K fragment reads of 16 consecutive rows and the 4-byte V reads of a step hit 64
+// distinct banks.  3 waves per CU (43.6 KB of LDS each).
+template <int HD, int WS>
+__global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
+                                                                       float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift) {
+    static_assert(HD == 32 && WS == 12, "Swin-B window geometry");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int N = WS * WS, NT = N / 16, LS = HD + 4, NB = (2 * WS - 1) * (2 * WS - 1);
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* Ks = smem;                       // [N][LS]
+    float* Vs = Ks + N * LS;                // [N][LS]
+    float* Bs = Vs + N * LS;                // [NB]
+    const int win = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, n16 = lane & 15, kk = lane >> 4;
+    const long row0 = (long)win * N;
+    for (int e = lane; e < N * (HD / 4); e += 64) {                      // 144 rows x 8 float4 per operand
+        const int r = e >> 3, c4 = (e & 7) * 4;
+        const float* p = qkv + (row0 + r) * 3 * C + h * HD + c4;
+        *reinterpret_cast<psalm_f32x4*>(&Ks[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + C);
+        *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
+    }
+    for (int e = lane; e < NB; e += 64) Bs[e] = bias_table[(long)e * heads + h];
+    __syncthreads();
+    const float scale = rsqrtf((float)HD);
+    // shift-mask region label of a token (swin_trans.py:371-387): slices (0,-ws), (-ws,-shift), (-shift,None)
+    const int wwin = win % (nWh * nWw);
+    const int wh = wwin / nWw, ww = wwin % nWw;
+    const int Hp = nWh * WS, Wp = nWw * WS;
+    auto label = [&](int t) -> int {
+        const int gy = wh * WS + t / WS, gx = ww * WS + t % WS;
+        const int ly = gy < Hp - WS ? 0 : (gy < Hp - shift ? 1 : 2);
+        const int lx = gx < Wp - WS ? 0 : (gx < Wp - shift ? 1 : 2);
+        return ly * 3 + lx;
+    };
+    int klab[NT][4];                                                     // labels of the keys this lane holds (16 tk + 4 kk + r)
+    if (shift > 0) {
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) klab[tk][r] = label(16 * tk + 4 * kk + r);
+    }
+#pragma unroll 1
+    for (int tq = 0; tq < NT; ++tq) {
+        const int qi = 16 * tq + n16;                                    // this lane's query (column of S^T / O^T)
+        float qf[8];
+        {
+            const float* p = qkv + (row0 + qi) * 3 * C + h * HD + 8 * kk;
+            const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], b = reinterpret_cast<const psalm_f32x4*>(p)[1];
+            qf[0] = a.x * scale; qf[1] = a.y * scale; qf[2] = a.z * scale; qf[3] = a.w * scale;
+            qf[4] = b.x * scale; qf[5] = b.y * scale; qf[6] = b.z * scale; qf[7] = b.w * scale;
+        }
+        const int yi = qi / WS, xi = qi % WS;
+        const int qlab = shift > 0 ? label(qi) : 0;
+        f32x4 sc[NT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* kp = &Ks[(16 * tk + n16) * LS + 8 * kk];
+            const psalm_f32x4 k0 = reinterpret_cast<const psalm_f32x4*>(kp)[0], k1 = reinterpret_cast<const psalm_f32x4*>(kp)[1];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[5], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * tk + 4 * kk + r;
+                const int yj = j / WS, xj = j % WS;
+                float v = acc[r] + Bs[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
+                if (shift > 0 && klab[tk][r] != qlab) v += -100.0f;
+                acc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            sc[tk] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[tk][r] - mx);
+                sc[tk][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};       // O^T d-tiles: rows d = 16 t + 4 kk + r, column q
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = &Vs[(16 * tk + 4 * kk + r) * LS + n16];
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], sc[tk][r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], sc[tk][r], o1, 0, 0, 0);
+            }
+        const float inv = 1.f / l;
+        float* op = out + (row0 + qi) * C + h * HD + 4 * kk;
+        *reinterpret_cast<psalm_f32x4*>(op) = psalm_f32x4{o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
+        *reinterpret_cast<psalm_f32x4*>(op + 16) = psalm_f32x4{o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
+    }
+}
+
 extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw,
                                       int C, int heads, int ws, int shift, void* stream) {
     PSALM_CHECK_ARG(C == heads * 32, "psalm_window_attention: head_dim must be 32");
@@ -104,6 +219,12 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
     const int nwin = B * nWh * nWw;
     if (nwin == 0) return 0;
     const int N = ws * ws;
+    if (dtype == PSALM_F32 && ws == 12 && C % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {     // fp32 matrix-core kernel
+        const size_t lds = (size_t)(2 * N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
+        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
+                           (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
+        PSALM_LAUNCH_END("psalm_window_attention");
+    }
     const size_t shmem = (size_t)(2 * N * 33 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
     PSALM_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((window_attention_kernel<T, 32>), dim3(nwin, heads), dim3(192), shmem, (hipStream_t)stream,

@@ -179,11 +179,14 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
 }
 
 // Plugin form: explicit sampling locations / attention weights (the reference op's contract).
-template <typename TV, typename TO, int LP_UNROLL>
+// DEV = true: the level table is read from DEVICE memory (`shapes_dev` (L,2) / `starts_dev` (L) int64 -- exactly the tensors the
+// reference op receives, ms_deform_attn_cuda.cu:64-75), so the caller needs no host copy of them (no D2H sync on the seam).
+template <typename TV, typename TO, int LP_UNROLL, bool DEV = false>
 __global__ void __launch_bounds__(256) msda_forward_kernel(const TV* __restrict__ value, MsdaLevels lv,
                                                            const float* __restrict__ loc, const float* __restrict__ attw,
                                                            TO* __restrict__ out, int B, int S, int M, int D, int L, int Lq,
-                                                           int P) {
+                                                           int P, const long* __restrict__ shapes_dev = nullptr,
+                                                           const long* __restrict__ starts_dev = nullptr) {
     const int G = D >> 2;  // lanes per (q,head)
     const long total = (long)B * Lq * M * G;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -200,11 +203,13 @@ __global__ void __launch_bounds__(256) msda_forward_kernel(const TV* __restrict_
         const TV* vb = value + (long)b * S * row_stride + m * D + g * 4;
         f32x4_s acc{0.f, 0.f, 0.f, 0.f};
         for (int l = 0; l < L; ++l) {
-            const TV* vl = vb + (long)lv.start[l] * row_stride;
+            const int Hl = DEV ? (int)shapes_dev[2 * l] : lv.H[l], Wl = DEV ? (int)shapes_dev[2 * l + 1] : lv.W[l];
+            const long sl = DEV ? starts_dev[l] : (long)lv.start[l];
+            const TV* vl = vb + sl * row_stride;
 #pragma unroll LP_UNROLL
             for (int p = 0; p < P; ++p) {
                 const int i = l * P + p;
-                msda_sample<TV>(vl, lv.H[l], lv.W[l], row_stride, lp[2 * i], lp[2 * i + 1], wp[i], acc);
+                msda_sample<TV>(vl, Hl, Wl, row_stride, lp[2 * i], lp[2 * i + 1], wp[i], acc);
             }
         }
         st4(out + qm * D + g * 4, acc);
@@ -293,6 +298,27 @@ extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int6
                            (const TV*)value, lv, sampling_loc, attn_weight, (TO*)out, B, S, M, D, L, Lq, P);
     }));
     PSALM_LAUNCH_END("psalm_msda_forward");
+}
+
+// Same op with the level table on the DEVICE (the reference's own calling convention: spatial_shapes / level_start_index are CUDA
+// int64 tensors, ms_deform_attn.h:25-44): asynchronous, no host copy.  sum(H_l*W_l) == S is the caller's contract (unchecked, as in
+// the reference).
+extern "C" int psalm_msda_forward_dev(const void* value, int value_dtype, const int64_t* spatial_shapes_dev,
+                                      const int64_t* level_start_dev, const float* sampling_loc, const float* attn_weight, void* out,
+                                      int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream) {
+    PSALM_CHECK_ARG(D % 4 == 0 && D > 0, "psalm_msda_forward_dev: head dim must be a multiple of 4");
+    PSALM_CHECK_ARG(L >= 1 && spatial_shapes_dev && level_start_dev, "psalm_msda_forward_dev: level table missing");
+    MsdaLevels lv = {};
+    const long total = (long)B * Lq * M * (D / 4);
+    if (total == 0) return 0;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block < 65536 * 8 ? (total + block - 1) / block : 65536 * 8);
+    PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
+        hipLaunchKernelGGL((msda_forward_kernel<TV, TO, 4, true>), dim3(grid), dim3(block), 0, (hipStream_t)stream,
+                           (const TV*)value, lv, sampling_loc, attn_weight, (TO*)out, B, S, M, D, L, Lq, P,
+                           (const long*)spatial_shapes_dev, (const long*)level_start_dev);
+    }));
+    PSALM_LAUNCH_END("psalm_msda_forward_dev");
 }
 
 extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_shapes_host,

@@ -1,0 +1,175 @@
+"""Evaluator-facing outputs computed on the device.
+
+The reference's evaluators start every image with `.cpu().numpy()` of the model's full-resolution outputs -- `sem_seg` (133,H,W) fp32 =
+558 MB and `instances.pred_masks` (100,H,W) fp32 = 419 MB at 1024^2 -- and then reduce them on the host to a label map, a confusion
+matrix, a PNG, run-length codes or a few intersection / union counts.  These functions produce those SMALL results on the GPU (kernels in
+csrc/evalout.hip) in exactly the evaluators' arithmetic, so only KBs..MBs cross PCIe and the metric meters can be combined across ranks
+with one tiny RCCL all-reduce (`psalm_amd.dist.reduce_metrics`, the role of AverageMeter.all_reduce, referring_segmentation.py:58-79).
+
+    semantic_labels(sem_seg)                      panoptic_evaluation.py:125        -> (H,W) int32 labels
+    ConfusionMatrix(C, ignore).update(pred, gt)   panoptic_evaluation.py:127-134    -> (C+1,C+1) int64 on the device
+    panoptic_png_rgb(panoptic_ids)                panoptic_evaluation.py:204 (id2rgb) -> (H,W,3) uint8, ready for the PNG encoder
+    masks_to_rle(pred_masks)                      region_segmentation.py:282 (pycocotools mask.encode) -> [{"size": [h,w], "counts": bytes}]
+    iou_counts(pred_masks, gt_masks, pairs)       referring_segmentation.py:101-113 (intersectionAndUnionGPU, K=2) -> intersection, union
+    IoUMeters                                     referring_segmentation.py:139-177 + :58-79 (cIoU / gIoU bookkeeping + all-reduce)
+"""
+from __future__ import annotations
+
+from ctypes import c_long
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip_ops as H
+
+
+def _ops(ops):
+    return ops if ops is not None else H.get_ops()
+
+
+def semantic_labels(sem_seg: torch.Tensor, ops=None) -> torch.Tensor:
+    """`sem_seg.argmax(dim=0)` for a (C,H,W) float32 class map -> (H,W) int32 (first maximal class on ties, as torch)."""
+    o = _ops(ops)
+    C, Hh, Ww = sem_seg.shape
+    out = o.empty(Hh, Ww, dtype=torch.int32)
+    o._check(o.lib.psalm_semantic_labels(o._p(sem_seg), o._p(out), C, c_long(Hh * Ww), o._stream()), "psalm_semantic_labels")
+    return out
+
+
+class ConfusionMatrix:
+    """my_SemSegEvaluator's `_conf_matrix` (panoptic_evaluation.py:127-134) kept on the device: rows = prediction, columns = ground truth,
+    last row / column = the ignore bucket.  `update` takes int32 label maps (the prediction from `semantic_labels`)."""
+
+    def __init__(self, num_classes: int, ignore_label: int = 255, ops=None):
+        self.ops = _ops(ops)
+        self.num_classes, self.ignore_label = num_classes, ignore_label
+        self.conf = torch.zeros(num_classes + 1, num_classes + 1, dtype=torch.int64, device=self.ops.device)
+
+    def update(self, pred: torch.Tensor, gt: torch.Tensor) -> None:
+        o = self.ops
+        gt = gt.to(o.device, torch.int32).contiguous()
+        if pred.shape != gt.shape or pred.dtype != torch.int32:
+            raise H.PsalmHipError("ConfusionMatrix.update: int32 label maps of equal shape")
+        o._check(o.lib.psalm_confusion_accumulate(o._p(pred), o._p(gt), c_long(pred.numel()), self.num_classes, self.ignore_label,
+                                                  o._p(self.conf), o._stream()), "psalm_confusion_accumulate")
+
+    def miou(self) -> Tuple[np.ndarray, float]:
+        """Per-class IoU and mIoU as my_SemSegEvaluator.evaluate derives them from the matrix (detectron2 SemSegEvaluator.evaluate)."""
+        conf = self.conf.cpu().numpy().astype(np.float64)
+        tp = conf.diagonal()[:-1]
+        pos_gt = conf[:-1, :-1].sum(0)
+        pos_pred = conf[:-1, :-1].sum(1)
+        union = pos_gt + pos_pred - tp
+        valid = pos_gt > 0
+        iou = np.where(union > 0, tp / np.maximum(union, 1), np.nan)
+        return iou, float(np.nansum(iou[valid]) / max(valid.sum(), 1))
+
+
+def panoptic_png_rgb(panoptic_ids: torch.Tensor, ops=None) -> torch.Tensor:
+    """panopticapi `id2rgb`: id -> (id % 256, id // 256 % 256, id // 65536 % 256); (H,W) int32 -> (H,W,3) uint8 on the device."""
+    o = _ops(ops)
+    Hh, Ww = panoptic_ids.shape
+    out = o.empty(Hh, Ww, 3, dtype=torch.uint8)
+    o._check(o.lib.psalm_panoptic_rgb(o._p(panoptic_ids.to(torch.int32).contiguous()), o._p(out), c_long(Hh * Ww), o._stream()), "psalm_panoptic_rgb")
+    return out
+
+
+def rle_counts_to_string(counts: Sequence[int]) -> bytes:
+    """pycocotools maskApi.c rleToString: LEB128-like, 5 data bits + continuation bit per char, chars 48..111, counts after the third
+    stored as differences to the count two positions earlier."""
+    out = bytearray()
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def masks_to_rle(masks: torch.Tensor, ops=None) -> List[dict]:
+    """Binary masks (n,H,W) float32 | uint8 (nonzero = foreground) -> COCO RLE dicts, == `mask.encode(np.asfortranarray(m))` of pycocotools.
+    The device finds the run boundaries (column-major); only those (4 bytes per run) are copied to the host."""
+    o = _ops(ops)
+    if masks.dim() != 3 or masks.dtype not in (torch.float32, torch.uint8, torch.bool):
+        raise H.PsalmHipError("masks_to_rle: (n,H,W) float32 / uint8 / bool masks")
+    if masks.dtype == torch.bool:
+        masks = masks.view(torch.uint8)
+    masks = masks.contiguous()
+    n, Hh, Ww = masks.shape
+    if n == 0:
+        return []
+    u8 = 1 if masks.dtype == torch.uint8 else 0
+    col_cnt = o.empty(n, Ww, dtype=torch.int32)
+    col_off = o.empty(n, Ww, dtype=torch.int32)
+    total = o.empty(n, dtype=torch.int32)
+    o._check(o.lib.psalm_mask_rle_count(o._p(masks), u8, n, Hh, Ww, o._p(col_cnt), o._p(col_off), o._p(total), o._stream()), "psalm_mask_rle_count")
+    tot = total.cpu().numpy().astype(np.int64)                 # the one sync: n small integers
+    base = np.concatenate(([0], np.cumsum(tot)[:-1]))
+    pos = o.empty(max(int(tot.sum()), 1), dtype=torch.int32)
+    o._check(o.lib.psalm_mask_rle_emit(o._p(masks), u8, n, Hh, Ww, o._p(col_off), o._p(torch.from_numpy(base).to(o.device)), o._p(pos), o._stream()),
+             "psalm_mask_rle_emit")
+    pos = pos.cpu().numpy().astype(np.int64)
+    out = []
+    for i in range(n):
+        b = pos[base[i]: base[i] + tot[i]]
+        counts = np.diff(np.concatenate(([0], b, [Hh * Ww])))  # run lengths, starting with the zeros run (0 if the mask starts with 1)
+        out.append({"size": [Hh, Ww], "counts": rle_counts_to_string(counts.tolist())})
+    return out
+
+
+def iou_counts(pred_masks: torch.Tensor, gt_masks: torch.Tensor, pairs: Sequence[Tuple[int, int]], ops=None):
+    """intersectionAndUnionGPU(pred, gt, K=2, ignore_index=255) for each (prediction index, target index) pair, on the device:
+    pred_masks (n,H,W) float32|uint8 (nonzero = 1), gt_masks (m,H,W) uint8 with 255 = ignore.
+    Returns (intersection (P,2), union (P,2), target (P,2)) int64 tensors on the device (classes: background, foreground)."""
+    o = _ops(ops)
+    if pred_masks.dtype == torch.bool:
+        pred_masks = pred_masks.view(torch.uint8)
+    pred_masks = pred_masks.contiguous()
+    gt = gt_masks.to(o.device, torch.uint8).contiguous()
+    if tuple(pred_masks.shape[1:]) != tuple(gt.shape[1:]):
+        raise H.PsalmHipError("iou_counts: prediction / target size mismatch")
+    P = len(pairs)
+    pi = torch.tensor([p for p, _ in pairs], dtype=torch.int32, device=o.device)
+    ti = torch.tensor([t for _, t in pairs], dtype=torch.int32, device=o.device)
+    counts = torch.zeros(P, 6, dtype=torch.int64, device=o.device)
+    HW = int(pred_masks.shape[1] * pred_masks.shape[2])
+    o._check(o.lib.psalm_iou_counts(o._p(pred_masks), 1 if pred_masks.dtype == torch.uint8 else 0, o._p(gt), o._p(pi), o._p(ti), P, c_long(HW),
+                                    o._p(counts), o._stream()), "psalm_iou_counts")
+    inter, outp, tgt = counts[:, 0:2], counts[:, 2:4], counts[:, 4:6]
+    return inter, outp + tgt - inter, tgt
+
+
+class IoUMeters:
+    """The three AverageMeters of the referring / region evaluation loops (referring_segmentation.py:139-177: intersection, union,
+    acc_iou) fed from device-side counts; `all_reduce()` = AverageMeter.all_reduce (:58-79) as ONE small SUM all-reduce."""
+
+    def __init__(self):
+        self.sum = torch.zeros(7, dtype=torch.float64)         # [I0, I1, U0, U1, acc0, acc1, n]
+
+    def update(self, inter: torch.Tensor, union: torch.Tensor) -> None:
+        """inter / union (P,2) for the evaluator's top-1 prediction of each of P samples (compute_metric, :139-171)."""
+        i, u = inter.double().cpu(), union.double().cpu()
+        acc = i / (u + 1e-5)
+        acc[u == 0] = 1.0                                       # no-object target (:158)
+        self.sum[0:2] += i.sum(0)
+        self.sum[2:4] += u.sum(0)
+        self.sum[4:6] += acc.sum(0)
+        self.sum[6] += i.shape[0]
+
+    def all_reduce(self, device=None) -> None:
+        from .dist import reduce_metrics
+        t = self.sum.float().to(device) if device is not None else self.sum.float()
+        self.sum = reduce_metrics(t).double().cpu()
+
+    def results(self) -> dict:
+        ciou = float(self.sum[1] / (self.sum[3] + 1e-10))      # iou_class[1], region_segmentation.py:286-287
+        giou = float(self.sum[5] / max(float(self.sum[6]), 1e-5))
+        return {"ciou": ciou, "giou": giou, "n": int(self.sum[6])}

@@ -703,6 +703,20 @@ class Ops:
         self._check(rc, "psalm_msda_forward")
         return out
 
+    def msda_forward_dev(self, value, spatial_shapes, level_start, loc, attw, out_dtype=None):
+        """msda_forward with `spatial_shapes` (L,2) / `level_start` (L) as int64 tensors ON THE DEVICE (the reference op's signature):
+        nothing is copied to the host, the call is asynchronous."""
+        B, S, M, D = value.shape
+        _, Lq, _, L, P, _ = loc.shape
+        for t in (spatial_shapes, level_start):
+            if t.dtype != torch.int64 or t.device != value.device:
+                raise PsalmHipError("msda_forward_dev: int64 level tensors on the value's device")
+        out = self.empty(B, Lq, M * D, dtype=out_dtype or value.dtype)
+        rc = self.lib.psalm_msda_forward_dev(self._p(value), _dt(value), self._p(spatial_shapes.contiguous()), self._p(level_start.contiguous()),
+                                             self._p(loc), self._p(attw), self._p(out), _dt(out), B, S, M, D, L, Lq, P, self._stream())
+        self._check(rc, "psalm_msda_forward_dev")
+        return out
+
     def msda_fused(self, value, spatial_shapes, level_start, offsets_logits, M, out_dtype=None):
         """value (B,S,M*D); offsets_logits (B,S,M*L*P*3) f32 = [offsets | logits] -> (B,S,M*D)."""
         B, S, C = value.shape

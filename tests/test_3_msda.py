@@ -131,3 +131,29 @@ def test_fused_matches_explicit(ops):
     want = O.msda_core(value.view(B, S, M, D), shapes, st, loc, aw)
     got = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
     assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
+
+
+def test_plugin_module_by_name_device_side_level_table(ops, monkeypatch):
+    """Seam B1: import the extension module by the reference's name and call it the way MSDeformAttnFunction.forward does
+    (ops/functions/ms_deform_attn_func.py:34-39): `spatial_shapes` / `level_start_index` are int64 TENSORS on the op's device and stay
+    there -- the module must not copy them to the host (no `.tolist()` / `.item()` sync on a seam the reference calls asynchronously)."""
+    import inspect
+    import MultiScaleDeformableAttention as MSDA
+    src = inspect.getsource(MSDA.ms_deform_attn_forward)
+    assert ".tolist(" not in src and ".item(" not in src and ".cpu(" not in src
+    monkeypatch.setattr(MSDA, "get_ops", lambda: ops)           # CPU run: the emulated library; GPU run: the product library
+    B, M, D, Lq, shapes, P = 2, 8, 32, 45, [(5, 7), (3, 4), (2, 2)], 4
+    value, loc, w = _rand_case(1, B, M, D, Lq, shapes, P)
+    st = _starts(shapes)
+    d = ops.device
+    ss = torch.as_tensor(shapes, dtype=torch.long, device=d)                        # msdeformattn.py:139-145 builds exactly these
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    got = MSDA.ms_deform_attn_forward(value.to(d), ss, lsi, loc.to(d), w.to(d), 128).cpu()
+    ref64 = _c_ref(value, shapes, st, loc, w, f64=True)
+    assert got.shape == (B, Lq, M * D)
+    assert (got - ref64).abs().max() <= 2e-6 * value.abs().max().item() * 4
+    assert torch.equal(got, ops.msda_forward(value.to(d), shapes, st, loc.to(d), w.to(d)).cpu())      # == the host-table entry point
+    with pytest.raises(NotImplementedError):
+        MSDA.ms_deform_attn_backward(None)
+    with pytest.raises(RuntimeError):                                                                    # contiguity contract, ms_deform_attn_cuda.cu:33-43
+        MSDA.ms_deform_attn_forward(value.to(d).transpose(1, 2), ss, lsi, loc.to(d), w.to(d), 128)

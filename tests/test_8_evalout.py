@@ -1,0 +1,92 @@
+"""SURVEY §8 f2 -- evaluator-facing outputs on the device vs the host arithmetic of the reference's evaluators (oracle/evalout_ref.py).
+Integer / byte work: every comparison is EXACT."""
+import numpy as np
+import pytest
+import torch
+
+from ops_backend import ops  # noqa: F401
+from oracle import evalout_ref as R
+from psalm_amd import evalout as E
+
+
+def test_rle_codec_known_answers_and_round_trip():
+    m = np.array([[0, 1], [1, 1]], np.uint8)                    # column-major: 0 1 1 1
+    assert R.rle_encode(m) == [1, 3]
+    assert R.rle_encode(np.ones((2, 3), np.uint8)) == [0, 6]    # starts with foreground -> leading zero-length run
+    assert R.rle_encode(np.zeros((2, 3), np.uint8)) == [6]
+    m2 = np.array([[1, 0, 0], [0, 0, 1]], np.uint8)             # column-major: 1 0 | 0 0 | 0 1
+    assert R.rle_encode(m2) == [0, 1, 4, 1]
+    rng = np.random.default_rng(0)
+    for h, w, p in [(7, 5, 0.5), (40, 33, 0.1), (64, 64, 0.9), (3, 200, 0.3)]:
+        m = (rng.random((h, w)) < p).astype(np.uint8)
+        c = R.rle_encode(m)
+        assert sum(c) == h * w
+        s = R.rle_to_string(c)
+        assert all(48 <= ch < 112 for ch in s)
+        assert R.rle_from_string(s) == c and np.array_equal(R.rle_decode(c, h, w), m)
+        assert E.rle_counts_to_string(c) == s
+    big = [0, 5, 100000, 3, 7, 2 ** 20, 1]                      # multi-char counts, negative differences
+    assert R.rle_from_string(R.rle_to_string(big)) == big
+
+
+@pytest.mark.parametrize("C,H,W", [(9, 33, 47), (133, 64, 64), (1, 5, 5)])
+def test_semantic_labels_and_confusion_matrix(ops, C, H, W):
+    g = torch.Generator().manual_seed(C + H)
+    sem = torch.randn(C, H, W, generator=g)
+    sem[:, 0, 0] = 0.25                                          # an exact tie: first class wins (torch.argmax / np.argmax)
+    gt = torch.randint(0, C, (H, W), generator=g)
+    gt[torch.rand(H, W, generator=g) < 0.1] = 255
+    pred_ref, conf_ref = R.semantic_confusion(sem.numpy(), gt.numpy(), C, 255)
+    lab = E.semantic_labels(sem.to(ops.device), ops=ops)
+    assert lab.dtype == torch.int32 and np.array_equal(lab.cpu().numpy(), pred_ref)
+    cm = E.ConfusionMatrix(C, 255, ops=ops)
+    cm.update(lab, gt)
+    cm.update(lab, gt)                                           # accumulates over images
+    assert np.array_equal(cm.conf.cpu().numpy(), 2 * conf_ref)
+    iou, miou = cm.miou()
+    assert iou.shape == (C,) and 0.0 <= miou <= 1.0
+
+
+def test_panoptic_png_rgb(ops):
+    ids = torch.tensor([[0, 1, 255, 256], [65535, 65536, 16777215, 70000]], dtype=torch.int32)
+    got = E.panoptic_png_rgb(ids.to(ops.device), ops=ops).cpu().numpy()
+    assert np.array_equal(got, R.id2rgb(ids.numpy()))
+
+
+@pytest.mark.parametrize("n,H,W,dtype", [(3, 40, 33, torch.float32), (5, 64, 300, torch.uint8), (2, 7, 5, torch.bool), (1, 1, 1, torch.float32)])
+def test_masks_to_rle(ops, n, H, W, dtype):
+    g = torch.Generator().manual_seed(n * H + W)
+    m = (torch.rand(n, H, W, generator=g) < torch.tensor([0.5, 0.05, 0.95, 0.0, 1.0])[:n, None, None])
+    m[0, :, 0] = True                                            # first mask starts with foreground
+    masks = m.to(dtype).to(ops.device)
+    got = E.masks_to_rle(masks, ops=ops)
+    assert len(got) == n
+    for i in range(n):
+        want = R.rle_encode(m[i].numpy())
+        assert got[i]["size"] == [H, W] and got[i]["counts"] == R.rle_to_string(want)
+        assert np.array_equal(R.rle_decode(R.rle_from_string(got[i]["counts"]), H, W), m[i].numpy().astype(np.uint8))
+
+
+def test_iou_counts_and_meters(ops):
+    g = torch.Generator().manual_seed(3)
+    n, m, H, W = 6, 3, 50, 70
+    pred = (torch.rand(n, H, W, generator=g) < 0.4).float()
+    gt = (torch.rand(m, H, W, generator=g) < 0.3).to(torch.uint8)
+    gt[0][torch.rand(H, W, generator=g) < 0.2] = 255             # ignore region
+    gt[2] = 0                                                    # no-object target
+    pred[5] = 0
+    pairs = [(0, 0), (3, 1), (5, 2), (1, 2)]
+    inter, union, tgt = E.iou_counts(pred.to(ops.device), gt, pairs, ops=ops)
+    meters = E.IoUMeters()
+    ref = {"I": np.zeros(2), "U": np.zeros(2), "acc": np.zeros(2), "n": 0}
+    for k, (p, t) in enumerate(pairs):
+        ai, au, at = R.intersection_and_union(pred[p].numpy().astype(np.uint8), gt[t].numpy())
+        assert np.array_equal(inter[k].cpu().numpy(), ai) and np.array_equal(union[k].cpu().numpy(), au) and np.array_equal(tgt[k].cpu().numpy(), at)
+        R.compute_metric_update(ref, pred[p].numpy().astype(np.uint8), gt[t].numpy())
+    meters.update(inter, union)
+    res = meters.results()
+    assert res["n"] == 4
+    assert abs(res["ciou"] - ref["I"][1] / (ref["U"][1] + 1e-10)) < 1e-12
+    assert abs(res["giou"] - ref["acc"][1] / 4) < 1e-9
+    meters.all_reduce()                                          # no process group: identity
+    assert meters.results()["n"] == 4
