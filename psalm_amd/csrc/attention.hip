@@ -581,6 +581,216 @@ extern "C" int psalm_mha_attention(const void* q, long ldq, const void* k, long 
     PSALM_LAUNCH_END("psalm_mha_attention");
 }
 
+// ---- fp32 matrix-core form, split over keys (v_mfma_f32_16x16x4_f32), used for fp32 buffers.
+// The per-query-wave kernel above re-reads every K / V row once per query (800 waves x Lk rows x 256 B from L2 at Lk = 16384) and does the
+// products on the VALU (2.6 ms of a 34 ms f16x3 image).  Here one wavefront owns ALL queries (<= 128, NQT tiles of 16) of one head for a
+// chunk of 256 keys: Q fragments resident in registers, K / V tiles of 64 keys staged in LDS once, swapped products
+// (S^T = K . Q^T, O^T += V^T . P^T with P straight from the score registers, as in the window kernel), an online-softmax state per
+// query tile.  heads x ceil(Lk / 256) wavefronts; with more than one chunk each writes (O unnormalised, m, l) to the workspace and
+// mha_f32_combine_kernel merges the chunks.
+#define MHA_F32_CHUNK 256
+template <int NQT>
+__global__ void __launch_bounds__(64) mha_attention_f32_mfma_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
+                                                                    const float* __restrict__ V, long ldv, float* __restrict__ O, long ldo,
+                                                                    const unsigned char* __restrict__ mask,
+                                                                    const unsigned char* __restrict__ row_all_masked, float* __restrict__ part,
+                                                                    int Lq, int Lk, int heads, int splits, float scale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int HD = 32, LS = HD + 4, KT = 64;
+    __shared__ __attribute__((aligned(16))) float Ks[KT * LS];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * LS];
+    const int lane = threadIdx.x, n16 = lane & 15, kk = lane >> 4;
+    const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int k_lo = sp * MHA_F32_CHUNK, k_hi = min(Lk, k_lo + MHA_F32_CHUNK);
+    float qf[NQT][8];
+    const unsigned char* mrow[NQT];
+    bool qok[NQT], use_m[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const int qi = 16 * t + n16;
+        qok[t] = qi < Lq;
+        const float* p = Q + ((long)b * Lq + min(qi, Lq - 1)) * ldq + h * HD + 8 * kk;
+        const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], c = reinterpret_cast<const psalm_f32x4*>(p)[1];
+        qf[t][0] = a.x * scale; qf[t][1] = a.y * scale; qf[t][2] = a.z * scale; qf[t][3] = a.w * scale;
+        qf[t][4] = c.x * scale; qf[t][5] = c.y * scale; qf[t][6] = c.z * scale; qf[t][7] = c.w * scale;
+        // mask row of this lane's query (always a loadable address when a mask is given; `use_m` says whether it applies)
+        mrow[t] = mask ? mask + ((long)b * Lq + min(qi, Lq - 1)) * Lk : nullptr;
+        use_m[t] = mask && qok[t] && !(row_all_masked && row_all_masked[(long)b * Lq + min(qi, Lq - 1)]);
+    }
+    const bool fast_mask = mask && (Lk & 3) == 0 && (((uintptr_t)mask) & 3) == 0;
+    f32x4 o0[NQT], o1[NQT];
+    float m[NQT], l[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) { o0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; m[t] = -3.0e38f; l[t] = 0.f; }
+    for (int kb = k_lo; kb < k_hi; kb += KT) {
+        __syncthreads();
+        for (int e = lane; e < KT * (HD / 4); e += 64) {                  // 64 keys x 8 float4 per operand (rows past Lk: clamped, masked below)
+            const int r = e >> 3, c4 = (e & 7) * 4;
+            const long row = (long)b * Lk + min(kb + r, Lk - 1);
+            *reinterpret_cast<psalm_f32x4*>(&Ks[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(K + row * ldk + h * HD + c4);
+            *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(V + row * ldv + h * HD + c4);
+        }
+        __syncthreads();
+        unsigned mbn[NQT];                                                // blocked flags of the NEXT key tile (byte r = key kj + r)
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) mbn[t] = fast_mask ? *reinterpret_cast<const unsigned*>(mrow[t] + min(kb + 4 * kk, Lk - 4)) : 0u;
+#pragma unroll 1
+        for (int tk = 0; tk < KT / 16; ++tk) {
+            const int key0 = kb + 16 * tk;
+            if (key0 >= k_hi) break;
+            const float* kp = &Ks[(16 * tk + n16) * LS + 8 * kk];
+            const psalm_f32x4 k0 = reinterpret_cast<const psalm_f32x4*>(kp)[0], k1 = reinterpret_cast<const psalm_f32x4*>(kp)[1];
+            float va[4], vb[4];                                           // V^T fragments of the 4 contraction steps (d-tiles 0 / 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[r] = Vs[(16 * tk + 4 * kk + r) * LS + n16]; vb[r] = Vs[(16 * tk + 4 * kk + r) * LS + 16 + n16]; }
+            const int kj = key0 + 4 * kk;                                 // this lane's 4 keys: kj .. kj + 3
+            // blocked flags (byte r = key kj + r) of all query tiles, fetched together and unconditionally: a load guarded per tile
+            // compiles to a branch + s_waitcnt vmcnt(0) each, i.e. NQT dependent L2 round trips per key tile
+            unsigned mbv[NQT];
+            if (fast_mask) {
+                // software-pipelined by one key tile: this tile's flags were fetched during the previous tile (`mbn`), the next tile's are
+                // issued now and first needed one tile of MFMAs later (keys past Lk are excluded by the range test below)
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) mbv[t] = mbn[t];
+                const int kc = min(kj + 16, Lk - 4);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) mbn[t] = *reinterpret_cast<const unsigned*>(mrow[t] + kc);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    mbv[t] = 0;
+                    if (mask) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mbv[t] |= (unsigned)mrow[t][min(kj + r, Lk - 1)] << (8 * r);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[t][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[t][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[t][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.w, qf[t][3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.x, qf[t][4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.y, qf[t][5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.z, qf[t][6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[t][7], acc, 0, 0, 0);
+                const unsigned mb = use_m[t] ? mbv[t] : 0u;
+                float mc = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (kj + r < k_hi) && !((mb >> (8 * r)) & 0xffu);
+                    acc[r] = ok ? acc[r] : -3.0e38f;
+                    mc = fmaxf(mc, acc[r]);
+                }
+                mc = fmaxf(mc, __shfl_xor(mc, 16));
+                mc = fmaxf(mc, __shfl_xor(mc, 32));
+                const float mn = fmaxf(m[t], mc);
+                const float alpha = __expf(m[t] - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = acc[r] > -1.0e38f ? __expf(acc[r] - mn) : 0.f;
+                    acc[r] = p;
+                    ps += p;
+                }
+                ps += __shfl_xor(ps, 16);
+                ps += __shfl_xor(ps, 32);
+                l[t] = l[t] * alpha + ps;
+                m[t] = mn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o0[t][r] *= alpha; o1[t][r] *= alpha; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], acc[r], o0[t], 0, 0, 0);
+                    o1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[r], acc[r], o1[t], 0, 0, 0);
+                }
+            }
+            if (fast_mask) {
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) PSALM_OPAQUE_VGPR(mbn[t]);    // (keeps the optimiser from sinking each load into its `use_m` branch)
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const int qi = 16 * t + n16;
+        if (!qok[t]) continue;
+        if (splits == 1) {
+            const float inv = l[t] > 0.f ? 1.f / l[t] : 0.f;
+            float* op = O + ((long)b * Lq + qi) * ldo + h * HD + 4 * kk;
+            *reinterpret_cast<psalm_f32x4*>(op) = psalm_f32x4{o0[t][0] * inv, o0[t][1] * inv, o0[t][2] * inv, o0[t][3] * inv};
+            *reinterpret_cast<psalm_f32x4*>(op + 16) = psalm_f32x4{o1[t][0] * inv, o1[t][1] * inv, o1[t][2] * inv, o1[t][3] * inv};
+        } else {                                                          // partial state: [O (32) | m | l | pad 2] per (b, h, split, q)
+            float* pp = part + ((((long)b * heads + h) * splits + sp) * Lq + qi) * 36;
+            *reinterpret_cast<psalm_f32x4*>(pp + 4 * kk) = psalm_f32x4{o0[t][0], o0[t][1], o0[t][2], o0[t][3]};
+            *reinterpret_cast<psalm_f32x4*>(pp + 16 + 4 * kk) = psalm_f32x4{o1[t][0], o1[t][1], o1[t][2], o1[t][3]};
+            if (kk == 0) { pp[32] = m[t]; pp[33] = l[t]; }
+        }
+    }
+}
+
+// merge of the key chunks: thread = (b, h, q, d); weights e^(m_s - M)
+__global__ void __launch_bounds__(256) mha_f32_combine_kernel(const float* __restrict__ part, float* __restrict__ O, long ldo, int B, int Lq, int heads,
+                                                              int splits) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * heads * Lq * 32;
+    if (idx >= total) return;
+    const int d = (int)(idx & 31);
+    const int qi = (int)((idx >> 5) % Lq);
+    const int h = (int)((idx >> 5) / Lq % heads);
+    const int b = (int)((idx >> 5) / ((long)Lq * heads));
+    const float* p0 = part + (((long)b * heads + h) * splits * Lq + qi) * 36;
+    const long sstride = (long)Lq * 36;
+    float M = -3.0e38f;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, p0[s * sstride + 32]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float ms = p0[s * sstride + 32];
+        const float f = ms > -1.0e38f ? __expf(ms - M) : 0.f;
+        L += p0[s * sstride + 33] * f;
+        acc += p0[s * sstride + d] * f;
+    }
+    O[((long)b * Lq + qi) * ldo + h * 32 + d] = L > 0.f ? acc / L : 0.f;
+}
+
+extern "C" long psalm_mha_attention_f32_workspace(int B, int heads, int Lq, int Lk) {
+    const int splits = cdiv(Lk, MHA_F32_CHUNK);
+    return splits > 1 ? (long)B * heads * splits * Lq * 36 * (long)sizeof(float) : 0;
+}
+
+// fp32 q / k / v / out (row strides in elements, 16-byte aligned rows, head_dim 32, Lq <= 128); workspace: psalm_mha_attention_f32_workspace bytes.
+extern "C" int psalm_mha_attention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* out, long ldo,
+                                       const unsigned char* mask, const unsigned char* row_all_masked, void* workspace, int B, int Lq, int Lk,
+                                       int heads, int head_dim, void* stream) {
+    PSALM_CHECK_ARG(head_dim == 32, "psalm_mha_attention_f32: head_dim must be 32");
+    PSALM_CHECK_ARG(Lq >= 1 && Lq <= 128, "psalm_mha_attention_f32: 1 <= Lq <= 128");
+    PSALM_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 &&
+                        (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_mha_attention_f32: 16-byte aligned rows");
+    if (B == 0 || Lk == 0) return 0;
+    const int splits = cdiv(Lk, MHA_F32_CHUNK);
+    PSALM_CHECK_ARG(splits == 1 || workspace != nullptr, "psalm_mha_attention_f32: workspace required when Lk > 256");
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const dim3 grid(splits, heads, B);
+    const int nqt = cdiv(Lq, 16);
+    hipStream_t s = (hipStream_t)stream;
+#define MHA_F32_LAUNCH(N_) hipLaunchKernelGGL((mha_attention_f32_mfma_kernel<N_>), grid, dim3(64), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, mask, \
+                                              row_all_masked, (float*)workspace, Lq, Lk, heads, splits, scale)
+    if (nqt <= 1) MHA_F32_LAUNCH(1);
+    else if (nqt <= 2) MHA_F32_LAUNCH(2);
+    else if (nqt <= 4) MHA_F32_LAUNCH(4);
+    else if (nqt <= 7) MHA_F32_LAUNCH(7);
+    else MHA_F32_LAUNCH(8);
+#undef MHA_F32_LAUNCH
+    if (splits > 1) {
+        const long total = (long)B * heads * Lq * 32;
+        hipLaunchKernelGGL(mha_f32_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)workspace, out, ldo, B, Lq,
+                           heads, splits);
+    }
+    PSALM_LAUNCH_END("psalm_mha_attention_f32");
+}
+
 // ============================================================================================ attention-mask generation
 // masks (B*Q, h, w) f32 logits -> bilinear (align_corners=False, PyTorch index rule) to (Ht,Wt) -> mask = logit < 0
 // (== sigmoid < 0.5) -> u8 (B*Q, Ht*Wt); row_all_masked[bq] = 1 when every key is masked.

@@ -1402,20 +1402,26 @@ extern "C" int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, co
 //
 // psalm_split_f16: x (rows, K) f32, row stride ldx  ->  out (rows, 2 Kp) f16 = [hi (Kp) | lo (Kp)], Kp = K rounded up to 64 (pad
 // columns zero), row stride ldo (elements), and inv_scale (rows) = 1 / s (a power of two; 1 for an all-zero row).  One wavefront / row.
+// LPR lanes per row (16 / 32 / 64): short rows (K <= 128 / 256) share a wavefront so that every lane has a 32-byte vector to convert --
+// with one wavefront per row a K = 128 row (Swin stage 0, 65536 rows) kept 16 of 64 lanes busy.
+template <int LPR>
 __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
                                                         float* __restrict__ inv_scale, int rows, int K, int Kp) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * ldx;
+    constexpr int RPW = 64 / LPR;                                // rows per wavefront
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const float* xr = x + (live ? row : 0) * ldx;
     float amax = 0.f;
-    for (int c = lane * 8; c < K; c += 512) {
+    for (int c = sub * 8; c < K; c += LPR * 8) {
         float v[8];
         load8_f32(xr + c, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
     }
-    amax = wave_max(amax);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (!live) return;
     // s = 2^(13 - floor(log2 amax)), exponent clamped so that s and 1/s stay normal fp32 numbers
     int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
     int se = 13 - e;
@@ -1423,9 +1429,9 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
     const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);        // all-zero (or non-finite) row: leave it unscaled
     const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
     const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
-    if (lane == 0) inv_scale[row] = inv;
+    if (sub == 0) inv_scale[row] = inv;
     unsigned short* orow = out + row * ldo;
-    for (int c = lane * 8; c < Kp; c += 512) {
+    for (int c = sub * 8; c < Kp; c += LPR * 8) {
         float v[8];
         if (c < K) load8_f32(xr + c, v);                         // K % 8 == 0: a vector is entirely inside or outside the row
         else {
@@ -1451,8 +1457,10 @@ extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, fl
     const int Kp = (K + 63) / 64 * 64;
     PSALM_CHECK_ARG(K > 0 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0, "psalm_split_f16: K % 8 == 0, 16-byte aligned input rows");
     PSALM_CHECK_ARG((uintptr_t)out % 16 == 0 && (ldo * 2) % 16 == 0 && ldo >= 2L * Kp, "psalm_split_f16: output rows of >= 2*ceil64(K) f16, 16-byte aligned");
-    hipLaunchKernelGGL(split_f16_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)out, ldo,
-                       inv_scale, rows, K, Kp);
+    hipStream_t s = (hipStream_t)stream;
+    if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
+    else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
+    else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
     PSALM_LAUNCH_END("psalm_split_f16");
 }
 

@@ -444,6 +444,20 @@ class Ops:
         """q (B*Lq, D) / k, v (B*Lk, D) row-strided views, head_dim 32; mask (B,Lq,Lk) u8 1 = blocked."""
         D = heads * 32
         out = self.empty(B * Lq, D, dtype=q.dtype)
+        if q.dtype == torch.float32 and Lq <= 128 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (q, k, v)):
+            self.lib.psalm_mha_attention_f32_workspace.restype = c_long          # fp32 matrix-core kernel, split over 256-key chunks
+            nbytes = self.lib.psalm_mha_attention_f32_workspace(B, heads, Lq, Lk)
+            ws = None
+            if nbytes:
+                key = ("mha_f32_ws", nbytes)
+                ws = self._ws.get(key)
+                if ws is None:
+                    ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            rc = self.lib.psalm_mha_attention_f32(self._pv(q), c_long(q.stride(0)), self._pv(k), c_long(k.stride(0)), self._pv(v),
+                                                  c_long(v.stride(0)), self._p(out), c_long(D), self._p(mask), self._p(row_all_masked),
+                                                  self._p(ws), B, Lq, Lk, heads, 32, self._stream())
+            self._check(rc, "psalm_mha_attention_f32")
+            return out
         rc = self.lib.psalm_mha_attention(self._pv(q), c_long(q.stride(0)), self._pv(k), c_long(k.stride(0)), self._pv(v),
                                           c_long(v.stride(0)), self._p(out), c_long(D), _dt(q), self._p(mask),
                                           self._p(row_all_masked), B, Lq, Lk, heads, 32, self._stream())

@@ -450,3 +450,30 @@ def test_resize_and_layout(ops):
     assert torch.equal(nhwc.view(2, 5, 6), t.transpose(1, 2))
     back = ops.permute_layout(nhwc.to(ops.device), 2, 6, 5, False).cpu()
     assert torch.equal(back, t)
+
+
+@pytest.mark.parametrize("Lq,Lk,masked", [(100, 1024, True), (100, 100, False), (37, 203, True), (128, 700, True), (12, 64, True)])
+def test_mha_attention_f32_matrix_core_split_kv(ops, Lq, Lk, masked):
+    """fp32 matrix-core MHA (psalm_mha_attention_f32: 256-key chunks, partial softmax states merged by the combine kernel) vs torch fp32."""
+    B, heads, hd = 2, 4, 32
+    D = heads * hd
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B * Lq, D + 8, generator=g)
+    kv = torch.randn(B * Lk, 2 * D + 4, generator=g)
+    qq, kk, vv = q[:, 8:8 + D], kv[:, :D], kv[:, D + 4:]
+    mask = flags = None
+    a = (qq.view(B, Lq, heads, hd).transpose(1, 2) * hd ** -0.5) @ kk.reshape(B, Lk, heads, hd).transpose(1, 2).transpose(-2, -1)
+    if masked:
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.6
+        mask[0, 1, :] = True                                       # an all-masked row: flagged -> attends everywhere (TD:647)
+        mask[1, 2, : Lk - 3] = True                                # a row whose only visible keys sit in the last chunk
+        flags = mask.all(-1)
+        wm = mask.clone()
+        wm[flags] = False
+        a = a.masked_fill(wm[:, None], float("-inf"))
+    want = (a.softmax(-1) @ vv.reshape(B, Lk, heads, hd).transpose(1, 2)).transpose(1, 2).reshape(B * Lq, D)
+    d = ops.device
+    qd, kvd = q.to(d), kv.to(d)
+    got = ops.mha_attention(qd[:, 8:8 + D], kvd[:, :D], kvd[:, D + 4:], B, Lq, Lk, heads,
+                            mask.to(torch.uint8).to(d) if masked else None, flags.to(torch.uint8).to(d) if masked else None).cpu()
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max()
