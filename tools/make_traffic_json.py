@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_hbm_traffic.json from the per-kernel PMC summary written by tools/rocpd_pmc.py (--json):
+"""profiles/rNN_pmc_hbm_traffic.json from the per-kernel PMC summary written by tools/rocpd_pmc.py (--json):
 
     python tools/make_traffic_json.py gpurun_out/final_pmc.json profiles/r01_pmc_hbm_traffic.json [source-label]
 
@@ -17,10 +17,12 @@ def bench_name(rk):
         a = [x.strip() for x in m.group(1).split(",")]
         tc = "bf16" if a[0] == "unsigned short" else "f32"
         conv = len(a) > 6 and a[6] == "true"
-        return f"gemm_bf16_glds_kernel<{tc},{a[1]},{a[2]},{a[3]},{a[4]}{',conv' if conv else ''}>"
+        x3 = len(a) > 10 and a[10] == "true"                       # split-f16 variant (template parameter X3)
+        return f"gemm_bf16_glds_kernel<{tc},{a[1]},{a[2]},{a[3]},{a[4]}{',conv' if conv else ''}{',x3' if x3 else ''}>"
     m = re.search(r"gemm_bf16_skinny_kernel<([^>]*)>", rk)
     if m:
-        return f"gemm_bf16_skinny_kernel<{'bf16' if m.group(1).strip() == 'unsigned short' else 'f32'}>"
+        a = [x.strip() for x in m.group(1).split(",")]
+        return f"gemm_bf16_skinny_kernel<{'bf16' if a[0] == 'unsigned short' else 'f32'}{',x3' if len(a) > 1 and a[1] == 'true' else ''}>"
     m = re.search(r"(\w+)<", rk) or re.search(r"(\w+)\(", rk)
     return m.group(1) if m else rk
 
