@@ -352,23 +352,27 @@ __global__ void __launch_bounds__(QT) causal_attention_kernel(const T* __restric
 // (lane (q, hi) holds keys (r&3) + 8(r>>2) + 4hi, r = 0..15) is used as the key order of the second product -- step r contracts keys
 // {.. + 0, .. + 4}; V^T is read from LDS in the same order.  Likewise the first product contracts head dims in the order
 // d = 32 hi + s (step s = 0..31), so both K fragments and V^T fragments are contiguous 16-byte LDS reads.
-// Block = 4 wavefronts = 128 consecutive queries sharing the K / V tiles (RoPE applied to K while staging; V transposed while staging).
-template <int HD, int ROT>
-__global__ void __launch_bounds__(256) causal_attention_f32_mfma_kernel(const float* __restrict__ base, long ld, int q_off, int k_off,
+// Block = NW wavefronts = 32 NW consecutive queries sharing the K / V tiles (RoPE applied to K while staging; V transposed while staging).
+// K / V tiles are double-buffered: the next tile's global loads are issued before the current tile's 64 MFMAs and land in LDS after them
+// (one barrier per tile) -- with single-buffered staging the exposed load latency was 1.5x the MFMA time per tile (r02e: 134 us per layer).
+// Causal work grows with the query index: blocks are issued last query tile first.  (Tried r02: 2-wave blocks, several per CU -- slower,
+// 189 us: twice the staging traffic and no better balance, since all blocks are resident from the start.)
+template <int HD, int ROT, int NW>
+__global__ void __launch_bounds__(64 * NW) causal_attention_f32_mfma_kernel(const float* __restrict__ base, long ld, int q_off, int k_off,
                                                                         int v_off, float* out, long ldo, int o_off,
                                                                         const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                                         const unsigned char* __restrict__ key_mask, int L, int heads,
                                                                         float scale) {
-    static_assert(HD == 64 && ROT == 32, "Phi-1.5 geometry");
+    static_assert(HD == 64 && ROT == 32 && NW == 4, "Phi-1.5 geometry; 256 threads stage one 32-key tile in one pass");
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int KT = 32, KS = HD + 4, VS = KT + 4, half = ROT / 2;   // padded LDS row strides (floats): conflict-free ds_read_b128
-    __shared__ __attribute__((aligned(16))) float Ks[KT * KS];           // [key][d]
-    __shared__ __attribute__((aligned(16))) float Vt[HD * VS];           // [d][key]
-    __shared__ unsigned char Ms[KT];
+    __shared__ __attribute__((aligned(16))) float Ks[2][KT * KS];        // [key][d]   double-buffered: tile kt+1 is fetched (global ->
+    __shared__ __attribute__((aligned(16))) float Vt[2][HD * VS];        // [d][key]   registers) before tile kt's MFMAs and written after
+    __shared__ unsigned char Ms[2][KT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;      // heaviest (last) query tiles first
     const long tok0 = (long)b * L;
-    const int q0 = qt * 128 + wave * 32;                                 // this wave's first query
+    const int q0 = qt * (32 * NW) + wave * 32;                           // this wave's first query
     const int qi = q0 + n32;                                             // this lane's query column
     // ---- Q: lane (q, hi) holds (RoPE'd, scaled) Q[q][32 hi + s], s = 0..31
     float qv[32];
@@ -396,89 +400,101 @@ __global__ void __launch_bounds__(256) causal_attention_f32_mfma_kernel(const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -3.0e38f, l = 0.f;
-    const int last_q = min(L - 1, qt * 128 + 127);
+    const int last_q = min(L - 1, qt * (32 * NW) + 32 * NW - 1);
     const int ntiles = last_q / KT + 1;                                  // key tiles the block's last query can see
+    // staging: thread -> key tid/8 of the tile, head dims 8 (tid%8) .. +7
+    const int sr = tid >> 3, sc0 = (tid & 7) * 8;
+    float kv[8], vv[8], ko[8], cs8[8], sn8[8];
+    unsigned char mk = 0;
+    auto fetch = [&](int kt) {                                           // global -> registers (all loads unconditional, row clamped)
+        const int kj = min(kt * KT + sr, L - 1);
+        const float* p = base + (tok0 + kj) * ld;
+        ld8(p + k_off + h * HD + sc0, kv);
+        ld8(p + v_off + h * HD + sc0, vv);
+        const int cr = sc0 < ROT ? sc0 : 0;                               // (non-rotary threads fetch a valid dummy: results unused)
+        ld8(p + k_off + h * HD + (cr < half ? cr + half : cr - half), ko);
+        ld8(cosT + (long)kj * ROT + cr, cs8);
+        ld8(sinT + (long)kj * ROT + cr, sn8);
+        if (tid < KT) { const int kk = kt * KT + tid; mk = key_mask[(long)b * L + min(kk, L - 1)] && kk < L; }
+    };
+    auto stage = [&](int buf) {                                          // registers -> LDS (RoPE on K, V transposed)
+        if (sc0 < ROT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kv[i] = kv[i] * cs8[i] + (sc0 < half ? -ko[i] : ko[i]) * sn8[i];
+        }
+        *reinterpret_cast<psalm_f32x4*>(&Ks[buf][sr * KS + sc0]) = psalm_f32x4{kv[0], kv[1], kv[2], kv[3]};
+        *reinterpret_cast<psalm_f32x4*>(&Ks[buf][sr * KS + sc0 + 4]) = psalm_f32x4{kv[4], kv[5], kv[6], kv[7]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Vt[buf][(sc0 + i) * VS + sr] = vv[i];
+        if (tid < KT) Ms[buf][tid] = mk;
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();                                                 // everyone done with the previous tile
-        {   // ---- stage K (RoPE) and V^T: thread -> key tid/8, head dims 8 (tid%8) .. +7
-            const int r = tid >> 3, c0 = (tid & 7) * 8;
-            const int kj = min(kt * KT + r, L - 1);
-            const float* p = base + (tok0 + kj) * ld;
-            float kv[8], vv[8], ko[8];
-            ld8(p + k_off + h * HD + c0, kv);
-            ld8(p + v_off + h * HD + c0, vv);
-            if (c0 < ROT) {
-                ld8(p + k_off + h * HD + (c0 < half ? c0 + half : c0 - half), ko);
-                const float* cs = cosT + (long)kj * ROT + c0;
-                const float* sn = sinT + (long)kj * ROT + c0;
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) fetch(kt + 1);                              // in flight during this tile's 64 MFMAs
+        if (kt * KT <= min(q0 + 31, L - 1)) {                            // (else: tile entirely above this wave's diagonal; wave-uniform)
+            // ---- S^T = K . Q^T
+            f32x16 sacc;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) kv[i] = kv[i] * cs[i] + (c0 < half ? -ko[i] : ko[i]) * sn[i];
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            {
+                const float* kp = &Ks[buf][n32 * KS + 32 * hi];
+#pragma unroll
+                for (int c = 0; c < 32; c += 4) {
+                    const psalm_f32x4 kf = *reinterpret_cast<const psalm_f32x4*>(kp + c);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qv[c], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qv[c + 1], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qv[c + 2], sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv[c + 3], sacc, 0, 0, 0);
+                }
             }
-            *reinterpret_cast<psalm_f32x4*>(&Ks[r * KS + c0]) = psalm_f32x4{kv[0], kv[1], kv[2], kv[3]};
-            *reinterpret_cast<psalm_f32x4*>(&Ks[r * KS + c0 + 4]) = psalm_f32x4{kv[4], kv[5], kv[6], kv[7]};
+            // ---- mask + online softmax of this lane's query column (16 of its 32 keys here, the other 16 in lane ^ 32)
+            float mc = -3.0e38f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Vt[(c0 + i) * VS + r] = vv[i];
-            if (tid < KT) { const int kk = kt * KT + tid; Ms[tid] = kk < L ? key_mask[(long)b * L + kk] : 0; }
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = (kt * KT + j <= qi) && Ms[buf][j];
+                sacc[r] = ok ? sacc[r] : -3.0e38f;
+                mc = fmaxf(mc, sacc[r]);
+            }
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            const float mn = fmaxf(m, mc);
+            const float alpha = __expf(m - mn);                          // m = mn = -3e38 (nothing visible yet): exp(0) = 1, harmless
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
+                sacc[r] = p;
+                psum += p;
+            }
+            psum += __shfl_xor(psum, 32);
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // ---- O^T += V^T . P^T   (step r contracts keys (r&3) + 8(r>>2) + {0, 4}: exactly what lane (q, hi) holds in sacc[r])
+            {
+                const float* v0 = &Vt[buf][n32 * VS + 4 * hi];
+                const float* v1 = &Vt[buf][(32 + n32) * VS + 4 * hi];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const psalm_f32x4 a0 = *reinterpret_cast<const psalm_f32x4*>(v0 + 8 * g);
+                    const psalm_f32x4 a1 = *reinterpret_cast<const psalm_f32x4*>(v1 + 8 * g);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, sacc[4 * g], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, sacc[4 * g], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, sacc[4 * g + 1], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, sacc[4 * g + 1], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, sacc[4 * g + 2], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, sacc[4 * g + 2], o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, sacc[4 * g + 3], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, sacc[4 * g + 3], o1, 0, 0, 0);
+                }
+            }
         }
+        if (kt + 1 < ntiles) stage(buf ^ 1);       // the other buffer: last read in tile kt-1, which every wave left at the previous barrier
         __syncthreads();
-        if (kt * KT > min(q0 + 31, L - 1)) continue;                     // tile entirely above this wave's diagonal (wave-uniform)
-        // ---- S^T = K . Q^T
-        f32x16 sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        {
-            const float* kp = &Ks[n32 * KS + 32 * hi];
-#pragma unroll
-            for (int c = 0; c < 32; c += 4) {
-                const psalm_f32x4 kf = *reinterpret_cast<const psalm_f32x4*>(kp + c);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qv[c], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qv[c + 1], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qv[c + 2], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qv[c + 3], sacc, 0, 0, 0);
-            }
-        }
-        // ---- mask + online softmax of this lane's query column (16 of its 32 keys here, the other 16 in lane ^ 32)
-        float mc = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool ok = (kt * KT + j <= qi) && Ms[j];
-            sacc[r] = ok ? sacc[r] : -3.0e38f;
-            mc = fmaxf(mc, sacc[r]);
-        }
-        mc = fmaxf(mc, __shfl_xor(mc, 32));
-        const float mn = fmaxf(m, mc);
-        const float alpha = __expf(m - mn);                              // m = mn = -3e38 (nothing visible yet): exp(0) = 1, harmless
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
-            sacc[r] = p;
-            psum += p;
-        }
-        psum += __shfl_xor(psum, 32);
-        l = l * alpha + psum;
-        m = mn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        // ---- O^T += V^T . P^T   (step r contracts keys (r&3) + 8(r>>2) + {0, 4}: exactly what lane (q, hi) holds in sacc[r])
-        {
-            const float* v0 = &Vt[n32 * VS + 4 * hi];
-            const float* v1 = &Vt[(32 + n32) * VS + 4 * hi];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const psalm_f32x4 a0 = *reinterpret_cast<const psalm_f32x4*>(v0 + 8 * g);
-                const psalm_f32x4 a1 = *reinterpret_cast<const psalm_f32x4*>(v1 + 8 * g);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, sacc[4 * g], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, sacc[4 * g], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, sacc[4 * g + 1], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, sacc[4 * g + 1], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, sacc[4 * g + 2], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, sacc[4 * g + 2], o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, sacc[4 * g + 3], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, sacc[4 * g + 3], o1, 0, 0, 0);
-            }
-        }
     }
     if (qi < L) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -501,7 +517,7 @@ extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q
     const float scale = 1.0f / sqrtf((float)head_dim);
     if (dtype == PSALM_F32 && ld % 4 == 0 && ldo % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && o_off % 4 == 0 &&
         (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {          // fp32 matrix-core kernel (16-byte accesses)
-        hipLaunchKernelGGL((causal_attention_f32_mfma_kernel<64, 32>), dim3(cdiv(L, 128), heads, B), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((causal_attention_f32_mfma_kernel<64, 32, 4>), dim3(cdiv(L, 128), heads, B), dim3(256), 0, (hipStream_t)stream,
                            (const float*)qkv, ld, q_off, k_off, v_off, (float*)out, ldo, o_off, cos_table, sin_table, key_mask, L,
                            heads, scale);
         PSALM_LAUNCH_END("psalm_causal_attention");

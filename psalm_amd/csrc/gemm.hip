@@ -996,6 +996,56 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
             epilogue_store<TC>(g, acc[i][j], bm + wm * (BM / 2) + i * 32, bn + wn * 64 + j * 32 + (lane & 31), lane);
 }
 
+// ---- exact-fp32 skinny GEMM (M <= 192): the latency-bound M = 100 GEMMs of the mask decoder in the fp32 / f16x3 modes.  Same shape as
+// the bf16 skinny kernel (block = one 32 x 32 output tile, 4 wavefronts split K, fragments straight from global / L2, no K-loop barrier),
+// on v_mfma_f32_32x32x2_f32.  Lane (n, hi) contracts k = 8 c + 4 hi + i in step i of chunk c, so A and W fragments are 16-byte loads.
+// In the f16x3 mode this replaces split + split-f16 skinny GEMM (two launches, ~15 us) for these ~100 tiny GEMMs per image.
+template <typename TC>
+__global__ void __launch_bounds__(256) gemm_f32_skinny_kernel(GemmArgs g) {
+    __shared__ float part[3][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
+    const float* A = (const float*)g.A + (long)min(bm + n32, g.M - 1) * g.lda + 4 * hi;
+    const float* W = (const float*)g.W + (long)min(bn + n32, g.N - 1) * g.ldw + 4 * hi;
+    const int chunks = g.K / 8, cpw = (chunks + 3) / 4;
+    const int c_lo = wave * cpw, c_hi = min(chunks, c_lo + cpw);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int c = c_lo;
+    auto group = [&](auto NT_) {
+        constexpr int NT = decltype(NT_)::value;
+        f32x4_g fa_[NT], fb_[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            fa_[i] = *reinterpret_cast<const f32x4_g*>(A + (long)(c + i) * 8);
+            fb_[i] = *reinterpret_cast<const f32x4_g*>(W + (long)(c + i) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // all loads of the group in flight before the first MFMA waits
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].x, fb_[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].y, fb_[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].z, fb_[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].w, fb_[i].w, acc, 0, 0, 0);
+        }
+        c += NT;
+    };
+    while (c + 8 <= c_hi) group(std::integral_constant<int, 8>{});
+    if (c + 4 <= c_hi) group(std::integral_constant<int, 4>{});
+    while (c < c_hi) group(std::integral_constant<int, 1>{});
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += part[0][r * 64 + lane] + part[1][r * 64 + lane] + part[2][r * 64 + lane];
+        epilogue_store<TC>(g, acc, bm, bn + n32, lane);
+    }
+}
+
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
 // (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
 static int g_tile_policy = 0;
@@ -1255,6 +1305,13 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
         return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, s);
     }
 
+    if (a_dtype == PSALM_F32 && w_dtype == PSALM_F32 && M <= 192 && N <= 8192 && K % 8 == 0 && !g_tile_policy) {
+        // ---- exact-fp32 skinny path (mask-decoder GEMMs with M = 100 query rows in the fp32 / f16x3 modes)
+        const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<float>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g);
+        PSALM_LAUNCH_END("psalm_gemm");
+    }
     // ---- register-staged path (fp32 activations converted on the fly, odd K, or exact fp32 arithmetic)
     g.tiles_n = cdiv(N, 128);
     // 128-row tiles unless that leaves the 256 CUs under-filled
@@ -1452,12 +1509,64 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
     }
 }
 
+// Few, long rows (Phi: 899 tokens x 2048 / 10240 columns): a whole 256-thread block per row -- one wavefront per row was a 20-iteration
+// dependent load loop on 899 wavefronts (r02e: ~14 us per launch, 2.6 ms per image).
+__global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
+                                                            float* __restrict__ inv_scale, int K, int Kp) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    float amax = 0.f;
+    for (int c = tid * 8; c < K; c += 2048) {
+        float v[8];
+        load8_f32(xr + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+    const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+    if (tid == 0) inv_scale[row] = inv;
+    unsigned short* orow = out + row * ldo;
+    for (int c = tid * 8; c < Kp; c += 2048) {
+        float v[8];
+        if (c < K) load8_f32(xr + c, v);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = v[2 * k] * sc, a1 = v[2 * k + 1] * sc;
+            const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+            const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+            hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        *reinterpret_cast<u32x4_s*>(orow + c) = u32x4_s{hw[0], hw[1], hw[2], hw[3]};
+        *reinterpret_cast<u32x4_s*>(orow + Kp + c) = u32x4_s{lw[0], lw[1], lw[2], lw[3]};
+    }
+}
+
 extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream) {
     if (rows == 0) return 0;
     const int Kp = (K + 63) / 64 * 64;
     PSALM_CHECK_ARG(K > 0 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0, "psalm_split_f16: K % 8 == 0, 16-byte aligned input rows");
     PSALM_CHECK_ARG((uintptr_t)out % 16 == 0 && (ldo * 2) % 16 == 0 && ldo >= 2L * Kp, "psalm_split_f16: output rows of >= 2*ceil64(K) f16, 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (Kp >= 1024 && rows <= 4096) {
+        hipLaunchKernelGGL(split_f16_row_kernel, dim3(rows), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, K, Kp);
+        PSALM_LAUNCH_END("psalm_split_f16");
+    }
     if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
     else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
     else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);

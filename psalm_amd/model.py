@@ -202,8 +202,12 @@ class PSALM:
         t = self._aligned(t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device))
         return self.ops.split_f16(t) if self.x3 else t      # f16x3: split once at load time ([hi | lo] f16 + per-row scales)
 
+    def _Ws(self, t):                     # weight of a GEMM whose M is the ~100 decoder queries / a handful of prompt rows: in the f16x3 mode
+        #                                   these stay fp32 and run on the exact-fp32 skinny kernel (no split launch, latency-bound anyway)
+        return self._aligned(t.detach().to(torch.float32).contiguous().to(self.wdt).to(self.device))
+
     def _wop(self, t):                    # an ACTIVATION used as the W operand of a GEMM (mask features, class embeddings, ...)
-        return self.ops.split_f16(t) if self.x3 and t is not None else t
+        return self.ops.split_f16(t) if self.x3 and t is not None and t.shape[0] > 4096 else t
 
     def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
         return self._aligned(t.detach().to(torch.float32).contiguous().to(self.device))
@@ -212,8 +216,8 @@ class PSALM:
         cfg, w = self.cfg, self.w
         W, Fp = self._W, self._F
 
-        def lin(dst, src, bias=True):
-            w[dst + ".w"] = W(sd[src + ".weight"])
+        def lin(dst, src, bias=True, small=False):
+            w[dst + ".w"] = (self._Ws if small else W)(sd[src + ".weight"])
             if bias and (src + ".bias") in sd:
                 w[dst + ".b"] = Fp(sd[src + ".bias"])
 
@@ -292,7 +296,7 @@ class PSALM:
 
         # ---- LLM -> decoder projectors
         for n in ("seg_query_projector", "SEG_token_projector", "class_name_projector", "region_projector"):
-            lin(n, n)
+            lin(n, n, small=True)
 
         # ---- pixel decoder
         pd = "pixel_decoder."
@@ -327,18 +331,18 @@ class PSALM:
         for i in range(nl):
             c = f"{pr}transformer_cross_attention_layers.{i}."
             Wi, bi = sd[c + "multihead_attn.in_proj_weight"], sd[c + "multihead_attn.in_proj_bias"]
-            w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"] = W(Wi[:D]), Fp(bi[:D])
-            lin(f"pr{i}.co", c + "multihead_attn.out_proj")
+            w[f"pr{i}.cq.w"], w[f"pr{i}.cq.b"] = self._Ws(Wi[:D]), Fp(bi[:D])
+            lin(f"pr{i}.co", c + "multihead_attn.out_proj", small=True)
             norm(f"pr{i}.cn", c + "norm")
             s_ = f"{pr}transformer_self_attention_layers.{i}."
             Ws, bs = sd[s_ + "self_attn.in_proj_weight"], sd[s_ + "self_attn.in_proj_bias"]
-            w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"] = W(Ws[:2 * D]), Fp(bs[:2 * D])
-            w[f"pr{i}.sv.w"], w[f"pr{i}.sv.b"] = W(Ws[2 * D:]), Fp(bs[2 * D:])
-            lin(f"pr{i}.so", s_ + "self_attn.out_proj")
+            w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"] = self._Ws(Ws[:2 * D]), Fp(bs[:2 * D])
+            w[f"pr{i}.sv.w"], w[f"pr{i}.sv.b"] = self._Ws(Ws[2 * D:]), Fp(bs[2 * D:])
+            lin(f"pr{i}.so", s_ + "self_attn.out_proj", small=True)
             norm(f"pr{i}.sn", s_ + "norm")
             f_ = f"{pr}transformer_ffn_layers.{i}."
-            lin(f"pr{i}.f1", f_ + "linear1")
-            lin(f"pr{i}.f2", f_ + "linear2")
+            lin(f"pr{i}.f1", f_ + "linear1", small=True)
+            lin(f"pr{i}.f2", f_ + "linear2", small=True)
             norm(f"pr{i}.fn", f_ + "norm")
         # cross-attention K / V projections of all layers that read level l, stacked: one GEMM per level
         for l in range(nlev):
@@ -355,7 +359,7 @@ class PSALM:
         w["pr.level_embed"] = Fp(sd[pr + "level_embed.weight"])
         for name, n in (("mask_embed", 3), ("SEG_proj", 2), ("CLASS_proj", 2), ("REGION_proj", 2)):
             for j in range(n):
-                lin(f"pr.{name}{j}", f"{pr}{name}.layers.{j}")
+                lin(f"pr.{name}{j}", f"{pr}{name}.layers.{j}", small=True)
 
     # ======================================================================================= small host tables
     def _pos_embed(self, Hh, Ww):

@@ -370,3 +370,20 @@ def test_gemm_x3_flag_routes_fp32_gemms(ops):
         ops.x3 = False
     assert torch.equal(got, want)
     assert (got - exact).abs().max() < 1e-4 and (gb - exact).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,cd,has_res,act", [(100, 256, 256, "f32", True, H.ACT_RELU), (134, 256, 2048, "f32", False, H.ACT_NONE),
+                                                   (100, 2048, 256, "bf16", False, H.ACT_RELU), (3, 100, 256, "f32", False, H.ACT_NONE),
+                                                   (192, 40, 72, "f32", True, H.ACT_GELU), (100, 134, 264, "f32", False, H.ACT_NONE)])
+def test_gemm_f32_skinny_exact(ops, M, N, K, cd, has_res, act):
+    """Exact-fp32 skinny kernel (M <= 192, fp32 operands): the mask decoder's M = 100 GEMMs in the fp32 / f16x3 modes."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01
+    w = torch.randn(N, K, generator=g) * 0.5 - torch.arange(N)[:, None] * 0.003
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(DT[cd]) if has_res else None
+    want = _ref(a, w, bias, res.float() if has_res else None, act, 0)
+    d = ops.device
+    got = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d) if has_res else None, act, 0, out_dtype=DT[cd]).cpu().double()
+    tol = (2 ** -8 if cd == "bf16" else 4e-6) * want.abs().max().item() + 1e-6
+    assert (got - want).abs().max().item() <= tol
