@@ -141,6 +141,14 @@ int psalm_mha_attention_f32(const float* q, long ldq, const float* k, long ldk, 
                             const unsigned char* mask, const unsigned char* row_all_masked, void* workspace, int B, int Lq, int Lk, int heads,
                             int head_dim, void* stream);
 
+/* Phi prefill attention (modeling_phi.py:189-245; eager softmax :137-160; partial RoPE :92-122) for fp32 buffers on the fp32 matrix cores,
+ * split over keys inside a block (fp32 / f16x3 modes).  Operands as psalm_causal_attention + a 16-byte aligned workspace of
+ * psalm_causal_attention_f32_workspace(B, L, heads) bytes (RoPE'd Q / K and the padded key mask). */
+long psalm_causal_attention_f32_workspace(int B, int L, int heads);
+int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
+                               const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace, int B, int L,
+                               int heads, int head_dim, int rot, void* stream);
+
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;

@@ -507,6 +507,204 @@ __global__ void __launch_bounds__(64 * NW) causal_attention_f32_mfma_kernel(cons
     }
 }
 
+// ---- key-split form (the one psalm_causal_attention_f32 launches).  The kernel above gives one wavefront ALL key tiles of its 32 queries:
+// the last query tile walks 29 tiles alone while 255 other CUs have long finished (r02e/f: 129 us per layer, 4.4 us per tile against
+// 1.7 us of MFMA -- one wave per SIMD, nothing to overlap LDS / exp latencies with).  Here a BLOCK owns one 32-query tile and its 4
+// wavefronts take every 4th key tile (critical path 8 tiles instead of 29; 928 blocks of graded size, heaviest first, two resident per
+// CU), each keeping a private online-softmax state that is merged through LDS at the end.  No tile is shared between wavefronts, so K
+// and V^T fragments are read straight from global / L2 (K rows and V rows are contiguous 128 / 256 B per lane group); RoPE, the 1/sqrt(d)
+// scale and the padded key mask come from a small pre-pass (phi_rope_prep_f32_kernel) into the caller's workspace.
+__global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __restrict__ base, long ld, int q_off, int k_off,
+                                                                const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                                const unsigned char* __restrict__ key_mask, float* __restrict__ Qr,
+                                                                float* __restrict__ Kr, unsigned char* __restrict__ Mk, int L, int Lp, int heads,
+                                                                float scale) {
+    constexpr int HD = 64, ROT = 32, half = 16;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 32 + (threadIdx.x >> 3), c0 = (threadIdx.x & 7) * 8;     // token, 8-wide head-dim chunk
+    if (t >= Lp) return;
+    float* qd = Qr + (((long)b * heads + h) * Lp + t) * HD + c0;
+    float* kd = Kr + (((long)b * heads + h) * Lp + t) * HD + c0;
+    if (h == 0 && c0 == 0) Mk[(long)b * Lp + t] = t < L ? (key_mask[(long)b * L + t] ? 1 : 0) : 0;
+    float q[8], k[8];
+    if (t < L) {
+        const float* p = base + ((long)b * L + t) * ld;
+        ld8(p + q_off + h * HD + c0, q);
+        ld8(p + k_off + h * HD + c0, k);
+        if (c0 < ROT) {
+            float qo[8], ko[8], cs[8], sn[8];
+            const int oc = c0 < half ? c0 + half : c0 - half;
+            ld8(p + q_off + h * HD + oc, qo);
+            ld8(p + k_off + h * HD + oc, ko);
+            ld8(cosT + (long)t * ROT + c0, cs);
+            ld8(sinT + (long)t * ROT + c0, sn);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                q[i] = q[i] * cs[i] + (c0 < half ? -qo[i] : qo[i]) * sn[i];
+                k[i] = k[i] * cs[i] + (c0 < half ? -ko[i] : ko[i]) * sn[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] *= scale;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { q[i] = 0.f; k[i] = 0.f; }
+    }
+    st8(qd, q);
+    st8(kd, k);
+}
+
+__global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr,
+                                                                          const unsigned char* __restrict__ Mk, const float* __restrict__ base,
+                                                                          long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
+                                                                          int heads) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int HD = 64, OS = HD + 4;
+    __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
+    __shared__ float Ml[4][2][32];                                        // per-wave (m, l) per query
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;      // heaviest (last) query tiles first
+    const long bh = (long)b * heads + h;
+    const int qi = qt * 32 + n32;                                         // this lane's query column (row qi < Lp of Qr)
+    float qv[32];
+    {
+        const float* p = Qr + (bh * Lp + qi) * HD + 32 * hi;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const psalm_f32x4 t = *reinterpret_cast<const psalm_f32x4*>(p + c);
+            qv[c] = t.x; qv[c + 1] = t.y; qv[c + 2] = t.z; qv[c + 3] = t.w;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const float* vbase = base + (long)b * L * ld + v_off + h * HD + n32;
+    for (int kt = wave; kt <= qt; kt += 4) {                              // key tiles 0..qt (the diagonal tile is qt)
+        // ---- fragments of this tile, all loads issued up front (rows clamped: padded keys are masked below)
+        psalm_f32x4 kf[8];
+        {
+            const float* kp = Kr + (bh * Lp + kt * 32 + n32) * HD + 32 * hi;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kf[c] = reinterpret_cast<const psalm_f32x4*>(kp)[c];
+        }
+        float va[16], vb[16];                                             // V^T fragments: step r = 4g + i contracts key 8g + 4hi + i
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* vp = vbase + (long)min(kt * 32 + 8 * g + 4 * hi + i, L - 1) * ld;
+                va[4 * g + i] = vp[0];
+                vb[4 * g + i] = vp[32];
+            }
+        unsigned mw[4];                                                   // key-valid bytes of keys 8g + 4hi .. +3
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mw[g] = *reinterpret_cast<const unsigned*>(Mk + (long)b * Lp + kt * 32 + 8 * g + 4 * hi);
+        // ---- S^T = K . Q^T
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].x, qv[4 * c], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].y, qv[4 * c + 1], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qv[4 * c + 2], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qv[4 * c + 3], sacc, 0, 0, 0);
+        }
+        float mc = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = (kt * 32 + j <= qi) && ((mw[r >> 2] >> (8 * (r & 3))) & 0xffu);
+            sacc[r] = ok ? sacc[r] : -3.0e38f;
+            mc = fmaxf(mc, sacc[r]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
+            sacc[r] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32);
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], sacc[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], sacc[r], o1, 0, 0, 0);
+        }
+    }
+    // ---- merge the 4 key-interleaved states: O = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M)
+    {
+        float* ow = &Os[wave][n32 * OS + 4 * hi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                    // rows d = 8g + 4hi + {0..3} (+32 for the second d-tile)
+            *reinterpret_cast<psalm_f32x4*>(ow + 8 * g) = psalm_f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+            *reinterpret_cast<psalm_f32x4*>(ow + 32 + 8 * g) = psalm_f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+        }
+        if (hi == 0) { Ml[wave][0][n32] = m; Ml[wave][1][n32] = l; }
+    }
+    __syncthreads();
+    {
+        const int q = tid >> 3, d0 = (tid & 7) * 8;                       // thread -> query q of the tile, 8 head dims
+        const int tq = qt * 32 + q;
+        if (tq < L) {
+            float M = -3.0e38f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) M = fmaxf(M, Ml[w][0][q]);
+            float Lsum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float mw_ = Ml[w][0][q];
+                const float f = mw_ > -1.0e38f ? __expf(mw_ - M) : 0.f;
+                Lsum += Ml[w][1][q] * f;
+                const psalm_f32x4 a = *reinterpret_cast<const psalm_f32x4*>(&Os[w][q * OS + d0]);
+                const psalm_f32x4 c = *reinterpret_cast<const psalm_f32x4*>(&Os[w][q * OS + d0 + 4]);
+                acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
+                acc[4] += c.x * f; acc[5] += c.y * f; acc[6] += c.z * f; acc[7] += c.w * f;
+            }
+            const float inv = Lsum > 0.f ? 1.f / Lsum : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] *= inv;
+            st8(out + ((long)b * L + tq) * ldo + o_off + h * HD + d0, acc);
+        }
+    }
+}
+
+extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
+    const long Lp = (L + 31) / 32 * 32;
+    return 2L * B * heads * Lp * 64 * (long)sizeof(float) + (long)B * Lp + 64;
+}
+
+// Phi prefill attention for fp32 buffers, same operands as psalm_causal_attention + a workspace of psalm_causal_attention_f32_workspace
+// bytes (16-byte aligned).  head_dim 64, rotary dim 32; column offsets / row strides multiples of 4 elements.
+extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
+                                          const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
+                                          int B, int L, int heads, int head_dim, int rot, void* stream) {
+    PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_f32: head_dim 64, rotary dim 32 (Phi-1.5)");
+    PSALM_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && o_off % 4 == 0 &&
+                        (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0,
+                    "psalm_causal_attention_f32: 16-byte aligned rows / offsets and a workspace");
+    if (B == 0 || L == 0) return 0;
+    const int Lp = (L + 31) / 32 * 32;
+    float* Qr = (float*)workspace;
+    float* Kr = Qr + (long)B * heads * Lp * 64;
+    unsigned char* Mk = (unsigned char*)(Kr + (long)B * heads * Lp * 64);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(phi_rope_prep_f32_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, cos_table, sin_table, key_mask,
+                       Qr, Kr, Mk, L, Lp, heads, scale);
+    hipLaunchKernelGGL(causal_attention_f32_splitk_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
+                       (const unsigned char*)Mk, qkv, ld, v_off, out, ldo, o_off, L, Lp, heads);
+    PSALM_LAUNCH_END("psalm_causal_attention_f32");
+}
+
 extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,
                                       int o_off, const float* cos_table, const float* sin_table,
                                       const unsigned char* key_mask, int B, int L, int heads, int head_dim, int rot,

@@ -434,6 +434,19 @@ class Ops:
                                                       self._p(ws), B, L, heads, head_dim, rot, self._stream())
             self._check(rc, "psalm_causal_attention_mfma")
             return out
+        if (buf.dtype == torch.float32 and head_dim == 64 and rot == 32 and buf.stride(0) % 4 == 0 and out.stride(0) % 4 == 0
+                and all(v % 4 == 0 for v in (q_off, k_off, v_off, o_off)) and buf.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+            self.lib.psalm_causal_attention_f32_workspace.restype = c_long      # fp32 matrix-core kernel, key-split inside the block
+            nbytes = self.lib.psalm_causal_attention_f32_workspace(B, L, heads)
+            key = ("causal_f32_ws", nbytes)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            rc = self.lib.psalm_causal_attention_f32(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out),
+                                                     c_long(out.stride(0)), o_off, self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
+                                                     B, L, heads, head_dim, rot, self._stream())
+            self._check(rc, "psalm_causal_attention_f32")
+            return out
         rc = self.lib.psalm_causal_attention(self._pv(buf), _dt(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out),
                                              c_long(out.stride(0)), o_off, self._p(cos), self._p(sin), self._p(key_mask), B, L,
                                              heads, head_dim, rot, self._stream())
