@@ -55,3 +55,84 @@ def test_two_rank_broadcast_shard_reduce():
     assert all(r[2] == expect_bytes for r in res)
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]          # round-robin, disjoint, complete
     assert res[0][4] == res[1][4] == [7.0, 21.0, 2.0]
+
+
+def _worker_real_model(rank, world, port, q):
+    """Real tiny PSALM on each rank (kernels in the host emulator), weights built from DIFFERENT seeds, then overwritten by rank 0's
+    through broadcast_weights -- in both weight layouts (plain fp32 tensors and the f16x3 mode's split-f16 pairs) -- and each rank runs
+    eval_seg on ITS shard of the images; the per-rank IoU meters are combined by the all-reduce."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "emu")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ops_backend import make_ops
+    from psalm_amd import evalout as E
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.dist import broadcast_weights, shard_indices
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    ops = make_ops("emu")
+    cfg = PsalmConfig.tiny("referring")
+    out = {"rank": rank}
+    for precision in ("fp32", "f16x3"):
+        model = PSALM(cfg, make_state_dict(cfg, seed=100 + rank), ops=ops, precision=precision)        # different weights per rank
+        nbytes, _ = broadcast_weights(model, src=0, bucket_bytes=1 << 16)
+        ref = PSALM(cfg, make_state_dict(cfg, seed=100), ops=ops, precision=precision)                 # what rank 0 holds
+        same = True
+        for k, v in ref.w.items():
+            a = model.w[k]
+            same &= (torch.equal(a.t, v.t) and torch.equal(a.inv_scale, v.inv_scale)) if hasattr(v, "inv_scale") else torch.equal(a, v)
+        out[precision] = (bool(same), int(nbytes))
+    # images sharded round-robin: 3 images -> rank 0 gets {0, 2}, rank 1 gets {1}; same pixels whoever computes them
+    meters = E.IoUMeters()
+    mine = shard_indices(3, rank, world)
+    digest = []
+    for i in mine:
+        inputs = make_inputs(cfg, "referring", size=96, batch=1, seed=40 + i)
+        r = model.eval_seg(**inputs)[0]
+        inst = r["instances"]
+        top = int(inst.scores.argmax())
+        gt = (torch.rand(1, 96, 96, generator=torch.Generator().manual_seed(i)) < 0.3).to(torch.uint8)
+        inter, union, _ = E.iou_counts(inst.pred_masks, gt, [(top, 0)], ops=ops)
+        meters.update(inter, union)
+        digest.append((i, float(r["mask_pred"].double().sum())))
+    meters.all_reduce()
+    out["mine"], out["digest"], out["meters"] = mine, digest, meters.results()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_two_rank_real_model_broadcast_and_sharded_eval():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_real_model, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in ps), key=lambda d: d["rank"])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["fp32"][0] and r["f16x3"][0], "weights differ from rank 0's after the broadcast"
+        assert r["fp32"][1] > 0 and r["f16x3"][1] > 0
+    assert res[0]["fp32"][1] == res[1]["fp32"][1] and res[0]["f16x3"][1] == res[1]["f16x3"][1]
+    assert res[0]["mine"] == [0, 2] and res[1]["mine"] == [1]
+    assert res[0]["meters"] == res[1]["meters"] and res[0]["meters"]["n"] == 3          # all-reduced: every rank holds the global meters
+    # the shards are what a single process computes for the same images with rank 0's weights
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from ops_backend import make_ops
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    cfg = PsalmConfig.tiny("referring")
+    m = PSALM(cfg, make_state_dict(cfg, seed=100), ops=make_ops("emu"), precision="f16x3")
+    want = {i: float(m.eval_seg(**make_inputs(cfg, "referring", size=96, batch=1, seed=40 + i))[0]["mask_pred"].double().sum()) for i in range(3)}
+    got = dict(res[0]["digest"] + res[1]["digest"])
+    assert got == want
