@@ -163,7 +163,7 @@ def main():
                 geo = (a[12], a[13], 3 * a[6], True, False, ",x3")
             if geo is not None:
                 M, N, K, a_bf16, c_bf16, tag = geo
-                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True)
+                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True, x3=x3)
                 if x3:
                     K = a[6]                                                      # ALGORITHMIC flops: 2 M N K of the fp32 product it stands for
                 if path == 2 and name in ("psalm_gemm", "psalm_gemm_x3"):

@@ -290,6 +290,10 @@ int psalm_linear_res_ln(const void* a_bf16, long lda, const void* w_bf16, const 
  * mask_score (Q) f32 or NULL: psalm_mask_scores' result from the same read (workspace Q*512*2 floats, else NULL). */
 int psalm_semantic_from_masks(const float* mask, const void* probsT_bf16, float* out, float* mask_score, float* workspace, int Q, int C,
                               long HW, int Kpad, void* stream);
+/* fp32-class (split-f16) form for precision="f16x3": probsT (C,128) FLOAT32; both operands carried as f16 hi + lo with the fixed scale
+ * 2^13 (probabilities / sigmoids <= 1), three f16 MFMAs per product, fp32 accumulate.  Same single pass over the logits. */
+int psalm_semantic_from_masks_x3(const float* mask, const float* probsT_f32, float* out, float* mask_score, float* workspace, int Q, int C,
+                                 long HW, int Kpad, void* stream);
 /* mask score = sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6) (llava_phi.py:318-320,439-441). workspace Q*64*2 floats. */
 int psalm_mask_scores(const float* mask, float* score, float* workspace, int Q, long HW, void* stream);
 /* topk over Q*C candidates + thing filter + score product (llava_phi.py:407-447, 308-324). */

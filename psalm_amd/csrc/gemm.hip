@@ -1073,7 +1073,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
 }
 
 // Tile / split-K selection of the direct-to-LDS path (pure function of the problem size).
-static void select_fast_config(int M, int N, int K, bool have_ws, long workspace_bytes, int& BM, int& BN, int& splits) {
+static void select_fast_config(int M, int N, int K, bool have_ws, long workspace_bytes, int& BM, int& BN, int& splits, bool x3 = false) {
     // 256^2 tiles pay off only when they alone fill the chip and the K loop is long enough to amortise the bigger
     // prologue / two-pass epilogue (measured r1e: 4096^3 1092 vs 937 TF/s, Phi [k|v|q|fc1] 713 vs 630; K <= 256 or
     // < 200 tiles: the 128^2 configuration (2 blocks/CU, optional split-K) wins)
@@ -1085,6 +1085,10 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     else if (M > 192 && t128 >= 100 && t128 < 200 && K <= 2048) { BM = 64; BN = 128; no_split = true; }   // r1l: Swin fc2 24 vs 35 us (split-K)
     else if (M > 192) { BM = 128; BN = 128; }
     else { BM = 64; BN = 128; }
+    // split-f16 GEMMs (K = 3 Kp, fp32 output): short K loops and grids that cannot fill two 128^2 blocks per CU run better on 64 x 128
+    // tiles (r02 sweep tools/bench_gemm_x3.py, profiles/r02f_gemm_x3_policies.json: M21504 N1024 K256 105 -> 67 us, M65536 N512 K128
+    // 112 -> 77, M16384 N1024 K256 67 -> 53, M1024 N4096 K1024 57 -> 42)
+    if (x3 && M > 192 && (K <= 1024 || (t128 < 448 && K <= 4096))) { BM = 64; BN = 128; no_split = true; }
     if (g_tile_policy == 12864) { if (M > 192) { BM = 128; BN = 64; } }       // experiment: 48 KB LDS -> 3 blocks/CU
     else if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; no_split = false; }
     const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
@@ -1107,7 +1111,14 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
 // Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS, 2 skinny), out[1] = BM,
 // out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
 extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
-    if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+    const bool x3 = a_dtype == 2 && w_dtype == 2;                              // dtype code 2: split-f16 operands (psalm_gemm_x3, K = 3 Kp)
+    if (x3 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+        out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;
+    } else if (x3) {
+        int BM, BN, splits;
+        select_fast_config(M, N, K, workspace_bytes > 0, workspace_bytes, BM, BN, splits, true);
+        out4[0] = 1; out4[1] = BM; out4[2] = BN; out4[3] = splits;
+    } else if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;                     // skinny kernel
     } else if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0) {
         int BM, BN, splits;
@@ -1129,7 +1140,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
                        const LnEpilogue* ln = nullptr, bool fp8 = false, bool x3 = false) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
-    select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits);
+    select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
     g.tiles_m = cdiv(M, BM);
     g.tiles_n = cdiv(N, BN);
     g.row_fast = N > M ? 1 : 0;                                  // the larger operand's tiles stay in one XCD's L2
@@ -1168,6 +1179,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
         if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
         else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
+        else if (BM == 128 && g_ring_depth == 3) LAUNCH_X3(128, 128, 2, 2, 3, 0);
         else if (BM == 128) LAUNCH_X3(128, 128, 2, 2, 2, 0);
         else if ((g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2)) >= 3) LAUNCH_X3(64, 128, 2, 2, 3, 0);
         else LAUNCH_X3(64, 128, 2, 2, 2, 0);

@@ -230,6 +230,146 @@ __global__ void __launch_bounds__(256, 2) semantic_from_masks_kernel(const float
     }
 }
 
+// ---- split-f16 ("X3", fp32-class) form of the fused semantic pass, for precision = "f16x3": the same single pass over the logits, but
+// both operands are carried as f16 hi + lo (probabilities and sigmoids are <= 1: fixed scale 2^13, no per-row maximum needed) and each
+// (class tile, k-step) is three f16 MFMAs (hi.hi + lo.hi + hi.lo), fp32 accumulate, result scaled by 2^-26.  Replaces, in that mode,
+// sigmoid_transpose (419 MB read + 512 MB write) + split (1 GB) + the K = 384 GEMM + the separate mask-score pass (r02e: 1.0 ms) by the
+// compulsory read + write.  LDS: 2 x (160 + 128) rows x 264 B = 152 KB, one persistent block per CU.
+typedef _Float16 pp_f16x8 __attribute__((ext_vector_type(8)));
+template <int NI>
+__global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const float* __restrict__ mask, const float* __restrict__ probsT,
+                                                                        float* __restrict__ out, float* __restrict__ partial, int Q, int C,
+                                                                        long HW, int ntiles) {
+    constexpr int KP = 128, PITCH = KP + 4, CT = 5;
+    constexpr float SC = 8192.0f, INV2 = 1.0f / (8192.0f * 8192.0f);
+    __shared__ __attribute__((aligned(16))) unsigned short Ph[CT * 32 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Pl[CT * 32 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Sh[128 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Sl[128 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto split = [&](float x, unsigned short& h, unsigned short& l) {
+        const float a = x * SC;
+        const _Float16 hh = (_Float16)a;
+        const _Float16 ll = (_Float16)(a - (float)hh);
+        h = __builtin_bit_cast(unsigned short, hh);
+        l = __builtin_bit_cast(unsigned short, ll);
+    };
+    for (int e = tid; e < CT * 32 * KP; e += 256) {          // probsT (C, 128) f32 -> hi / lo in LDS, zero rows beyond C
+        const int c = e / KP, k = e % KP;
+        unsigned short h = 0, l = 0;
+        if (c < C) split(probsT[(long)c * KP + k], h, l);
+        Ph[c * PITCH + k] = h;
+        Pl[c * PITCH + k] = l;
+    }
+    for (int e = tid; e < 128 * (KP - 4 * NI); e += 256) {   // q columns the staging loop never writes: zero once
+        const int p = e / (KP - 4 * NI), q = 4 * NI + e % (KP - 4 * NI);
+        Sh[p * PITCH + q] = 0;
+        Sl[p * PITCH + q] = 0;
+    }
+    float num[NI], den[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long p0 = (long)t * 128;
+        __syncthreads();
+        const long pa = min(p0 + lane, HW - 1), pb = min(p0 + 64 + lane, HW - 1);
+        const bool va = p0 + lane < HW, vb = p0 + 64 + lane < HW;
+        constexpr int G = NI % 5 == 0 ? NI : 8;
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += G) {
+            float ma[G], mb[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float* row = mask + (long)min(wave + 4 * (i0 + g), Q - 1) * HW;
+                ma[g] = row[pa];
+                mb[g] = row[pb];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i = i0 + g, q = wave + 4 * i;
+                const float xa = va ? ma[g] : 0.f, xb = vb ? mb[g] : 0.f;
+                const float sa = sigmoidf_(xa), sb = sigmoidf_(xb);
+                unsigned short h, l;
+                split(sa, h, l);
+                Sh[lane * PITCH + q] = h;
+                Sl[lane * PITCH + q] = l;
+                split(sb, h, l);
+                Sh[(64 + lane) * PITCH + q] = h;
+                Sl[(64 + lane) * PITCH + q] = l;
+                num[i] += (xa > 0.f ? sa : 0.f) + (xb > 0.f ? sb : 0.f);
+                den[i] += (xa > 0.f ? 1.f : 0.f) + (xb > 0.f ? 1.f : 0.f);
+            }
+        }
+        __syncthreads();
+        pp_f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        int arow = n * PITCH;
+        PSALM_OPAQUE_VGPR(arow);
+        auto frag = [&](const unsigned short* base) -> pp_f16x8 {
+            const unsigned long long* p = reinterpret_cast<const unsigned long long*>(base);
+            const unsigned long long a0 = p[0], a1 = p[1];
+            return __builtin_bit_cast(pp_f16x8, psalm_u32x4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)});
+        };
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            const int ko = 16 * kk + 8 * hi;
+            const pp_f16x8 bh = frag(&Sh[(32 * wave + n) * PITCH + ko]), bl = frag(&Sl[(32 * wave + n) * PITCH + ko]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const pp_f16x8 ah = frag(&Ph[32 * ct * PITCH + arow + ko]), al = frag(&Pl[32 * ct * PITCH + arow + ko]);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ct], 0, 0, 0);
+            }
+        }
+        const bool pv = p0 + 32 * wave + n < HW;
+        const unsigned voff = (unsigned)(32 * wave + n) + (unsigned)(4 * hi) * (unsigned)HW;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cb = 32 * ct + (r & 3) + 8 * (r >> 2);
+                float* rowp = out + (long)cb * HW + p0;
+                if (pv && cb + 4 * hi < C) rowp[voff] = acc[ct][r] * INV2;
+            }
+    }
+    if (partial) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = wave + 4 * i;
+            const float a = wave_sum(num[i]), b = wave_sum(den[i]);
+            if (lane == 0 && q < Q) {
+                partial[((long)q * gridDim.x + blockIdx.x) * 2 + 0] = a;
+                partial[((long)q * gridDim.x + blockIdx.x) * 2 + 1] = b;
+            }
+        }
+    }
+}
+
+// fp32-class form: probsT (C, 128) FLOAT32 (psalm_class_softmax with an fp32 transposed copy); otherwise as psalm_semantic_from_masks.
+extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* probsT_f32, float* out, float* mask_score, float* workspace,
+                                            int Q, int C, long HW, int Kpad, void* stream) {
+    PSALM_CHECK_ARG(Kpad == 128 && Q >= 1 && Q <= 128 && C >= 1 && C <= 160, "psalm_semantic_from_masks_x3: Kpad 128, Q <= 128, C <= 160");
+    PSALM_CHECK_ARG(mask_score == nullptr || workspace != nullptr, "psalm_semantic_from_masks_x3: mask_score needs the workspace");
+    PSALM_CHECK_ARG(HW <= (1L << 27), "psalm_semantic_from_masks_x3: HW <= 2^27 (32-bit lane offsets)");
+    if (HW == 0) return 0;
+    const int ntiles = (int)((HW + 127) / 128);
+    const int grid = ntiles < 256 ? ntiles : 256;            // 1 persistent block per CU (LDS 152 KB)
+    if (Q <= 100)
+        hipLaunchKernelGGL(semantic_from_masks_x3_kernel<25>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, probsT_f32, out,
+                           mask_score ? workspace : nullptr, Q, C, HW, ntiles);
+    else
+        hipLaunchKernelGGL(semantic_from_masks_x3_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, probsT_f32, out,
+                           mask_score ? workspace : nullptr, Q, C, HW, ntiles);
+    if (mask_score)
+        hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
+    PSALM_LAUNCH_END("psalm_semantic_from_masks_x3");
+}
+
 // mask (Q, HW) f32 logits; probsT (C, 128) bf16 = softmax probabilities transposed and zero-padded (psalm_class_softmax);
 // out (C, HW) f32.  Q <= 128, C <= 160.  mask_score (Q) f32 or NULL: the per-query mask score of psalm_mask_scores, accumulated from
 // the same read of the logits (workspace: Q * 512 * 2 floats).

@@ -290,9 +290,12 @@ class Ops:
         self._check(rc, "psalm_conv2d_nhwc")
         return out
 
-    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True):
-        """(path, BM, BN, splits) psalm_gemm uses for this problem (path 1 = direct-to-LDS kernel)."""
+    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True, x3=False):
+        """(path, BM, BN, splits) psalm_gemm / psalm_gemm_x3 (x3=True, K = 3*Kp) uses for this problem (path 1 = direct-to-LDS kernel)."""
         out = (c_int * 4)()
+        if x3:
+            self._cdll_raw.psalm_gemm_describe(M, N, K, 2, 2, c_long(self.GEMM_WS_BYTES), out)
+            return tuple(out)
         self._cdll_raw.psalm_gemm_describe(M, N, K, BF16 if a_bf16 else F32, BF16 if w_bf16 else F32, c_long(self.GEMM_WS_BYTES), out)
         return tuple(out)
 
@@ -649,13 +652,14 @@ class Ops:
         want_mask_score also returns mask_scores(mask) accumulated from the same read."""
         Q, HW = mask.shape
         C, Kpad = probsT.shape
-        if probsT.dtype != torch.bfloat16 or mask.dtype != torch.float32:
-            raise PsalmHipError("semantic_from_masks: f32 logits, bf16 probsT")
+        if probsT.dtype not in (torch.bfloat16, torch.float32) or mask.dtype != torch.float32:
+            raise PsalmHipError("semantic_from_masks: f32 logits, bf16 probsT (bf16 MFMA) or f32 probsT (split-f16, fp32-class)")
         out = self.empty(C, HW, dtype=torch.float32)
         ms = self.empty(Q) if want_mask_score else None
         ws = self.empty(Q * 512 * 2) if want_mask_score else None
-        rc = self.lib.psalm_semantic_from_masks(self._p(mask), self._p(probsT), self._p(out), self._p(ms) if want_mask_score else None,
-                                                self._p(ws) if want_mask_score else None, Q, C, c_long(HW), Kpad, self._stream())
+        fn = self.lib.psalm_semantic_from_masks_x3 if probsT.dtype == torch.float32 else self.lib.psalm_semantic_from_masks
+        rc = fn(self._p(mask), self._p(probsT), self._p(out), self._p(ms) if want_mask_score else None,
+                self._p(ws) if want_mask_score else None, Q, C, c_long(HW), Kpad, self._stream())
         self._check(rc, "psalm_semantic_from_masks")
         return (out, ms) if want_mask_score else out
 

@@ -116,8 +116,10 @@ class PSALM:
         self._plan_cache: Dict = {}
         self.max_graphs = 8                           # captured input signatures kept alive (oldest dropped first)
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
-        self.overlap_streams = False                  # opt-in: pixel decoder on a second HIP stream, concurrent with the LLM
-        #                                               (measured r1k: no gain -- the LLM GEMMs already fill the chip)
+        # pixel decoder on a second HIP stream, concurrent with the LLM (fork / join, captured into the hipGraph).  bf16 mode, r1k: no
+        # gain (the LLM GEMMs fill the chip).  f16x3, r02: the 3x longer LLM GEMMs leave room (224 tiles on 256 CUs) for the decoder's ~150
+        # small kernels: 28.96 -> 28.04 ms per image -> on by default in that mode.
+        self.overlap_streams = precision == "f16x3"
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.config = None                            # LlavaConfig when built by from_pretrained (llava_phi.py:34)
@@ -941,8 +943,8 @@ class PSALM:
         bf16 mode: one fused pass over the mask logits (sigmoid -> LDS -> MFMA, score sums on the side); exact mode (or shapes
         outside the fused kernel's limits): fp32 sigmoid^T + fp32 GEMM + the separate mask-score reduction."""
         o = self.ops
-        if probsT.dtype == torch.bfloat16 and Kpad == 128 and probsT.shape[0] <= 160:
-            return o.semantic_from_masks(mflat, probsT, want_mask_score=want_mask_score)
+        if (probsT.dtype == torch.bfloat16 or self.x3) and Kpad == 128 and probsT.shape[0] <= 160:
+            return o.semantic_from_masks(mflat, probsT, want_mask_score=want_mask_score)    # bf16 MFMA / split-f16 (f16x3) fused pass
         sem = o.gemm(probsT, self._wop(o.sigmoid_transpose(mflat, Kpad, self.wdt)), out_dtype=torch.float32)
         return (sem, o.mask_scores(mflat)) if want_mask_score else sem
 

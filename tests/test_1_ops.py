@@ -477,3 +477,23 @@ def test_mha_attention_f32_matrix_core_split_kv(ops, Lq, Lk, masked):
     got = ops.mha_attention(qd[:, 8:8 + D], kvd[:, :D], kvd[:, D + 4:], B, Lq, Lk, heads,
                             mask.to(torch.uint8).to(d) if masked else None, flags.to(torch.uint8).to(d) if masked else None).cpu()
     assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("Q,C,HW", [(100, 133, 128 * 3 + 40), (12, 9, 300), (128, 160, 256)])
+def test_semantic_from_masks_x3_fp32_class(ops, Q, C, HW):
+    """Split-f16 form of the fused semantic pass (precision="f16x3"): fp32-class agreement with the float64 product of the UNROUNDED
+    probabilities and sigmoids (the bf16 form above is only good to 2^-8)."""
+    g = torch.Generator().manual_seed(Q + C)
+    mask = torch.randn(Q, HW, generator=g) * 4
+    cls = torch.randn(Q, C + 1, generator=g) * 2
+    d = ops.device
+    probs, probsT, score, label = ops.class_softmax(cls.to(d), 128, probsT_dtype=torch.float32)
+    got, ms = ops.semantic_from_masks(mask.to(d), probsT, want_mask_score=True)
+    got = got.cpu().double()
+    pos = (mask > 0).double()
+    want_ms = (mask.double().sigmoid() * pos).sum(1) / (pos.sum(1) + 1e-6)
+    assert (ms.cpu().double() - want_ms).abs().max() < 1e-5
+    want = probsT.cpu().double()[:, :Q] @ mask.double().sigmoid()
+    assert got.shape == (C, HW)
+    # operands carried to 2^-22 relative, device sigmoid (v_exp) good to ~1e-6 relative: compare at 4e-6 of the output scale
+    assert (got - want).abs().max() <= 4e-6 * want.abs().max() + 1e-7

@@ -164,12 +164,14 @@ def test_tiny_eval_video_vs_oracle():
     assert (a["pred_region_logits"] - b_["pred_region_logits"]).abs().max() > 1e-3 * a["pred_region_logits"].abs().max()
 
 
-def test_tiny_eval_seg_f16x3_mode():
+@pytest.mark.parametrize("queries,size", [(12, 96), (72, 128)])
+def test_tiny_eval_seg_f16x3_mode(queries, size):
     """precision="f16x3" (the qualifying fast mode: every GEMM in split-f16 arithmetic, everything else as the exact-fp32 mode) end to
-    end on the emulator: fp32-class agreement with the oracle, i.e. the tolerances of the fp32-mode tests, not the bf16 mode's."""
-    cfg = PsalmConfig.tiny("panoptic")
+    end on the emulator: fp32-class agreement with the oracle, i.e. the tolerances of the fp32-mode tests, not the bf16 mode's.
+    72 queries (a 128-wide padded K) also takes the fused split-f16 semantic / mask-score pass and the MFMA-tiled attention sizes."""
+    cfg = dataclasses.replace(PsalmConfig.tiny("panoptic"), md_queries=queries)
     sd = make_state_dict(cfg, seed=12)
-    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=4, num_classes=9)
+    inputs = make_inputs(cfg, "panoptic", size=size, batch=1, seed=4, num_classes=9)
     model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
     torch.manual_seed(5)
     w = O.eval_seg(sd, cfg, **inputs)[0]
@@ -177,7 +179,12 @@ def test_tiny_eval_seg_f16x3_mode():
     g = model.eval_seg(**inputs)[0]
     assert _rel(g["mask_pred"], w["mask_pred"]) < 1e-4
     assert _rel(g["sem_seg"], w["sem_seg"]) < 1e-4
-    assert (g["sem_seg"].argmax(0).cpu() == w["sem_seg"].argmax(0)).float().mean() >= 0.999
+    # labels: identical wherever the oracle's decision is not an exact tie (this tiny random model has pixels whose two best classes
+    # differ by ~1e-11 at a scale of 2e-4, i.e. below one fp32 ulp of the sum: any summation order may pick either)
+    top2 = w["sem_seg"].topk(2, 0).values
+    decided = (top2[0] - top2[1]) > 1e-6 * w["sem_seg"].abs().max()
+    same = g["sem_seg"].argmax(0).cpu() == w["sem_seg"].argmax(0)
+    assert bool(same[decided].all()) and same.float().mean() >= 0.98
     assert torch.equal(g["panoptic_seg"][0].cpu(), w["panoptic_seg"][0])
     assert g["panoptic_seg"][1] == w["panoptic_seg"][1]
     gi, wi = g["instances"], w["instances"]

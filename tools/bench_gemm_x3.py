@@ -1,0 +1,54 @@
+"""Split-f16 (X3) GEMM micro-benchmark over the shapes of the f16x3 image, per tile policy.
+    python tools/bench_gemm_x3.py [out.json]"""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from psalm_amd.hip_ops import get_ops
+
+SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512, 2048), (5184, 1536, 512), (5184, 512, 512),
+          (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256), (65536, 512, 128), (65536, 128, 512), (16384, 1024, 256),
+          (1024, 4096, 1024), (100, 65536, 256), (133, 1048576, 128), (65536, 256, 2304)]
+POLICIES = [("auto", [0]), ("t256", [256]), ("t128", [128]), ("t128_ring3", [128, 1283]), ("t64", [64]), ("t64_ring3", [64, 643])]
+
+
+def main():
+    ops = get_ops()
+    out = {}
+    for M, N, K in SHAPES:
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda")
+        asp, wsp = ops.split_f16(a), ops.split_f16(w)
+        c = torch.empty(M, N, device="cuda")
+        row = {}
+        for name, pol in POLICIES:
+            for p in pol:
+                ops.gemm_tile_policy(p)
+            try:
+                for _ in range(3):
+                    ops.gemm_x3(asp, wsp, out=c)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 20
+                e0.record()
+                for _ in range(reps):
+                    ops.gemm_x3(asp, wsp, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / reps * 1e3
+                row[name] = {"us": round(us, 1), "TF_alg": round(2.0 * M * N * K / us / 1e6, 1), "describe": ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)}
+            except Exception as ex:  # noqa
+                row[name] = {"error": str(ex)[:80]}
+            finally:
+                ops.gemm_tile_policy(1282)
+                ops.gemm_tile_policy(640)
+                ops.gemm_tile_policy(0)
+        out[f"M{M} N{N} K{K}"] = row
+        print(M, N, K, {k: v.get("us") for k, v in row.items()}, flush=True)
+        del a, w, asp, wsp, c
+    if len(sys.argv) > 1:
+        json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

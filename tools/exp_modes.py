@@ -23,7 +23,9 @@ def main():
     torch.cuda.empty_cache()
     out = {}
     for mode in modes:
-        m = PSALM(cfg, sd, precision=mode, use_graphs=True)
+        overlap = mode.endswith("+overlap")
+        m = PSALM(cfg, sd, precision=mode.split("+")[0], use_graphs=True)
+        m.overlap_streams = overlap
         for _ in range(3):
             r = m.eval_seg(**inputs)
         torch.cuda.synchronize()
