@@ -21,6 +21,7 @@
 //     sampling locations in-kernel (ops/modules/ms_deform_attn.py:101-110), so the (B,Lq,M,L,P,2)
 //     location and (B,Lq,M,L,P) weight tensors are never materialised in HBM.
 #include "common.h"
+#include <cstdlib>
 
 struct alignas(16) f32x4_s { float x, y, z, w; };
 struct alignas(8) bf16x4_s { bf16_t x, y, z, w; };
@@ -101,7 +102,12 @@ __device__ __forceinline__ MsdaTaps8<TV> msda_taps8(const TV* __restrict__ vbase
     return t;
 }
 
-template <typename TV, typename TO, int L, int P>
+// XCD_BANDS = true (B == 1, every level height a multiple of 8, block count a multiple of 8): the hardware places block b on XCD b % 8;
+// XCD k is given the queries of the k-th horizontal BAND (rows [k H_l / 8, (k+1) H_l / 8) of every level), in level order.  A query
+// samples every level around its own normalised position, so the corner rows an XCD touches are its band of each level (+ a halo):
+// 1/8 of the 22 MB fp32 value tensor = 2.75 MB, resident in that XCD's 4 MB L2 -- with the linear order every XCD streamed the whole
+// tensor through its L2 (r01 PMC: 1.9x the compulsory bytes from the fabric).
+template <typename TV, typename TO, int L, int P, bool XCD_BANDS = false>
 __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__ value, MsdaLevels lv,
                                                           const float* __restrict__ ow, TO* __restrict__ out, int B, int S,
                                                           int M, int D) {
@@ -109,13 +115,29 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
     const int Lq = S;
     const long total = (long)B * Lq * M * G;
     constexpr int LP = L * P;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx0 = (long)blockIdx.x * blockDim.x + threadIdx.x; idx0 < total; idx0 += (long)gridDim.x * blockDim.x) {
+        long idx = idx0;
+        if constexpr (XCD_BANDS)                                     // (grid covers `total` exactly once: no grid-stride wrap)
+            idx = ((long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x);   // position inside the band's (query, head, group) list
         const int g = (int)(idx % G);
         long t = idx / G;
         const int m = (int)(t % M);
         t /= M;
-        const int q = (int)(t % Lq);
-        const int b = (int)(t / Lq);
+        int q = (int)(t % Lq);
+        const int b = XCD_BANDS ? 0 : (int)(t / Lq);
+        if constexpr (XCD_BANDS) {                                   // t = index inside the band: level by cumulative band sizes
+            const int band = blockIdx.x & 7;
+            int r = (int)t, lq_ = 0, base = 0;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int nb = lv.H[l] * lv.W[l] / 8;
+                if (l == lq_ && r >= nb && l + 1 < L) { r -= nb; ++lq_; }
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (l == lq_) base = lv.start[l] + band * (lv.H[l] * lv.W[l] / 8);
+            q = base + r;
+        }
         int lq = 0;
 #pragma unroll
         for (int l = 1; l < L; ++l)
@@ -164,6 +186,7 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
 #pragma unroll
                     for (int c = 0; c < 4; ++c) ld8(tp[pp].p[c], v[pp][c]);
                 }
+                __builtin_amdgcn_sched_barrier(0);               // all 4 PB corner fetches issued before the first use waits on one
 #pragma unroll
                 for (int pp = 0; pp < PB; ++pp) {
                     const float wgt = lg[l * P + p0 + pp] * inv;
@@ -333,6 +356,16 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
     if (D % 8 == 0 && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0) {       // 8 channels per lane
         const long total8 = (long)B * S * M * (D / 8);
         if (total8 == 0) return 0;
+        static const bool no_bands = getenv("PSALM_MSDA_LINEAR") != nullptr;      // A/B knob (tools/bench_msda.py)
+        bool bands = !no_bands && B == 1 && total8 % (block * 8) == 0;            // XCD-band order (see the kernel comment)
+        for (int l = 0; l < L; ++l) bands = bands && lv.H[l] % 8 == 0;
+        if (bands) {
+            PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
+                hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4, true>), dim3((unsigned)(total8 / block)), dim3(block), 0,
+                                   (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);
+            }));
+            PSALM_LAUNCH_END("psalm_msda_fused");
+        }
         PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
             hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4>), dim3((unsigned)((total8 + block - 1) / block)), dim3(block), 0,
                                (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);

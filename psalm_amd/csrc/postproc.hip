@@ -231,8 +231,8 @@ __global__ void __launch_bounds__(256, 2) semantic_from_masks_kernel(const float
 }
 
 // ---- split-f16 ("X3", fp32-class) form of the fused semantic pass, for precision = "f16x3": the same single pass over the logits, but
-// both operands are carried as f16 hi + lo (probabilities and sigmoids are <= 1: fixed scale 2^13, no per-row maximum needed) and each
-// (class tile, k-step) is three f16 MFMAs (hi.hi + lo.hi + hi.lo), fp32 accumulate, result scaled by 2^-26.  Replaces, in that mode,
+// both operands are carried as f16 hi + lo (probabilities: fixed scale 2^13; sigmoids: a power-of-two scale per PIXEL from its largest
+// logit) and each (class tile, k-step) is three f16 MFMAs (hi.hi + lo.hi + hi.lo), fp32 accumulate, scales undone at the store.  Replaces, in that mode,
 // sigmoid_transpose (419 MB read + 512 MB write) + split (1 GB) + the K = 384 GEMM + the separate mask-score pass (r02e: 1.0 ms) by the
 // compulsory read + write.  LDS: 2 x (160 + 128) rows x 264 B = 152 KB, one persistent block per CU.
 typedef _Float16 pp_f16x8 __attribute__((ext_vector_type(8)));
@@ -241,24 +241,25 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
                                                                         float* __restrict__ out, float* __restrict__ partial, int Q, int C,
                                                                         long HW, int ntiles) {
     constexpr int KP = 128, PITCH = KP + 4, CT = 5;
-    constexpr float SC = 8192.0f, INV2 = 1.0f / (8192.0f * 8192.0f);
+    constexpr float SC = 8192.0f;
+    static_assert(NI % 5 == 0 || NI == 32, "all logits of a wave's queries are held in registers for the per-pixel scale");
     __shared__ __attribute__((aligned(16))) unsigned short Ph[CT * 32 * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Pl[CT * 32 * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Sh[128 * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Sl[128 * PITCH];
+    __shared__ float pmax[4][128];                           // per-wave maximum logit of each pixel of the tile
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto split = [&](float x, unsigned short& h, unsigned short& l) {
-        const float a = x * SC;
+    auto split = [&](float a, unsigned short& h, unsigned short& l) {     // a already scaled into f16 range
         const _Float16 hh = (_Float16)a;
         const _Float16 ll = (_Float16)(a - (float)hh);
         h = __builtin_bit_cast(unsigned short, hh);
         l = __builtin_bit_cast(unsigned short, ll);
     };
-    for (int e = tid; e < CT * 32 * KP; e += 256) {          // probsT (C, 128) f32 -> hi / lo in LDS, zero rows beyond C
+    for (int e = tid; e < CT * 32 * KP; e += 256) {          // probsT (C, 128) f32 -> hi / lo in LDS (probabilities <= 1: scale 2^13), zero rows beyond C
         const int c = e / KP, k = e % KP;
         unsigned short h = 0, l = 0;
-        if (c < C) split(probsT[(long)c * KP + k], h, l);
+        if (c < C) split(probsT[(long)c * KP + k] * SC, h, l);
         Ph[c * PITCH + k] = h;
         Pl[c * PITCH + k] = l;
     }
@@ -272,34 +273,54 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
     for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long p0 = (long)t * 128;
-        __syncthreads();
+        __syncthreads();                                     // previous tile's MFMA reads / pmax reads are done
         const long pa = min(p0 + lane, HW - 1), pb = min(p0 + 64 + lane, HW - 1);
         const bool va = p0 + lane < HW, vb = p0 + 64 + lane < HW;
-        constexpr int G = NI % 5 == 0 ? NI : 8;
+        // all logits of this wave's NI queries for its two pixels (unconditional clamped loads, 2 NI in flight per lane)
+        float ma[NI], mb[NI];
 #pragma unroll
-        for (int i0 = 0; i0 < NI; i0 += G) {
-            float ma[G], mb[G];
+        for (int i = 0; i < NI; ++i) {
+            const float* row = mask + (long)min(wave + 4 * i, Q - 1) * HW;
+            ma[i] = row[pa];
+            mb[i] = row[pb];
+        }
+        // per-pixel scale: sigmoid is monotone, so the largest sigmoid of a pixel belongs to its largest logit.  A FIXED scale would
+        // leave pixels whose masks are all strongly negative (most of a random-weight image) with subnormal f16 operands -- their class
+        // scores differ only in the bits that loses (r02: 0.009 % label flips vs 0.0007 % with per-pixel scales).
+        float xa_m = -3.0e38f, xb_m = -3.0e38f;
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float* row = mask + (long)min(wave + 4 * (i0 + g), Q - 1) * HW;
-                ma[g] = row[pa];
-                mb[g] = row[pb];
-            }
+        for (int i = 0; i < NI; ++i)
+            if (wave + 4 * i < Q) { xa_m = fmaxf(xa_m, ma[i]); xb_m = fmaxf(xb_m, mb[i]); }
+        pmax[wave][lane] = xa_m;
+        pmax[wave][64 + lane] = xb_m;
+        __syncthreads();
+        auto pix_scale = [&](int px, float& sc, float& inv) {  // power of two placing the pixel's largest sigmoid in [2^12, 2^14)
+            const float mxl = fmaxf(fmaxf(pmax[0][px], pmax[1][px]), fmaxf(pmax[2][px], pmax[3][px]));
+            const float smax = sigmoidf_(mxl);
+            int e = (int)((__builtin_bit_cast(unsigned, smax) >> 23) & 0xffu) - 127;     // floor(log2 smax), <= 0
+            int se = 13 - e;
+            se = se > 100 ? 100 : se;
+            const bool zero = !(smax > 0.f);
+            sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+            inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+        };
+        float sca, scb, ia, ib;
+        pix_scale(lane, sca, ia);
+        pix_scale(64 + lane, scb, ib);
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int i = i0 + g, q = wave + 4 * i;
-                const float xa = va ? ma[g] : 0.f, xb = vb ? mb[g] : 0.f;
-                const float sa = sigmoidf_(xa), sb = sigmoidf_(xb);
-                unsigned short h, l;
-                split(sa, h, l);
-                Sh[lane * PITCH + q] = h;
-                Sl[lane * PITCH + q] = l;
-                split(sb, h, l);
-                Sh[(64 + lane) * PITCH + q] = h;
-                Sl[(64 + lane) * PITCH + q] = l;
-                num[i] += (xa > 0.f ? sa : 0.f) + (xb > 0.f ? sb : 0.f);
-                den[i] += (xa > 0.f ? 1.f : 0.f) + (xb > 0.f ? 1.f : 0.f);
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int q = wave + 4 * i;
+            const float xa = va ? ma[i] : 0.f, xb = vb ? mb[i] : 0.f;
+            const float sa = sigmoidf_(xa), sb = sigmoidf_(xb);
+            unsigned short h, l;
+            split(sa * sca, h, l);
+            Sh[lane * PITCH + q] = h;
+            Sl[lane * PITCH + q] = l;
+            split(sb * scb, h, l);
+            Sh[(64 + lane) * PITCH + q] = h;
+            Sl[(64 + lane) * PITCH + q] = l;
+            num[i] += (xa > 0.f ? sa : 0.f) + (xb > 0.f ? sb : 0.f);
+            den[i] += (xa > 0.f ? 1.f : 0.f) + (xb > 0.f ? 1.f : 0.f);
         }
         __syncthreads();
         pp_f32x16 acc[CT];
@@ -326,6 +347,9 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
                 acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ct], 0, 0, 0);
             }
         }
+        float osc, oinv;                                     // this lane's OUTPUT pixel (32 wave + n): 1 / (2^13 * its scale)
+        pix_scale(32 * wave + n, osc, oinv);
+        oinv *= 1.0f / SC;
         const bool pv = p0 + 32 * wave + n < HW;
         const unsigned voff = (unsigned)(32 * wave + n) + (unsigned)(4 * hi) * (unsigned)HW;
 #pragma unroll
@@ -334,7 +358,7 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
             for (int r = 0; r < 16; ++r) {
                 const int cb = 32 * ct + (r & 3) + 8 * (r >> 2);
                 float* rowp = out + (long)cb * HW + p0;
-                if (pv && cb + 4 * hi < C) rowp[voff] = acc[ct][r] * INV2;
+                if (pv && cb + 4 * hi < C) rowp[voff] = acc[ct][r] * oinv;
             }
     }
     if (partial) {

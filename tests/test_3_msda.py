@@ -109,10 +109,11 @@ def test_border_semantics(ops):
     assert torch.equal(got, ref) or (got - ref).abs().max() < 1e-5
 
 
-def test_fused_matches_explicit(ops):
-    """Fused kernel (softmax + location arithmetic in-kernel) == ms_deform_attn.py:101-110 done in torch + explicit op."""
-    B, M, D, P = 2, 8, 32, 4
-    shapes = [(4, 4), (8, 8), (16, 16)]
+@pytest.mark.parametrize("B,shapes", [(2, [(4, 4), (8, 8), (16, 16)]), (1, [(8, 8), (16, 16), (32, 32)]), (1, [(8, 4), (16, 8), (24, 16)])])
+def test_fused_matches_explicit(ops, B, shapes):
+    """Fused kernel (softmax + location arithmetic in-kernel) == ms_deform_attn.py:101-110 done in torch + explicit op.
+    B = 1 with level heights that are multiples of 8 takes the XCD-band query order (each XCD owns a horizontal band of every level)."""
+    M, D, P = 8, 32, 4
     L = 3
     S = sum(h * w for h, w in shapes)
     st = _starts(shapes)
