@@ -116,6 +116,11 @@ class PSALM:
         self._plan_cache: Dict = {}
         self.max_graphs = 8                           # captured input signatures kept alive (oldest dropped first)
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
+        # Graph replay writes its results into buffers owned by the captured graph; "copy" (default) hands the caller private copies
+        # (device-to-device, ~1 GB per 1024^2 panoptic image = ~0.3 ms), "alias" returns the graph's own buffers, which the NEXT call with the
+        # same input signature overwrites -- only for callers that consume a result before the next call (bench.py, the reference's
+        # evaluators do; an evaluator that keeps tensors across iterations would silently read the next image's masks).
+        self.graph_outputs = "copy"
         # pixel decoder on a second HIP stream, concurrent with the LLM (fork / join, captured into the hipGraph).  bf16 mode, r1k: no
         # gain (the LLM GEMMs fill the chip).  f16x3, r02: the 3x longer LLM GEMMs leave room (224 tiles on 256 CUs) for the decoder's ~150
         # small kernels: 28.96 -> 28.04 ms per image -> on by default in that mode.
@@ -452,11 +457,111 @@ class PSALM:
     # ======================================================================================= token splicing (host ints)
     def _splice_plan(self, input_ids, attention_mask, n_img, class_name_ids, cls_indices, token_refer_id, n_regions,
                      want_cls, want_refer):
-        """llava_phi.py:767-971 on host integers: where every row of inputs_embeds comes from, plus the row sets used
-        after the LLM (seg queries LP:1299-1316, class-name groups LP:552-565, refer span LP:972-978, regions LP:302-307).
-        source ids: 0 = embed_tokens row, 1 = image token, 2 = seg_query row, 3 = region feature row."""
+        """llava_phi.py:767-971 on host integers, VECTORISED (numpy; no per-token Python loop -- the reference walks the prompt token by
+        token with `.item()` calls, LP:581-766): where every row of inputs_embeds comes from, plus the row sets used after the LLM (seg
+        queries LP:1299-1316, class-name groups LP:552-565, refer span LP:972-978, regions LP:302-307).
+        source ids: 0 = embed_tokens row, 1 = image token, 2 = seg_query row, 3 = region feature row.
+        `_splice_plan_reference` is the per-token form it is tested against (tests/test_8_collate.py)."""
+        ids_all = input_ids.cpu().numpy().astype(np.int64)
+        B, T = ids_all.shape
+        am_all = np.ones((B, T), bool) if attention_mask is None else attention_mask.cpu().numpy().astype(bool)   # LP accepts attention_mask=None
+        NQ = self.cfg.md_queries
+
+        def expand(starts, sizes):                       # concatenation of arange(starts[i], starts[i] + sizes[i])
+            sizes = np.asarray(sizes, np.int64)
+            tot = int(sizes.sum())
+            if tot == 0:
+                return np.zeros(0, np.int64)
+            off = np.concatenate(([0], np.cumsum(sizes)[:-1]))
+            return np.repeat(np.asarray(starts, np.int64) - off, sizes) + np.arange(tot)
+
+        per = []
+        reg_base = 0
+        known = (IMAGE_TOKEN_INDEX, SEG_TOKEN_INDEX, CLS_TOKEN_INDEX, REGION_TOKEN_INDEX, REFER_TOKEN_INDEX)
+        for b in range(B):
+            ids = ids_all[b]
+            neg = ids < 0
+            if neg.any() and not np.isin(ids[neg], known).all():
+                raise ValueError(f"unknown sentinel token id {int(ids[neg][~np.isin(ids[neg], known)][0])}")
+            is_img, is_seg, is_cls = ids == IMAGE_TOKEN_INDEX, ids == SEG_TOKEN_INDEX, ids == CLS_TOKEN_INDEX
+            is_reg, is_ref = ids == REGION_TOKEN_INDEX, ids == REFER_TOKEN_INDEX
+            lens = np.ones(T, np.int64)
+            lens[is_img] = n_img
+            lens[is_seg] = NQ
+            ctoks = gsz = None
+            if class_name_ids is not None:               # unique_consecutive groups of cls_indices >= 0 (LP:566-574)
+                ci = cls_indices[b].cpu().numpy().astype(np.int64)
+                cn = class_name_ids[b].cpu().numpy().astype(np.int64)
+                valid = ci >= 0
+                start = valid & np.concatenate(([True], (ci[1:] != ci[:-1]) | ~valid[:-1]))
+                ctoks = cn[valid]
+                gsz = np.diff(np.concatenate((np.flatnonzero(start[valid]), [int(valid.sum())])))
+                assert int(is_cls.sum()) == gsz.shape[0], "the number of <cls> tokens and class_embed needs to be same"      # LP:590-591
+                lens[is_cls] = gsz
+            refer_tok = None
+            if token_refer_id is not None:
+                refer_tok = token_refer_id[b].cpu().numpy().astype(np.int64)
+                lens[is_ref] = refer_tok.shape[0]
+            elif is_ref.any():
+                raise ValueError("<refer> token without token_refer_id")
+            n_reg = int(is_reg.sum())
+            if n_regions is not None:
+                assert n_reg == n_regions[b], "the number of <region> tokens and regions needs to be same"                  # LP:592-594
+            pos = np.cumsum(lens) - lens
+            Lb = int(lens.sum())
+            sid = np.zeros(Lb, np.int32)
+            srow = np.zeros(Lb, np.int32)
+            txt = ~neg
+            srow[pos[txt]] = ids[txt]
+            r = expand(pos[is_img], lens[is_img])
+            sid[r] = 1
+            srow[r] = np.tile(np.arange(b * n_img, (b + 1) * n_img), int(is_img.sum()))
+            seg_rows = expand(pos[is_seg], lens[is_seg])
+            sid[seg_rows] = 2
+            srow[seg_rows] = np.tile(np.arange(NQ), int(is_seg.sum()))
+            cls_rows = np.zeros(0, np.int64)
+            if ctoks is not None:
+                cls_rows = expand(pos[is_cls], gsz)
+                srow[cls_rows] = ctoks
+            reg_rows = pos[is_reg]
+            sid[reg_rows] = 3
+            srow[reg_rows] = reg_base + np.arange(n_reg)
+            reg_base += n_reg
+            ref_rows = np.zeros(0, np.int64)
+            if refer_tok is not None:
+                ref_rows = expand(pos[is_ref], lens[is_ref])
+                srow[ref_rows] = np.tile(refer_tok, int(is_ref.sum()))
+            per.append((sid, srow, seg_rows, cls_rows, gsz if gsz is not None else np.zeros(0, np.int64), ref_rows, reg_rows, Lb))
+        lens_b = [p[7] for p in per]
+        L = max(lens_b)
+        sid = np.full((B, L), -1, np.int32)
+        srow = np.zeros((B, L), np.int32)
+        kmask = np.zeros((B, L), np.uint8)
+        for b, p in enumerate(per):
+            Lb = lens_b[b]
+            sid[b, :Lb] = p[0]
+            srow[b, :Lb] = p[1]
+            kmask[b, : Lb - T] = 1                                # LP:939-946 / LP:965-968
+            kmask[b, Lb - T: Lb] = am_all[b]
+        plan = {"L": L, "lens": lens_b, "sid": sid, "srow": srow, "kmask": kmask}
+
+        def csr(rows_per_b, sizes_per_b):                        # CSR over rows of the flattened (B*L, H) hidden-state matrix
+            rows = np.concatenate([r + b * L for b, r in enumerate(rows_per_b)]) if rows_per_b else np.zeros(0, np.int64)
+            sizes = np.concatenate(sizes_per_b) if sizes_per_b else np.zeros(0, np.int64)
+            return np.concatenate(([0], np.cumsum(sizes))).astype(np.int32), rows.astype(np.int32)
+        plan["seg"] = csr([p[2] for p in per], [np.ones(p[2].shape[0], np.int64) for p in per])
+        plan["cls"] = csr([p[3] for p in per], [p[4] for p in per]) if want_cls else None
+        plan["n_cls"] = [int(p[4].shape[0]) for p in per]
+        plan["refer"] = csr([p[5] for p in per], [np.asarray([p[5].shape[0]], np.int64) for p in per]) if want_refer else None
+        plan["region"] = csr([p[6] for p in per], [np.ones(p[6].shape[0], np.int64) for p in per]) if n_regions is not None else None
+        return plan
+
+    def _splice_plan_reference(self, input_ids, attention_mask, n_img, class_name_ids, cls_indices, token_refer_id, n_regions,
+                               want_cls, want_refer):
+        """Per-token form of `_splice_plan` (the round-1 implementation, a direct restatement of LP:767-971): kept as the checker of the
+        vectorised version."""
         ids_all = input_ids.tolist()
-        am_all = attention_mask.to(torch.bool).tolist()
+        am_all = attention_mask.to(torch.bool).tolist() if attention_mask is not None else [[True] * len(r) for r in ids_all]
         B, T = len(ids_all), len(ids_all[0])
         NQ = self.cfg.md_queries
         per = []
@@ -1083,7 +1188,20 @@ class PSALM:
             ent["vp"].copy_(vp_images)
         ent["blob"].copy_(host)
         ent["graph"].replay()
-        return ent["outs"]
+        if self.graph_outputs == "alias":
+            return ent["outs"]
+
+        def own(v):
+            if torch.is_tensor(v):
+                return v.clone()
+            if isinstance(v, tuple):
+                return tuple(own(x) for x in v)
+            if isinstance(v, list):
+                return [own(x) for x in v]
+            if isinstance(v, dict):
+                return {k: own(x) for k, x in v.items()}
+            return v
+        return own(ent["outs"])
 
     @torch.no_grad()
     def eval_seg(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
@@ -1094,8 +1212,8 @@ class PSALM:
         """Same keyword signature as the reference's PSALM.eval_seg (llava_phi.py:1317-1336).  Returns list[dict] with
         `sem_seg`, `instances`, `panoptic_seg` (panoptic) / `instances` (referring) / `instances`,`gt` (region), one entry
         per image (the reference stops after image 0, LP:1472).
-        With use_graphs=True the result tensors are buffers owned by the captured graph: they are overwritten by the next
-        eval_seg call with the same input signature (the reference's evaluators consume them immediately)."""
+        With use_graphs=True the results are private copies of the graph's output buffers unless `graph_outputs = "alias"` (then they
+        are overwritten by the next eval_seg call with the same input signature)."""
         if self.seg_task == "panoptic":
             assert is_thing_list is not None, "is_thing_list need to be given"        # LP:1337-1339
             self.is_thing_list = is_thing_list

@@ -1,0 +1,67 @@
+"""SURVEY §8 f1 -- the batch collator in front of eval_seg: psalm_amd.collate.DataCollatorForCOCODatasetV2 vs the golden written by
+the REFERENCE's own class (tests/golden/make_collator_golden.py, psalm/train/train_datasets.py:968-1045) on the same seeded instances.
+Integer / index work: exact equality.  The collated batch then feeds eval_seg's splice plan (vectorised == per-token form)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_collator_golden import make_instances  # noqa: E402  (pure-torch instance generator; the reference import lives in main())
+
+from psalm_amd.collate import DataCollatorForCOCODatasetV2  # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["panoptic", "ragged_images", "referring"])
+def test_collator_equals_reference_golden(kind):
+    z = np.load(os.path.join(HERE, "golden", "collator.npz"))
+    tok = types.SimpleNamespace(pad_token_id=50256, model_max_length=48)
+    instances = make_instances(7, kind)
+    batch = DataCollatorForCOCODatasetV2(tokenizer=tok)(instances)
+    want_keys = {k.split("/")[1] for k in z.files if k.startswith(kind + "/")}
+    got_keys = {("images_list" if k == "images" and not torch.is_tensor(v) else "seg_info_keys" if k == "seg_info" else k) for k, v in batch.items()}
+    assert got_keys == want_keys
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            w = z[f"{kind}/{k}"]
+            assert v.dtype == torch.from_numpy(w).dtype and np.array_equal(v.numpy(), w), k
+        elif k in ("images", "token_refer_id"):
+            name = "images_list" if k == "images" else k
+            for j, t in enumerate(v):
+                assert np.array_equal(t.numpy(), z[f"{kind}/{name}/{j}"])
+        elif k == "seg_info":
+            assert [",".join(sorted(d.keys())) for d in v] == z[f"{kind}/seg_info_keys"].tolist()
+            assert all(a is b for a, b in zip(v, instances))                       # the instances themselves, mutated in place
+        elif k == "dataset_type":
+            assert list(v) == z[f"{kind}/dataset_type"].tolist()
+    assert batch["input_ids"].shape[1] <= tok.model_max_length                   # truncation to model_max_length
+
+
+def test_vectorised_splice_plan_equals_per_token_form():
+    """PSALM._splice_plan (numpy, no per-token Python loop) == the straightforward per-token restatement of llava_phi.py:767-971 kept
+    as PSALM._splice_plan_reference, on panoptic / ragged referring / region prompts."""
+    from ops_backend import make_ops
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    for task, batch in (("panoptic", 2), ("referring", 4), ("region", 3)):
+        cfg = PsalmConfig.tiny(task)
+        model = PSALM(cfg, make_state_dict(cfg, seed=1), ops=make_ops("emu"), precision="fp32")
+        inp = make_inputs(cfg, task, size=96, batch=batch, seed=9, num_classes=9)
+        n_regions = None
+        if task == "region":
+            n_regions = [int(s["instances"].region_masks.tensor.shape[0]) for s in inp["seg_info"]]
+        args = (inp["input_ids"], inp["attention_mask"], 9, inp.get("class_name_ids"), inp.get("cls_indices"), inp.get("token_refer_id"),
+                n_regions, "class_name_embedding_indices" in inp, "refer_embedding_indices" in inp)
+        a, b = model._splice_plan(*args), model._splice_plan_reference(*args)
+        assert a["L"] == b["L"] and a["lens"] == b["lens"] and a["n_cls"] == b["n_cls"]
+        for k in ("sid", "srow", "kmask"):
+            assert np.array_equal(a[k], b[k]), (task, k)
+        for k in ("seg", "cls", "refer", "region"):
+            assert (a[k] is None) == (b[k] is None)
+            if a[k] is not None:
+                assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]), (task, k)

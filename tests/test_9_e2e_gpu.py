@@ -198,6 +198,20 @@ def test_graph_replay_is_bitwise_eager(task, batch):
                 assert torch.equal(got[b]["panoptic_seg"][0], want[b]["panoptic_seg"][0])
                 assert got[b]["panoptic_seg"][1] == want[b]["panoptic_seg"][1]
     assert any("graph" in e for e in graphed._graphs.values())
+    # default graph_outputs="copy": a kept result is NOT overwritten by the next call; "alias" returns the graph's own buffers
+    inputs_a = make_inputs(cfg, task, size=96, batch=batch, seed=4, num_classes=9)
+    inputs_b = make_inputs(cfg, task, size=96, batch=batch, seed=5, num_classes=9)
+    kept = graphed.eval_seg(**inputs_a)[0]["mask_pred"]
+    snap = kept.clone()
+    graphed.eval_seg(**inputs_b)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, snap)
+    graphed.graph_outputs = "alias"
+    kept = graphed.eval_seg(**inputs_a)[0]["mask_pred"]
+    snap = kept.clone()
+    graphed.eval_seg(**inputs_b)
+    torch.cuda.synchronize()
+    assert not torch.equal(kept, snap)
 
 
 @pytest.mark.parametrize("precision,rtol", [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", 6e-2)])
