@@ -271,20 +271,6 @@ int psalm_class_softmax(const float* cls, float* probs, void* probsT, int probsT
                         int Kpad, void* stream);
 /* sigmoid(mask)^T padded to Kpad: second operand of class_name_semantic_inference (llava_phi.py:402-406). */
 int psalm_sigmoid_transpose(const float* mask, void* out, int out_dtype, int Q, long HW, int Kpad, void* stream);
-/* Prediction-head front end, fused: decoder_norm LayerNorm + the 3-layer mask_embed MLP (ReLU between layers) of
- * forward_prediction_heads (mask2former_transformer_decoder.py:695-709; MLP :187-199) in one launch.  x (rows,D) f32; w_j (D,D) bf16
- * nn.Linear weights, b_j (D) f32; ln_out (rows,D) bf16 = LayerNorm(x); out (rows,D) bf16 = MLP(LayerNorm(x)).  D in {64,128,256}. */
-int psalm_ln_mlp3(const float* x, long ldx, const float* gamma, const float* beta, float eps, const void* w0, const float* b0,
-                  const void* w1, const float* b1, const void* w2, const float* b2, void* ln_out_bf16, void* out_bf16, int rows, int D,
-                  void* stream);
-/* A/B switch of the two kernels below: 1 (default) = weights staged through LDS with coalesced copies, 0 = per-lane fragment loads. */
-int psalm_heads_set_variant(int staged);
-/* Post-norm sub-layer tail of the mask decoder, fused: y = LayerNorm(residual + a.w^T + bias) (attention out-projection + residual +
- * norm, mask2former_transformer_decoder.py:40-50, 99-111).  a (rows,K) bf16; w (D,K) bf16; residual (rows,D) f32 or NULL; outputs as
- * psalm_layernorm3: y f32, y2 = bf16(y) or NULL, y3 = bf16(y + add[row % add_rows]) or NULL.  D in {64,128,256}, K % 16 == 0, K <= 512. */
-int psalm_linear_res_ln(const void* a_bf16, long lda, const void* w_bf16, const float* bias, const float* residual, long ldr,
-                        const float* gamma, const float* beta, float eps, float* y, void* y2_bf16, const float* add, int add_rows,
-                        void* y3_bf16, int rows, int D, int K, void* stream);
 /* class_name_semantic_inference (llava_phi.py:402-406) fused for the bf16 mode: sem[c,p] = sum_q probsT[c,q] * sigmoid(mask[q,p]) in
  * one pass over the mask logits (no sigmoid^T tensor in HBM).  probsT (C,128) bf16 from psalm_class_softmax; Q <= 128, C <= 160.
  * mask_score (Q) f32 or NULL: psalm_mask_scores' result from the same read (workspace Q*512*2 floats, else NULL). */

@@ -52,7 +52,7 @@ class _ProfiledLib:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
         if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version",
-                                                         "psalm_gemm_set_tile_policy", "psalm_heads_set_variant") or name.endswith("_workspace"):
+                                                         "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -608,44 +608,6 @@ class Ops:
         rc = self.lib.psalm_sigmoid_transpose(self._p(mask), self._p(out), _dt(out), Q, c_long(HW), Kpad, self._stream())
         self._check(rc, "psalm_sigmoid_transpose")
         return out
-
-    def heads_variant(self, staged: bool):
-        """A/B switch of ln_mlp3 / linear_res_ln: weights staged through LDS (default) or per-lane fragment loads."""
-        self._check(self.lib.psalm_heads_set_variant(1 if staged else 0), "psalm_heads_set_variant")
-
-    def ln_mlp3(self, x, gamma, beta, ws, bs, eps=1e-5):
-        """x (rows,D) f32 -> (LayerNorm(x) bf16, MLP3(LayerNorm(x)) bf16): decoder_norm + mask_embed in one launch.
-        ws: three (D,D) bf16 weights, bs: three (D) f32 biases."""
-        rows, D = x.shape
-        if x.dtype != torch.float32 or x.stride(1) != 1 or any(w.dtype != torch.bfloat16 or tuple(w.shape) != (D, D) or not w.is_contiguous()
-                                                              for w in ws):
-            raise PsalmHipError("ln_mlp3: f32 rows, three contiguous (D,D) bf16 weights")
-        ln = self.empty(rows, D, dtype=torch.bfloat16)
-        out = self.empty(rows, D, dtype=torch.bfloat16)
-        rc = self.lib.psalm_ln_mlp3(self._p(x), c_long(x.stride(0)), self._p(gamma), self._p(beta), ctypes.c_float(eps),
-                                    self._p(ws[0]), self._p(bs[0]), self._p(ws[1]), self._p(bs[1]), self._p(ws[2]), self._p(bs[2]),
-                                    self._p(ln), self._p(out), rows, D, self._stream())
-        self._check(rc, "psalm_ln_mlp3")
-        return ln, out
-
-    def linear_res_ln(self, a, w, bias, residual, gamma, beta, eps=1e-5, out2=None, add=None, out3=None):
-        """LayerNorm(residual + a @ w.T + bias) in one launch.  a (rows,K) bf16, w (D,K) bf16, residual (rows,D) f32;
-        returns y (rows,D) f32; out2 (bf16 copy) / out3 (bf16 of y + add[row % add.shape[0]]) are filled when given."""
-        rows, K = a.shape
-        D = w.shape[0]
-        if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.stride(1) != 1 or not w.is_contiguous() or w.shape[1] != K:
-            raise PsalmHipError("linear_res_ln: bf16 a (rows,K) and contiguous bf16 w (D,K)")
-        if residual is not None and (residual.dtype != torch.float32 or residual.stride(1) != 1):
-            raise PsalmHipError("linear_res_ln: f32 residual")
-        y = self.empty(rows, D)
-        rc = self.lib.psalm_linear_res_ln(self._p(a), c_long(a.stride(0)), self._p(w), self._p(bias) if bias is not None else None,
-                                          self._p(residual) if residual is not None else None,
-                                          c_long(residual.stride(0) if residual is not None else 0), self._p(gamma), self._p(beta),
-                                          c_float(eps), self._p(y), self._p(out2) if out2 is not None else None,
-                                          self._p(add) if add is not None else None, add.shape[0] if add is not None else 0,
-                                          self._p(out3) if out3 is not None else None, rows, D, K, self._stream())
-        self._check(rc, "psalm_linear_res_ln")
-        return y
 
     def semantic_from_masks(self, mask, probsT, want_mask_score=False):
         """mask (Q,HW) f32 logits, probsT (C,128) bf16 -> (C,HW) f32 = probsT @ sigmoid(mask), one pass over the logits; with

@@ -106,7 +106,6 @@ class PSALM:
         self.llm_fp8 = precision == "fp8"             # Phi projections on e4m3 MFMA (per-row scales); everything else as "bf16"
         self.x3 = precision == "f16x3"                # fp32 activations, GEMM operands in split-f16 form (hip_ops.SplitF16)
         self.wdt = torch.float32 if precision in ("fp32", "f16x3") else torch.bfloat16   # weight / GEMM-operand dtype
-        self.fuse_heads = False                                               # see predictor()
         self.adt = self.wdt                                                     # GEMM-feeding activation dtype
         self.device = self.ops.device
         self.seg_task = cfg.seg_task
@@ -787,21 +786,11 @@ class PSALM:
                            out_dtype=out_dtype if last else self.adt)
             return x
 
-        # single-launch decoder heads / sub-layer tails (psalm_ln_mlp3, psalm_linear_res_ln).  OFF by default: with 32-row blocks only
-        # 4 CUs stream the weights and the r01 measurement on MI355X has them at 45 / 38 us per launch against 49 / 23 us for the
-        # separate launches (weight fragments fetched uncoalesced by 4 blocks) -- kept behind the switch, tested.
-        fused_head = self.fuse_heads and self.adt == torch.bfloat16 and self.wdt == torch.bfloat16 and D in (64, 128, 256)
-        fused_tail = mfma and fused_head and D <= 512
-
         mf_w = self._wop(mf)                                        # f16x3: the mask features are split once for the 10 head passes
 
         def mask_head(out):
-            if fused_head:                                          # decoder_norm + the 3 mask_embed layers in one launch (10x per image)
-                dec, me = o.ln_mlp3(out, w["pr.dn.g"], w["pr.dn.b"], [w[f"pr.mask_embed{j}.w"] for j in range(3)],
-                                    [w[f"pr.mask_embed{j}.b"] for j in range(3)])
-            else:
-                dec = o.layernorm(out, w["pr.dn.g"], w["pr.dn.b"], out_dtype=self.adt)
-                me = mlp(dec, "mask_embed", 3, self.adt)
+            dec = o.layernorm(out, w["pr.dn.g"], w["pr.dn.b"], out_dtype=self.adt)
+            me = mlp(dec, "mask_embed", 3, self.adt)
             return dec, o.gemm(me, mf_w, out_dtype=torch.float32)   # (Q, H2*W2) fp32 mask logits
 
         if mfma:
@@ -825,12 +814,8 @@ class PSALM:
                 a = o.mha_attention(qp, Kl[l][:, j * D:(j + 1) * D], Vl[l][:, j * D:(j + 1) * D], 1, Q, h * w_, nh, amask, flags)
             out_a = o.empty(Q, D, dtype=self.adt) if mfma else None          # bf16 copy of the stream = next GEMM operand
             out_q = o.empty(Q, D, dtype=self.adt) if mfma else None          # ... and stream + query_embed, from the same LayerNorm pass
-            if fused_tail:      # out-projection + residual + LayerNorm in one launch (two of them per layer)
-                out = o.linear_res_ln(a, w[f"pr{i}.co.w"], w[f"pr{i}.co.b"], out, w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"],
-                                      out2=out_a, add=qe, out3=out_q)
-            else:
-                out = o.layernorm(o.gemm(a, w[f"pr{i}.co.w"], w[f"pr{i}.co.b"], residual=out, out_dtype=torch.float32),
-                                  w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"], out2=out_a, add=qe if mfma else None, out3=out_q)
+            out = o.layernorm(o.gemm(a, w[f"pr{i}.co.w"], w[f"pr{i}.co.b"], residual=out, out_dtype=torch.float32),
+                              w[f"pr{i}.cn.g"], w[f"pr{i}.cn.b"], out2=out_a, add=qe if mfma else None, out3=out_q)
             if not mfma:
                 out_q = o.add_bcast(out, qe, out_dtype=self.adt)
             qk = o.gemm(out_q, w[f"pr{i}.sqk.w"], w[f"pr{i}.sqk.b"], out_dtype=self.adt)
@@ -840,11 +825,8 @@ class PSALM:
             else:
                 v = o.gemm(out, w[f"pr{i}.sv.w"], w[f"pr{i}.sv.b"], out_dtype=self.adt)
                 a = o.mha_attention(qk[:, :D], qk[:, D:], v, 1, Q, Q, nh)
-            if fused_tail:
-                out = o.linear_res_ln(a, w[f"pr{i}.so.w"], w[f"pr{i}.so.b"], out, w[f"pr{i}.sn.g"], w[f"pr{i}.sn.b"], out2=out_a)
-            else:
-                out = o.layernorm(o.gemm(a, w[f"pr{i}.so.w"], w[f"pr{i}.so.b"], residual=out, out_dtype=torch.float32),
-                                  w[f"pr{i}.sn.g"], w[f"pr{i}.sn.b"], out2=out_a)
+            out = o.layernorm(o.gemm(a, w[f"pr{i}.so.w"], w[f"pr{i}.so.b"], residual=out, out_dtype=torch.float32),
+                              w[f"pr{i}.sn.g"], w[f"pr{i}.sn.b"], out2=out_a)
             hdd = o.gemm(out_a if mfma else out, w[f"pr{i}.f1.w"], w[f"pr{i}.f1.b"], act=H.ACT_RELU, out_dtype=self.adt)
             out_q = o.empty(Q, D, dtype=self.adt) if mfma else None
             out = o.layernorm(o.gemm(hdd, w[f"pr{i}.f2.w"], w[f"pr{i}.f2.b"], residual=out, out_dtype=torch.float32),

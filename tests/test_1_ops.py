@@ -355,64 +355,6 @@ def test_semantic_from_masks(ops, Q, C, HW):
     assert (got - full).abs().max() <= 2 ** -7 * full.abs().max()
 
 
-@pytest.mark.parametrize("staged", [True, False])
-@pytest.mark.parametrize("rows,D", [(100, 256), (12, 64), (33, 128)])
-def test_ln_mlp3_fused_head(ops, rows, D, staged):
-    """decoder_norm + 3-layer mask_embed MLP in one launch vs LayerNorm -> Linear/ReLU x2 -> Linear in float64 on the same bf16
-    weights (bf16 activations between the layers, as in the unfused bf16 path)."""
-    from psalm_amd import hip_ops as H
-    g = torch.Generator().manual_seed(rows + D)
-    x = torch.randn(rows, D, generator=g) * 2 + 0.3
-    ga, be = torch.randn(D, generator=g), torch.randn(D, generator=g) * 0.1
-    ws = [(torch.randn(D, D, generator=g) * D ** -0.5).bfloat16() for _ in range(3)]
-    bs = [torch.randn(D, generator=g) * 0.1 for _ in range(3)]
-    d = ops.device
-    ops.heads_variant(staged)                                        # weights staged through LDS / per-lane fragment loads
-    try:
-        ln, out = ops.ln_mlp3(x.to(d), ga.to(d), be.to(d), [w.to(d) for w in ws], [b.to(d) for b in bs], eps=1e-5)
-    finally:
-        ops.heads_variant(True)
-    want_ln = torch.nn.functional.layer_norm(x.double(), (D,), ga.double(), be.double(), 1e-5)
-    assert (ln.cpu().double() - want_ln).abs().max() <= 2 ** -8 * want_ln.abs().max()
-    h = ln.cpu().double()                                            # continue from the kernel's own bf16 LayerNorm output
-    for j in range(3):
-        h = h @ ws[j].double().t() + bs[j].double()
-        if j < 2:
-            h = torch.relu(h).bfloat16().double()
-    assert (out.cpu().double() - h).abs().max() <= 2 ** -7 * h.abs().max()
-    # and against the unfused kernels of the bf16 path
-    ln2 = ops.layernorm(x.to(d), ga.to(d), be.to(d), out_dtype=torch.bfloat16)
-    y = ln2
-    for j in range(3):
-        y = ops.gemm(y, ws[j].to(d), bs[j].to(d), act=0 if j == 2 else H.ACT_RELU, out_dtype=torch.bfloat16)
-    assert (out.cpu().float() - y.cpu().float()).abs().max() <= 2 ** -6 * h.abs().max()
-
-
-@pytest.mark.parametrize("staged", [True, False])
-@pytest.mark.parametrize("rows,D,K", [(100, 256, 256), (12, 64, 64), (40, 128, 320), (70, 256, 512), (20, 64, 48)])
-def test_linear_res_ln_fused(ops, rows, D, K, staged):
-    """out-projection + residual + LayerNorm (+ bf16 copy, + bf16 copy with the query embedding added) in one launch."""
-    g = torch.Generator().manual_seed(rows + D + K)
-    a = torch.randn(rows, K, generator=g).bfloat16()
-    w = (torch.randn(D, K, generator=g) * K ** -0.5).bfloat16()
-    bias, res = torch.randn(D, generator=g) * 0.2, torch.randn(rows, D, generator=g)
-    ga, be, add = torch.randn(D, generator=g), torch.randn(D, generator=g) * 0.1, torch.randn(rows, D, generator=g)
-    d = ops.device
-    o2 = torch.empty(rows, D, dtype=torch.bfloat16, device=d)
-    o3 = torch.empty(rows, D, dtype=torch.bfloat16, device=d)
-    ops.heads_variant(staged)                                        # (K % 64 != 0 always takes the per-lane variant)
-    y = ops.linear_res_ln(a.to(d), w.to(d), bias.to(d), res.to(d), ga.to(d), be.to(d), 1e-5, out2=o2, add=add.to(d), out3=o3)
-    pre = a.double() @ w.double().t() + bias.double() + res.double()
-    want = torch.nn.functional.layer_norm(pre, (D,), ga.double(), be.double(), 1e-5)
-    assert (y.cpu().double() - want).abs().max() <= 2e-5 * want.abs().max()
-    assert (o2.cpu().double() - want).abs().max() <= 2 ** -8 * want.abs().max()
-    assert (o3.cpu().double() - (want + add.double())).abs().max() <= 2 ** -8 * (want + add.double()).abs().max()
-    y_plain = ops.linear_res_ln(a.to(d), w.to(d), None, None, ga.to(d), be.to(d))
-    ops.heads_variant(True)
-    want_plain = torch.nn.functional.layer_norm(a.double() @ w.double().t(), (D,), ga.double(), be.double(), 1e-5)
-    assert (y_plain.cpu().double() - want_plain).abs().max() <= 2e-5 * want_plain.abs().max()
-
-
 def test_im2col_and_convs(ops):
     g = torch.Generator().manual_seed(9)
     img = torch.randn(2, 3, 18, 13, generator=g)

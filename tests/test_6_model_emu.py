@@ -100,13 +100,11 @@ def test_tiny_eval_seg_postprocess_fp32(task, batch, pad):
 
 def test_tiny_eval_seg_bf16_mode_fused_paths():
     """precision="bf16" end to end on the emulator (the mode bench.py measures): bf16 GEMM operands on the direct-to-LDS kernels,
-    MFMA attention kernels, split-K + fused LayerNorm, the fused decoder heads (LayerNorm + mask_embed MLP; out-projection + residual +
-    LayerNorm) and -- with 72 queries, i.e. a 128-wide padded K -- the fused sigmoid / semantic / mask-score pass.  Tolerances are bf16-operand level against the fp32 oracle."""
+    MFMA attention kernels, split-K + fused LayerNorm and -- with 72 queries, i.e. a 128-wide padded K -- the fused sigmoid / semantic / mask-score pass.  Tolerances are bf16-operand level against the fp32 oracle."""
     cfg = dataclasses.replace(PsalmConfig.tiny("panoptic"), md_queries=72)
     sd = make_state_dict(cfg, seed=12)
     inputs = make_inputs(cfg, "panoptic", size=128, batch=1, seed=4, num_classes=9)     # 4x4 / 8x8 / 16x16 levels: MFMA attention path
     model = PSALM(cfg, sd, ops=make_ops("emu"), precision="bf16")
-    model.fuse_heads = True                 # also the single-launch decoder heads (off by default, see PSALM.predictor)
     torch.manual_seed(5)
     w = O.eval_seg(sd, cfg, **inputs)[0]
     torch.manual_seed(5)

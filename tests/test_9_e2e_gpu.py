@@ -154,27 +154,6 @@ def test_tiny_vs_oracle_on_gpu(task, batch):
             assert err < tol, (precision, err)
 
 
-def test_tiny_fused_decoder_heads_on_gpu():
-    """PSALM.fuse_heads (single-launch LayerNorm + mask_embed MLP and out-projection + residual + LayerNorm; off by default): same
-    results as the separate launches up to bf16 rounding of the intermediate activations, and within the bf16 tolerance of the oracle."""
-    from psalm_amd.model import PSALM
-    cfg = PsalmConfig.tiny("panoptic")
-    sd = make_state_dict(cfg, seed=12)
-    inputs = make_inputs(cfg, "panoptic", size=128, batch=1, seed=4, num_classes=9)      # 4x4 / 8x8 / 16x16 levels: MFMA attention path
-    torch.manual_seed(5)
-    want = O.eval_seg(sd, cfg, **inputs)[0]["mask_pred"]
-    outs = {}
-    for fused in (False, True):
-        model = PSALM(cfg, sd, precision="bf16")
-        model.fuse_heads = fused
-        torch.manual_seed(5)
-        outs[fused] = model.eval_seg(**inputs)[0]["mask_pred"].cpu()
-        err = float((outs[fused] - want).abs().max() / want.abs().max())
-        _report(test="tiny_fused_heads", fused=fused, mask_pred_err=err)
-        assert err < 8e-2, (fused, err)
-    assert float((outs[True] - outs[False]).abs().max() / want.abs().max()) < 4e-2
-
-
 @pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 2)])
 def test_graph_replay_is_bitwise_eager(task, batch):
     """use_graphs=True: 1st call eager, 2nd call captures the launch sequence into a hipGraph, later calls replay it with
