@@ -133,9 +133,9 @@ int psalm_iou_counts(const void* pred, int pred_is_u8, const unsigned char* tgt,
                      long long* counts_zeroed, void* stream);
 
 /* fp32 matrix-core MHA core of the predictor (nn.MultiheadAttention, mask2former_transformer_decoder.py:645-666; bool mask with the
- * all-masked-row rule :647) for the fp32 / f16x3 modes: exact-fp32 products (v_mfma_f32_16x16x4_f32), split over 256-key chunks.
+ * all-masked-row rule :647) for the fp32 / f16x3 modes: exact-fp32 products (v_mfma_f32_16x16x4_f32), split over 64..256-key chunks.
  * Same operands as psalm_mha_attention (fp32, row strides in elements, head_dim 32, Lq <= 128) + a workspace of
- * psalm_mha_attention_f32_workspace(B, heads, Lq, Lk) bytes (0 when Lk <= 256). */
+ * psalm_mha_attention_f32_workspace(B, heads, Lq, Lk) bytes (0 when the keys fit one chunk). */
 long psalm_mha_attention_f32_workspace(int B, int heads, int Lq, int Lk);
 int psalm_mha_attention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* out, long ldo,
                             const unsigned char* mask, const unsigned char* row_all_masked, void* workspace, int B, int Lq, int Lk, int heads,

@@ -105,8 +105,9 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
 //   statistics of a query live in the 4 lanes {q, q+16, q+32, q+48} (two xor-shuffles);
 //   O^T (16 d x 16 q)   += V_tile^T . P^T   4 MFMAs per key tile and d-tile, P straight from the score registers: step r contracts the
 //                                          keys 4 kk + r that lane (q, kk) holds in register r; V is read un-transposed from LDS.
-// K / V rows are padded to 36 floats: the 16-byte K fragment reads of 16 consecutive rows and the 4-byte V reads of a step hit 64
-// distinct banks.  3 waves per CU (43.6 KB of LDS each).
+// Only V (+ the bias column) is staged in LDS (rows padded to 36 floats: the 4-byte V reads of a step hit 64 distinct banks); the K
+// fragments -- 32 bytes per lane, each needed once per query tile -- come straight from global / L1 (a window-head's K is 18 KB).
+// 22.8 KB of LDS per wave instead of 43.6 KB: 7 instead of 3 resident waves per CU (r02: 3 waves left one SIMD in four idle).
 template <int HD, int WS>
 __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                        float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift) {
@@ -114,15 +115,13 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int N = WS * WS, NT = N / 16, LS = HD + 4, NB = (2 * WS - 1) * (2 * WS - 1);
     HIP_DYNAMIC_SHARED(float, smem)
-    float* Ks = smem;                       // [N][LS]
-    float* Vs = Ks + N * LS;                // [N][LS]
+    float* Vs = smem;                       // [N][LS]
     float* Bs = Vs + N * LS;                // [NB]
     const int win = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, n16 = lane & 15, kk = lane >> 4;
     const long row0 = (long)win * N;
     for (int e = lane; e < N * (HD / 4); e += 64) {                      // 144 rows x 8 float4 per operand
         const int r = e >> 3, c4 = (e & 7) * 4;
         const float* p = qkv + (row0 + r) * 3 * C + h * HD + c4;
-        *reinterpret_cast<psalm_f32x4*>(&Ks[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + C);
         *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
     }
     for (int e = lane; e < NB; e += 64) Bs[e] = bias_table[(long)e * heads + h];
@@ -162,7 +161,7 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* kp = &Ks[(16 * tk + n16) * LS + 8 * kk];
+            const float* kp = qkv + (row0 + 16 * tk + n16) * 3 * C + C + h * HD + 8 * kk;
             const psalm_f32x4 k0 = reinterpret_cast<const psalm_f32x4*>(kp)[0], k1 = reinterpret_cast<const psalm_f32x4*>(kp)[1];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], acc, 0, 0, 0);
@@ -220,7 +219,7 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
     if (nwin == 0) return 0;
     const int N = ws * ws;
     if (dtype == PSALM_F32 && ws == 12 && C % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {     // fp32 matrix-core kernel
-        const size_t lds = (size_t)(2 * N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
+        const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
         hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
                            (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
         PSALM_LAUNCH_END("psalm_window_attention");
@@ -798,24 +797,29 @@ extern "C" int psalm_mha_attention(const void* q, long ldq, const void* k, long 
 // ---- fp32 matrix-core form, split over keys (v_mfma_f32_16x16x4_f32), used for fp32 buffers.
 // The per-query-wave kernel above re-reads every K / V row once per query (800 waves x Lk rows x 256 B from L2 at Lk = 16384) and does the
 // products on the VALU (2.6 ms of a 34 ms f16x3 image).  Here one wavefront owns ALL queries (<= 128, NQT tiles of 16) of one head for a
-// chunk of 256 keys: Q fragments resident in registers, K / V tiles of 64 keys staged in LDS once, swapped products
+// chunk of 64..256 keys: Q fragments resident in registers, K / V tiles of 64 keys staged in LDS once, swapped products
 // (S^T = K . Q^T, O^T += V^T . P^T with P straight from the score registers, as in the window kernel), an online-softmax state per
 // query tile.  heads x ceil(Lk / 256) wavefronts; with more than one chunk each writes (O unnormalised, m, l) to the workspace and
 // mha_f32_combine_kernel merges the chunks.
-#define MHA_F32_CHUNK 256
+// keys per wavefront: as few as fill the chip (heads x chunks >= ~1024 wavefronts = one per SIMD), at least one 64-key LDS tile
+static int mha_f32_chunk(int B, int heads, int Lk) {
+    long c = ((long)Lk * heads * B + 1023) / 1024;
+    c = (c + 63) / 64 * 64;
+    return (int)(c < 64 ? 64 : (c > 256 ? 256 : c));
+}
 template <int NQT>
 __global__ void __launch_bounds__(64) mha_attention_f32_mfma_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
                                                                     const float* __restrict__ V, long ldv, float* __restrict__ O, long ldo,
                                                                     const unsigned char* __restrict__ mask,
                                                                     const unsigned char* __restrict__ row_all_masked, float* __restrict__ part,
-                                                                    int Lq, int Lk, int heads, int splits, float scale) {
+                                                                    int Lq, int Lk, int heads, int splits, int chunk, float scale) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int HD = 32, LS = HD + 4, KT = 64;
     __shared__ __attribute__((aligned(16))) float Ks[KT * LS];
     __shared__ __attribute__((aligned(16))) float Vs[KT * LS];
     const int lane = threadIdx.x, n16 = lane & 15, kk = lane >> 4;
     const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int k_lo = sp * MHA_F32_CHUNK, k_hi = min(Lk, k_lo + MHA_F32_CHUNK);
+    const int k_lo = sp * chunk, k_hi = min(Lk, k_lo + chunk);
     float qf[NQT][8];
     const unsigned char* mrow[NQT];
     bool qok[NQT], use_m[NQT];
@@ -970,7 +974,7 @@ __global__ void __launch_bounds__(256) mha_f32_combine_kernel(const float* __res
 }
 
 extern "C" long psalm_mha_attention_f32_workspace(int B, int heads, int Lq, int Lk) {
-    const int splits = cdiv(Lk, MHA_F32_CHUNK);
+    const int splits = cdiv(Lk, mha_f32_chunk(B, heads, Lk));
     return splits > 1 ? (long)B * heads * splits * Lq * 36 * (long)sizeof(float) : 0;
 }
 
@@ -983,14 +987,15 @@ extern "C" int psalm_mha_attention_f32(const float* q, long ldq, const float* k,
     PSALM_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 &&
                         (uintptr_t)v % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_mha_attention_f32: 16-byte aligned rows");
     if (B == 0 || Lk == 0) return 0;
-    const int splits = cdiv(Lk, MHA_F32_CHUNK);
-    PSALM_CHECK_ARG(splits == 1 || workspace != nullptr, "psalm_mha_attention_f32: workspace required when Lk > 256");
+    const int chunk = mha_f32_chunk(B, heads, Lk);
+    const int splits = cdiv(Lk, chunk);
+    PSALM_CHECK_ARG(splits == 1 || workspace != nullptr, "psalm_mha_attention_f32: workspace required when the keys are split");
     const float scale = 1.0f / sqrtf((float)head_dim);
     const dim3 grid(splits, heads, B);
     const int nqt = cdiv(Lq, 16);
     hipStream_t s = (hipStream_t)stream;
 #define MHA_F32_LAUNCH(N_) hipLaunchKernelGGL((mha_attention_f32_mfma_kernel<N_>), grid, dim3(64), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, mask, \
-                                              row_all_masked, (float*)workspace, Lq, Lk, heads, splits, scale)
+                                              row_all_masked, (float*)workspace, Lq, Lk, heads, splits, chunk, scale)
     if (nqt <= 1) MHA_F32_LAUNCH(1);
     else if (nqt <= 2) MHA_F32_LAUNCH(2);
     else if (nqt <= 4) MHA_F32_LAUNCH(4);
