@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -96,6 +97,8 @@ def main():
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"
+    if args.no_overlap:
+        model.overlap_streams = False
     bcast = None
     if world > 1:
         nbytes, secs = broadcast_weights(model, src=0)          # RCCL over xGMI, one-off
@@ -131,6 +134,8 @@ def main():
     if rank == 0:
         recs = []
         model.use_graphs = False                                  # per-launch events need the eager launch path
+        model.overlap_streams = False                             # ... and one stream: the timed region runs the pixel decoder concurrently with
+        #                                                           the LLM (f16x3), which would stretch every per-launch duration measured here
         model.eval_seg(**inputs)
         model.ops.lib.records = recs
         nprof = 3

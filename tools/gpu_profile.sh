@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 timeout 600 python bench.py --breakdown gpurun_out/${TAG}_breakdown.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-600
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-side-modes --eager"
+CMD="python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-side-modes --eager --no-overlap"
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -- $CMD > $R/gpurun_out/${TAG}_prof_kt.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- $CMD > $R/gpurun_out/${TAG}_prof_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -- $CMD > $R/gpurun_out/${TAG}_prof_write.log 2>&1
