@@ -101,6 +101,14 @@ int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* W
  * psalm_gemm_x3: C = act(A.W^T + bias) + residual, C / residual fp32, from split operands A2 (M,2Kp) / W2 (N,2Kp) + their scales:
  *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo, fp32 accumulate, scales in the epilogue; tiles / split-K as psalm_gemm. */
 int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream);
+/* im2col (K order ky,kx,c; as psalm_im2col_nhwc) emitted directly in split form -- the convolution-as-GEMM A operand of the f16x3 mode
+ * (F.conv2d at multimodal_projector/builder.py:85-111 and msdeformattn.py:248-254) without the fp32 im2col matrix in HBM. */
+int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
+/* LayerNorm whose result leaves in split-f16 form (the next GEMM's A operand in the f16x3 mode; nn.LayerNorm at modeling_phi.py:263-300,
+ * msdeformattn.py:57-66): y = LN(x) fp32 (optional) + split(y) (optional) + split(y + add[row % add_rows]) (optional), each split as
+ * psalm_split_f16 writes it (rows of 2*ceil64(C) f16 + inv_scale).  fp32 in, C % 8 == 0, C <= 2048. */
+int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C, float eps,
+                          void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, void* stream);
 int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);

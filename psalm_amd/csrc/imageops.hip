@@ -261,6 +261,76 @@ extern "C" int psalm_region_pool(const float* tokens, const int* img_of_region, 
     PSALM_LAUNCH_END("psalm_region_pool");
 }
 
+// ---------------------------------------------------------------- im2col straight into split-f16 form (precision = "f16x3")
+// The A operand of a convolution-as-GEMM in the f16x3 mode: row m = output pixel, K = (ky, kx, c), emitted as [hi (Kp) | lo (Kp)] f16 with
+// a per-row power-of-two scale (see psalm_split_f16) WITHOUT materialising the fp32 im2col matrix: for the FPN 3x3 convolution at 256^2
+// (msdeformattn.py:248-254) that matrix is 604 MB written, read twice by the split and written again (2.4 GB of traffic); here the
+// 67 MB NHWC input is read (9x, from L2) and the 604 MB split operand written once.  One wavefront per output pixel, two passes over
+// its k*k taps (row maximum, then conversion); C % 8 == 0.
+__global__ void __launch_bounds__(256) im2col_split_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, float* __restrict__ inv_scale,
+                                                               int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int K, int Kp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * Ho * Wo) return;
+    const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((long)Wo * Ho));
+    const float* xb = x + (long)b * H * W * C;
+    auto load = [&](int e, float* v) {                       // 8 consecutive K elements starting at e (inside one tap: C % 8 == 0)
+        const int tap = e / C, c = e - tap * C;
+        const int ky = tap / k, kx = tap - ky * k;
+        const int y = oy * stride - pad + ky, xx = ox * stride - pad + kx;
+        if (e < K && y >= 0 && y < H && xx >= 0 && xx < W) ld8(xb + ((long)y * W + xx) * C + c, v);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+    };
+    float amax = 0.f;
+    for (int e = lane * 8; e < K; e += 512) {
+        float v[8];
+        load(e, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    }
+    amax = wave_max(amax);
+    int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int se = 13 - ex;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+    const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+    if (lane == 0) inv_scale[row] = inv;
+    unsigned short* orow = out + row * 2L * Kp;
+    for (int e = lane * 8; e < Kp; e += 512) {
+        float v[8];
+        load(e, v);
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a0 = v[2 * i] * sc, a1 = v[2 * i + 1] * sc;
+            const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+            const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+            hw[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        *reinterpret_cast<psalm_u32x4*>(orow + e) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+        *reinterpret_cast<psalm_u32x4*>(orow + Kp + e) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+    }
+}
+
+// x (B,H,W,C) f32 NHWC -> out (B*Ho*Wo, 2*Kp) f16 [hi | lo], Kp = ceil64(k*k*C), inv_scale (B*Ho*Wo): psalm_im2col_nhwc + psalm_split_f16
+// in one pass.  C % 8 == 0; 16-byte aligned x / out.
+extern "C" int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, int H, int W, int C, int k, int stride, int pad,
+                                      void* stream) {
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long rows = (long)B * Ho * Wo;
+    if (rows <= 0) return 0;
+    PSALM_CHECK_ARG(C > 0 && C % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_im2col_split_f16: C % 8 == 0, 16-byte aligned buffers");
+    const int K = k * k * C, Kp = (K + 63) / 64 * 64;
+    hipLaunchKernelGGL(im2col_split_f16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out,
+                       inv_scale, B, H, W, C, k, stride, pad, Ho, Wo, K, Kp);
+    PSALM_LAUNCH_END("psalm_im2col_split_f16");
+}
+
 // ---------------------------------------------------------------- image pre-processing
 // The reference's eval-time input pipeline (coco_panoptic_mapper.py:60-91,134-163): detectron2 ResizeShortestEdge -> Pillow
 // `Image.resize(..., BILINEAR)` on the uint8 image, FixedSizeCrop -> pad bottom/right with 128, then (x - mean) / std in fp32.

@@ -124,6 +124,127 @@ extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, in
     return psalm_layernorm3(x, x_dtype, ldx, y, y_dtype, ldy, y2_bf16, ldy2, nullptr, 0, nullptr, 0, gamma, beta, rows, C, eps, stream);
 }
 
+// ---------------------------------------------------------------- LayerNorm emitting the NEXT GEMM's A operand in split-f16 form (f16x3 mode)
+// y = LN(x) (fp32, optional) and, from the same registers, split(y) and / or split(y + add[row % add_rows]) as psalm_split_f16 would write
+// them ([hi (Kp) | lo (Kp)] f16 + per-row power-of-two scale): the separate split pass (read 8 B + write 4 B per element and one launch
+// per GEMM) disappears for LayerNorm-fed projections -- Phi's [k|v|q|fc1] input, the pixel decoder's value / offset / FFN inputs.
+// One wavefront per row, row in registers (C % 8 == 0, C <= 2048).
+__device__ __forceinline__ void emit_split8(const float* o8, float sc, unsigned short* hi_dst, unsigned short* lo_dst) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a0 = o8[2 * k] * sc, a1 = o8[2 * k + 1] * sc;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+        hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+}
+__device__ __forceinline__ void split_scale(float amax, float& sc, float& inv) {     // as psalm_split_f16: row maximum into [2^13, 2^14)
+    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+    sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+}
+__global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C,
+                                                              float eps, unsigned short* __restrict__ s1, float* __restrict__ inv1,
+                                                              const float* __restrict__ add, long add_rows, unsigned short* __restrict__ s2,
+                                                              float* __restrict__ inv2, int Kp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            ld8(xr + c, v[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[i][k];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float g8[8], b8[8];
+            ld8(gamma + c, g8);
+            ld8(beta + c, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[i][k] = (v[i][k] - mean) * rstd * g8[k] + b8[k]; a1 = fmaxf(a1, fabsf(v[i][k])); }
+            if (y) st8(y + row * ldy + c, v[i]);
+            if (s2) {
+                float d8[8];
+                ld8(add + (row % add_rows) * C + c, d8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a2 = fmaxf(a2, fabsf(v[i][k] + d8[k]));
+            }
+        }
+    }
+    float sc1, iv1, sc2 = 1.f, iv2 = 1.f;
+    split_scale(wave_max(a1), sc1, iv1);
+    if (s2) split_scale(wave_max(a2), sc2, iv2);
+    if (lane == 0) {
+        if (s1) inv1[row] = iv1;
+        if (s2) inv2[row] = iv2;
+    }
+    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < Kp) {
+            const bool in = c < C;
+            if (s1) emit_split8(in ? v[i] : zero8, sc1, s1 + row * 2L * Kp + c, s1 + row * 2L * Kp + Kp + c);
+            if (s2) {
+                float t8[8];
+                if (in) {
+                    ld8(add + (row % add_rows) * C + c, t8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t8[k] += v[i][k];
+                }
+                emit_split8(in ? t8 : zero8, sc2, s2 + row * 2L * Kp + c, s2 + row * 2L * Kp + Kp + c);
+            }
+        }
+    }
+}
+
+// x (rows,C) f32 row stride ldx; y (rows,C) f32 row stride ldy or NULL; split1 / inv1: split(y) or NULL; split2 / inv2: split(y + add[row %
+// add_rows]) or NULL (add (add_rows, C) f32).  Split rows are 2 * ceil64(C) f16, contiguous.  C % 8 == 0, C <= 2048, 16-byte aligned rows.
+extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
+                                     float eps, void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2,
+                                     void* stream) {
+    if (rows == 0) return 0;
+    PSALM_CHECK_ARG(C % 8 == 0 && C > 0 && C <= 2048, "psalm_layernorm_split: C % 8 == 0, C <= 2048");
+    PSALM_CHECK_ARG((uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0 && (!y || ((uintptr_t)y % 16 == 0 && (ldy * 4) % 16 == 0)) &&
+                        (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0 && (!split1 || (uintptr_t)split1 % 16 == 0) &&
+                        (!split2 || ((uintptr_t)split2 % 16 == 0 && add && add_rows > 0 && (uintptr_t)add % 16 == 0)),
+                    "psalm_layernorm_split: 16-byte aligned rows; split2 needs the `add` table");
+    PSALM_CHECK_ARG((!split1 || inv1) && (!split2 || inv2) && (split1 || split2 || y), "psalm_layernorm_split: outputs / scale arrays missing");
+    const int Kp = (C + 63) / 64 * 64;
+    hipLaunchKernelGGL(layernorm_split_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, rows, C, eps,
+                       (unsigned short*)split1, inv1, add, add_rows, (unsigned short*)split2, inv2, Kp);
+    PSALM_LAUNCH_END("psalm_layernorm_split");
+}
+
 // ---------------------------------------------------------------- Swin: LN1 + pad + cyclic shift + window partition
 // swin_trans.py:206-227.  x (B,H,W,C) -> out (B*nWh*nWw*ws*ws, C); padded tokens are exact zeros (the pad is
 // applied AFTER norm1, swin_trans.py:207-214); torch.roll(x,-s)[i] = x[(i+s) mod n].

@@ -323,6 +323,27 @@ class Ops:
         self._check(rc, "psalm_layernorm3")
         return out
 
+    def layernorm_split(self, x, gamma, beta, eps=1e-5, want_y=False, want_split=True, add=None):
+        """LayerNorm of float32 rows whose result leaves as the next GEMM's split-f16 A operand (f16x3 mode).
+        Returns (y float32 | None, SplitF16(y) | None, SplitF16(y + add[row % r]) | None)."""
+        rows, C = x.shape
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            raise PsalmHipError("layernorm_split: float32 rows")
+        Kp = (C + 63) // 64 * 64
+        y = self.empty(rows, C, dtype=torch.float32) if want_y else None
+        s1 = i1 = s2 = i2 = None
+        if want_split:
+            s1, i1 = self.empty(rows, 2 * Kp, dtype=torch.float16), self.empty(rows, dtype=torch.float32)
+        if add is not None:
+            if add.dtype != torch.float32 or add.shape[1] != C:
+                raise PsalmHipError("layernorm_split: float32 (r,C) `add` table")
+            s2, i2 = self.empty(rows, 2 * Kp, dtype=torch.float16), self.empty(rows, dtype=torch.float32)
+        rc = self.lib.psalm_layernorm_split(self._pv(x), c_long(x.stride(0)), self._p(y), c_long(C), self._p(gamma), self._p(beta), rows, C,
+                                            c_float(eps), self._p(s1), self._p(i1), self._p(add), c_long(add.shape[0] if add is not None else 0),
+                                            self._p(s2), self._p(i2), self._stream())
+        self._check(rc, "psalm_layernorm_split")
+        return y, (SplitF16(s1, i1, C) if want_split else None), (SplitF16(s2, i2, C) if add is not None else None)
+
     def swin_window_gather(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5, out_dtype=None):
         """x (B*H*W, C) -> LN + pad + roll(-shift) + window partition -> (B*nW*ws*ws, C)."""
         C = x.shape[-1]
@@ -552,6 +573,20 @@ class Ops:
         rc = self.lib.psalm_im2col_nhwc(self._p(x), self._p(out), _dt(x), B, H, W, C, k, stride, pad, self._stream())
         self._check(rc, "psalm_im2col_nhwc")
         return out
+
+    def im2col_split(self, x, B, H, W, k, stride, pad):
+        """im2col_nhwc + split_f16 in one pass: x (B*H*W, C) float32 NHWC tokens -> SplitF16 of the (B*Ho*Wo, k*k*C) patch matrix."""
+        C = x.shape[-1]
+        if x.dtype != torch.float32 or C % 8:
+            raise PsalmHipError("im2col_split: float32 input, C % 8 == 0")
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        K = k * k * C
+        Kp = (K + 63) // 64 * 64
+        t = self.empty(B * Ho * Wo, 2 * Kp, dtype=torch.float16)
+        inv = self.empty(B * Ho * Wo, dtype=torch.float32)
+        rc = self.lib.psalm_im2col_split_f16(self._p(x), self._p(t), self._p(inv), B, H, W, C, k, stride, pad, self._stream())
+        self._check(rc, "psalm_im2col_split_f16")
+        return SplitF16(t, inv, K)
 
     def resize_planes(self, x, H, W, crop=None, out_dtype=None):
         """x (N,h,w) -> bilinear (align_corners=False) -> (N,H,W); optional crop (hc,wc) of the input first."""

@@ -444,12 +444,13 @@ class PSALM:
             y = o.conv2d_nhwc(y, B, ho, wo, w["proj.c2f.w"], 3, 1, 1, bias=w["proj.c2f.b"], residual=ds,
                               act=H.ACT_RELU | H.ACT_POST_RESIDUAL)
             return o.gemm(y, w["proj.fc.w"], w["proj.fc.b"], out_dtype=torch.float32), ho * wo
-        c1 = o.im2col_nhwc(res5, B, h, w_, 3, 2, 1)
+        im2col = o.im2col_split if (self.x3 and res5.shape[-1] % 8 == 0) else o.im2col_nhwc   # f16x3: patches straight into split form
+        c1 = im2col(res5, B, h, w_, 3, 2, 1)
         y = o.gemm(c1, w["proj.c1.w"], w["proj.c1.b"], act=H.ACT_RELU, out_dtype=self.adt)
         ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
-        y = o.gemm(o.im2col_nhwc(y, B, ho, wo, 3, 1, 1), w["proj.c2.w"], out_dtype=self.adt)
-        ds = o.gemm(o.im2col_nhwc(res5, B, h, w_, 1, 2, 0), w["proj.ds.w"], w["proj.ds.b"], out_dtype=self.adt)
-        y = o.gemm(o.im2col_nhwc(y, B, ho, wo, 3, 1, 1), w["proj.c2f.w"], w["proj.c2f.b"], residual=ds,
+        y = o.gemm(im2col(y, B, ho, wo, 3, 1, 1), w["proj.c2.w"], out_dtype=self.adt)
+        ds = o.gemm(im2col(res5, B, h, w_, 1, 2, 0), w["proj.ds.w"], w["proj.ds.b"], out_dtype=self.adt)
+        y = o.gemm(im2col(y, B, ho, wo, 3, 1, 1), w["proj.c2f.w"], w["proj.c2f.b"], residual=ds,
                    act=H.ACT_RELU | H.ACT_POST_RESIDUAL, out_dtype=self.adt)
         return o.gemm(y, w["proj.fc.w"], w["proj.fc.b"], out_dtype=torch.float32), ho * wo
 
@@ -667,7 +668,10 @@ class PSALM:
         x = embeds
         big = o.empty(B * L, 3 * Hd + I, dtype=self.adt)
         fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
-        h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
+        if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
+            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps)[1]
+        else:
+            h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
             last = i == cfg.num_layers - 1
             ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
@@ -688,7 +692,10 @@ class PSALM:
                                  ln_dtype=torch.float32 if last else self.adt)
             else:
                 x = o.gemm(big[:, 2 * Hd:], w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
-                h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
+                if self.x3 and not last:
+                    h = o.layernorm_split(x, ng, nb, cfg.layer_norm_eps)[1]
+                else:
+                    h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
         return h
 
     # ======================================================================================= pixel decoder (one image)
@@ -726,6 +733,16 @@ class PSALM:
             value = o.gemm(src_a, w[q_ + "value.w"], w[q_ + "value.b"], out_dtype=self.adt)
             ow = o.gemm(qin, w[q_ + "ow.w"], w[q_ + "ow.b"], out_dtype=torch.float32)
             att = o.msda_fused(value.view(1, S, D), shapes, starts, ow.view(1, S, -1), M, out_dtype=self.adt).view(S, D)
+            if self.x3 and D % 8 == 0 and D <= 2048:
+                # f16x3: both LayerNorms hand the fp32 stream AND the following GEMMs' split-f16 operands over in one pass
+                # (linear1 input; next layer's value input = src and offset / weight input = src + pos)
+                src, src_s, _ = o.layernorm_split(o.gemm(att, w[q_ + "out.w"], w[q_ + "out.b"], residual=src, out_dtype=torch.float32),
+                                                  w[q_ + "n1.g"], w[q_ + "n1.b"], want_y=True)
+                hdd = o.gemm(src_s, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+                more = i + 1 < cfg.md_enc_layers
+                src, src_a, qin = o.layernorm_split(o.gemm(hdd, w[q_ + "l2.w"], w[q_ + "l2.b"], residual=src, out_dtype=torch.float32),
+                                                    w[q_ + "n2.g"], w[q_ + "n2.b"], want_y=True, want_split=more, add=lvl_pos if more else None)
+                continue
             mid_a = o.empty(S, D, dtype=self.adt) if dual else None
             src = o.layernorm(o.gemm(att, w[q_ + "out.w"], w[q_ + "out.b"], residual=src, out_dtype=torch.float32),
                               w[q_ + "n1.g"], w[q_ + "n1.b"], out2=mid_a)
@@ -748,7 +765,8 @@ class PSALM:
         if self.adt == torch.bfloat16 and D % 64 == 0:
             y = o.conv2d_nhwc(y, 1, H2, W2, w["pd.layer.w"], 3, 1, 1, bias=w["pd.layer.b"])
         else:
-            y = o.gemm(o.im2col_nhwc(y, 1, H2, W2, 3, 1, 1), w["pd.layer.w"], w["pd.layer.b"], out_dtype=self.adt)
+            cols = o.im2col_split(y, 1, H2, W2, 3, 1, 1) if (self.x3 and D % 8 == 0) else o.im2col_nhwc(y, 1, H2, W2, 3, 1, 1)
+            y = o.gemm(cols, w["pd.layer.w"], w["pd.layer.b"], out_dtype=self.adt)
         y = o.groupnorm_nhwc(y, w["pd.layer.gn.g"], w["pd.layer.gn.b"], 1, H2 * W2, G, relu=True, out_dtype=self.adt)
         mf = o.gemm(y, w["pd.mf.w"], w["pd.mf.b"], out_dtype=self.wdt)
         return mf, ms, shapes, (H2, W2)

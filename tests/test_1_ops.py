@@ -443,3 +443,27 @@ def test_semantic_from_masks_x3_fp32_class(ops, Q, C, HW):
     # ... and at every PIXEL relative to that pixel's own largest class score (per-pixel operand scale): label decisions at pixels
     # where every sigmoid is tiny see the same relative accuracy as anywhere else
     assert ((got - want).abs() <= 4e-6 * want.abs().amax(0, keepdim=True) + 1e-37).all()
+
+
+@pytest.mark.parametrize("rows,C", [(37, 256), (5, 2048), (130, 64), (9, 200)])
+def test_layernorm_split(ops, rows, C):
+    """psalm_layernorm_split == LayerNorm (fp32) followed by psalm_split_f16 of y and of y + add, bit for bit."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C + 8, generator=g)[:, 4:4 + C] * 3 + 1                       # row-strided view
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    add = torch.randn(7, C, generator=g)
+    d = ops.device
+    xd = x.to(d) if x.is_contiguous() else torch.randn(rows, C + 8, generator=torch.Generator().manual_seed(rows + C)).to(d)[:, 4:4 + C] * 3 + 1
+    y, s1, s2 = ops.layernorm_split(xd, ga.to(d), be.to(d), 1e-5, want_y=True, add=add.to(d))
+    y_ref = ops.layernorm(xd, ga.to(d), be.to(d), 1e-5)
+    assert torch.equal(y, y_ref)
+    want = torch.nn.functional.layer_norm(xd.cpu(), (C,), ga, be, 1e-5)
+    assert (y.cpu() - want).abs().max() < 1e-5 * want.abs().max() + 1e-6
+    r1 = ops.split_f16(y_ref)
+    r2 = ops.split_f16(ops.add_bcast(y_ref, add.to(d)))
+    for got, ref in ((s1, r1), (s2, r2)):
+        assert got.K == C and got.Kp == ref.Kp
+        assert torch.equal(got.t.cpu().view(torch.int16), ref.t.cpu().view(torch.int16)) and torch.equal(got.inv_scale.cpu(), ref.inv_scale.cpu())
+    # split-only form (no fp32 output)
+    y0, s0, _ = ops.layernorm_split(xd, ga.to(d), be.to(d), 1e-5)
+    assert y0 is None and torch.equal(s0.t.cpu().view(torch.int16), r1.t.cpu().view(torch.int16))

@@ -387,3 +387,14 @@ def test_gemm_f32_skinny_exact(ops, M, N, K, cd, has_res, act):
     got = ops.gemm(a.to(d), w.to(d), bias.to(d), res.to(d) if has_res else None, act, 0, out_dtype=DT[cd]).cpu().double()
     tol = (2 ** -8 if cd == "bf16" else 4e-6) * want.abs().max().item() + 1e-6
     assert (got - want).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("B,H,W,C,k,s,p", [(2, 9, 7, 8, 3, 1, 1), (1, 10, 12, 16, 3, 2, 1), (2, 8, 8, 24, 1, 2, 0), (1, 6, 5, 256, 3, 1, 1)])
+def test_im2col_split_equals_im2col_then_split(ops, B, H, W, C, k, s, p):
+    """psalm_im2col_split_f16 == psalm_im2col_nhwc followed by psalm_split_f16, bit for bit (hi, lo, scales, zero padding)."""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = (torch.randn(B * H * W, C, generator=g) * torch.exp2(torch.randint(-8, 8, (B * H * W, 1), generator=g).float())).to(ops.device)
+    a = ops.im2col_split(x, B, H, W, k, s, p)
+    b = ops.split_f16(ops.im2col_nhwc(x, B, H, W, k, s, p))
+    assert a.K == b.K and a.Kp == b.Kp and torch.equal(a.t.cpu().view(torch.int16), b.t.cpu().view(torch.int16))
+    assert torch.equal(a.inv_scale.cpu(), b.inv_scale.cpu())
