@@ -109,6 +109,12 @@ int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, i
  * psalm_split_f16 writes it (rows of 2*ceil64(C) f16 + inv_scale).  fp32 in, C % 8 == 0, C <= 2048. */
 int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C, float eps,
                           void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, void* stream);
+/* f16x3 forms of the two Swin LayerNorm-fused data-movement steps (swin_trans.py:206-227 norm1 + pad + shift + window partition;
+ * :235-251 window reverse + un-shift + residual, then norm2): the normalised rows leave as the split-f16 A operand of the GEMM they feed. */
+int psalm_swin_window_gather_split(const float* x, void* out, float* inv_out, const float* gamma, const float* beta, int B, int H, int W, int C,
+                                   int ws, int shift, float eps, void* stream);
+int psalm_swin_window_merge_ln_split(const float* win, const float* shortcut, float* out_x, void* h_split, float* h_inv, const float* gamma,
+                                     const float* beta, int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
 int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);

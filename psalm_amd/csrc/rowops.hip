@@ -6,6 +6,28 @@
 
 // ---------------------------------------------------------------- LayerNorm core (one wave, one row)
 // Two-pass (mean, then centred variance) like torch.nn.functional.layer_norm; the row is re-read from L1/L2.
+// split-f16 emission helpers (f16x3 mode; see psalm_split_f16 in gemm.hip)
+__device__ __forceinline__ void emit_split8(const float* o8, float sc, unsigned short* hi_dst, unsigned short* lo_dst) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a0 = o8[2 * k] * sc, a1 = o8[2 * k + 1] * sc;
+        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+        hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+}
+__device__ __forceinline__ void split_scale(float amax, float& sc, float& inv) {     // as psalm_split_f16: row maximum into [2^13, 2^14)
+    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+    sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+}
 template <typename TI>
 __device__ __forceinline__ void row_stats(const TI* __restrict__ x, int C, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
@@ -129,27 +151,6 @@ extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, in
 // them ([hi (Kp) | lo (Kp)] f16 + per-row power-of-two scale): the separate split pass (read 8 B + write 4 B per element and one launch
 // per GEMM) disappears for LayerNorm-fed projections -- Phi's [k|v|q|fc1] input, the pixel decoder's value / offset / FFN inputs.
 // One wavefront per row, row in registers (C % 8 == 0, C <= 2048).
-__device__ __forceinline__ void emit_split8(const float* o8, float sc, unsigned short* hi_dst, unsigned short* lo_dst) {
-    unsigned hw[4], lw[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float a0 = o8[2 * k] * sc, a1 = o8[2 * k + 1] * sc;
-        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-        hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-        lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-    }
-    *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
-    *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
-}
-__device__ __forceinline__ void split_scale(float amax, float& sc, float& inv) {     // as psalm_split_f16: row maximum into [2^13, 2^14)
-    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
-    int se = 13 - e;
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
-    sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
-    inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
-}
 __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C,
                                                               float eps, unsigned short* __restrict__ s1, float* __restrict__ inv1,
@@ -329,7 +330,8 @@ template <typename TW, typename TH>
 __global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __restrict__ win, const float* __restrict__ shortcut,
                                                                    float* __restrict__ out_x, TH* __restrict__ out_h,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                   int B, int H, int W, int C, int ws, int shift, float eps) {
+                                                                   int B, int H, int W, int C, int ws, int shift, float eps,
+                                                                   unsigned short* __restrict__ h_split, float* __restrict__ h_inv, int Kp) {
     const int lane = threadIdx.x & 63;
     const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws, N = ws * ws;
     const int Hp = nWh * ws, Wp = nWw * ws;
@@ -364,6 +366,30 @@ __global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __r
             for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
         }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    if (h_split) {                                               // f16x3: norm2's result leaves as the fc1 GEMM's split-f16 A operand
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+                float g8[8], b8[8];
+                ld8(gamma + c, g8);
+                ld8(beta + c, b8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[i][k] = (v[i][k] - mean) * rstd * g8[k] + b8[k]; amax = fmaxf(amax, fabsf(v[i][k])); }
+            }
+        }
+        float sc, inv;
+        split_scale(wave_max(amax), sc, inv);
+        if (lane == 0) h_inv[r] = inv;
+        const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < Kp) emit_split8(c < C ? v[i] : zero8, sc, h_split + r * 2L * Kp + c, h_split + r * 2L * Kp + Kp + c);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 64 + lane) * 8;
@@ -386,9 +412,96 @@ extern "C" int psalm_swin_window_merge_ln(const void* win, int win_dtype, const 
     PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048, "psalm_swin_window_merge_ln: C % 8 == 0 and C <= 2048");
     PSALM_DISPATCH(win_dtype, TW, PSALM_DISPATCH(h_dtype, TH, {
         hipLaunchKernelGGL((swin_window_merge_ln_kernel<TW, TH>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const TW*)win, shortcut, out_x, (TH*)out_h, gamma, beta, B, H, W, C, ws, shift, eps);
+                           (const TW*)win, shortcut, out_x, (TH*)out_h, gamma, beta, B, H, W, C, ws, shift, eps, nullptr, nullptr, 0);
     }));
     PSALM_LAUNCH_END("psalm_swin_window_merge_ln");
+}
+
+// f16x3 forms of the two Swin LayerNorm-fused data-movement kernels: the normalised rows leave as the split-f16 A operand of the GEMM
+// they feed (qkv after norm1 + window partition; fc1 after window reverse + residual + norm2) -- see psalm_layernorm_split.
+//   psalm_swin_window_merge_ln_split: win / shortcut / out_x fp32 as psalm_swin_window_merge_ln; h_split (B*H*W, 2*ceil64(C)) f16, h_inv.
+//   psalm_swin_window_gather_split  : x fp32 (B,H,W,C) -> split (B*nW*ws*ws, 2*ceil64(C)) f16 + inv; padded tokens are zero rows.
+extern "C" int psalm_swin_window_merge_ln_split(const float* win, const float* shortcut, float* out_x, void* h_split, float* h_inv,
+                                                const float* gamma, const float* beta, int B, int H, int W, int C, int ws, int shift,
+                                                float eps, void* stream) {
+    const long rows = (long)B * H * W;
+    if (rows == 0) return 0;
+    PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048 && h_split && h_inv, "psalm_swin_window_merge_ln_split: C % 8 == 0, C <= 2048, outputs required");
+    hipLaunchKernelGGL((swin_window_merge_ln_kernel<float, float>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, win, shortcut, out_x,
+                       (float*)nullptr, gamma, beta, B, H, W, C, ws, shift, eps, (unsigned short*)h_split, h_inv, (C + 63) / 64 * 64);
+    PSALM_LAUNCH_END("psalm_swin_window_merge_ln_split");
+}
+
+__global__ void __launch_bounds__(256) swin_window_gather_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, float* __restrict__ inv_out,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H,
+                                                                       int W, int C, int ws, int shift, float eps, int Kp) {
+    const int lane = threadIdx.x & 63;
+    const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws, N = ws * ws;
+    const int Hp = nWh * ws, Wp = nWw * ws;
+    const long rows = (long)B * nWh * nWw * N;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int tok = (int)(r % N);
+    long t = r / N;
+    const int ww = (int)(t % nWw);
+    t /= nWw;
+    const int wh = (int)(t % nWh);
+    const int b = (int)(t / nWh);
+    const int y = (wh * ws + tok / ws + shift) % Hp, xx = (ww * ws + tok % ws + shift) % Wp;
+    const bool live = y < H && xx < W;                            // (wave-uniform: one row per wavefront)
+    float v[4][8];
+    float sc = 1.f, inv = 1.f;
+    if (live) {
+        const float* xr = x + (((long)b * H + y) * W + xx) * C;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+                ld8(xr + c, v[i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[i][k];
+            }
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((i * 64 + lane) * 8 < C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+                float g8[8], b8[8];
+                ld8(gamma + c, g8);
+                ld8(beta + c, b8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[i][k] = (v[i][k] - mean) * rstd * g8[k] + b8[k]; amax = fmaxf(amax, fabsf(v[i][k])); }
+            }
+        }
+        split_scale(wave_max(amax), sc, inv);
+    }
+    if (lane == 0) inv_out[r] = inv;
+    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < Kp) emit_split8((live && c < C) ? v[i] : zero8, sc, out + r * 2L * Kp + c, out + r * 2L * Kp + Kp + c);
+    }
+}
+extern "C" int psalm_swin_window_gather_split(const float* x, void* out, float* inv_out, const float* gamma, const float* beta, int B, int H,
+                                              int W, int C, int ws, int shift, float eps, void* stream) {
+    const long rows = (long)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws) * ws * ws;
+    if (rows == 0) return 0;
+    PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_swin_window_gather_split: C % 8 == 0, C <= 2048, aligned");
+    hipLaunchKernelGGL(swin_window_gather_split_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, inv_out,
+                       gamma, beta, B, H, W, C, ws, shift, eps, (C + 63) / 64 * 64);
+    PSALM_LAUNCH_END("psalm_swin_window_gather_split");
 }
 
 // ---------------------------------------------------------------- Swin PatchMerging: 2x2 gather-concat + LN(4C)

@@ -354,6 +354,34 @@ class Ops:
         self._check(rc, "psalm_swin_window_gather")
         return out
 
+    def swin_window_gather_split(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5):
+        """swin_window_gather whose rows leave as the qkv GEMM's split-f16 A operand (f16x3 mode): x (B*H*W, C) float32 -> SplitF16."""
+        C = x.shape[-1]
+        if x.dtype != torch.float32 or C % 8 or C > 2048:
+            raise PsalmHipError("swin_window_gather_split: float32, C % 8 == 0, C <= 2048")
+        nWh, nWw = (H + ws - 1) // ws, (W + ws - 1) // ws
+        rows, Kp = B * nWh * nWw * ws * ws, (C + 63) // 64 * 64
+        t = self.empty(rows, 2 * Kp, dtype=torch.float16)
+        inv = self.empty(rows, dtype=torch.float32)
+        rc = self.lib.psalm_swin_window_gather_split(self._p(x), self._p(t), self._p(inv), self._p(gamma), self._p(beta), B, H, W, C, ws, shift,
+                                                     c_float(eps), self._stream())
+        self._check(rc, "psalm_swin_window_gather_split")
+        return SplitF16(t, inv, C)
+
+    def swin_window_merge_ln_split(self, win, shortcut, gamma, beta, B, H, W, ws, shift, eps=1e-5):
+        """swin_window_merge_ln with norm2's result as the fc1 GEMM's split-f16 A operand: (x_new float32, SplitF16(LayerNorm(x_new)))."""
+        C = shortcut.shape[-1]
+        if shortcut.dtype != torch.float32 or win.dtype != torch.float32 or C % 8 or C > 2048:
+            raise PsalmHipError("swin_window_merge_ln_split: float32 operands, C % 8 == 0, C <= 2048")
+        rows, Kp = shortcut.shape[0], (C + 63) // 64 * 64
+        out_x = torch.empty_like(shortcut)
+        t = self.empty(rows, 2 * Kp, dtype=torch.float16)
+        inv = self.empty(rows, dtype=torch.float32)
+        rc = self.lib.psalm_swin_window_merge_ln_split(self._p(win), self._p(shortcut), self._p(out_x), self._p(t), self._p(inv), self._p(gamma),
+                                                       self._p(beta), B, H, W, C, ws, shift, c_float(eps), self._stream())
+        self._check(rc, "psalm_swin_window_merge_ln_split")
+        return out_x, SplitF16(t, inv, C)
+
     def swin_window_merge(self, win, shortcut, B, H, W, ws, shift, out=None):
         """out (B*H*W, C) = shortcut + window_reverse/roll(+shift)/crop(win)."""
         C = shortcut.shape[-1]

@@ -414,11 +414,17 @@ class PSALM:
             for b in range(depth):
                 q = f"swin{s}.{b}."
                 shift = 0 if b % 2 == 0 else ws // 2
-                xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
+                x3f = self.x3 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048   # f16x3: norm1 / norm2 rows leave in split-f16 form
+                if x3f:
+                    xw = o.swin_window_gather_split(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift)
+                else:
+                    xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
                 aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
                 pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)
-                if x.shape[-1] % 8 == 0:
+                if x3f:
+                    x, h = o.swin_window_merge_ln_split(pw, x, w[q + "n2.g"], w[q + "n2.b"], B, Hc, Wc, ws, shift)
+                elif x.shape[-1] % 8 == 0:
                     x, h = o.swin_window_merge_ln(pw, x, w[q + "n2.g"], w[q + "n2.b"], B, Hc, Wc, ws, shift, h_dtype=self.adt)
                 else:
                     x = o.swin_window_merge(pw, x, B, Hc, Wc, ws, shift)

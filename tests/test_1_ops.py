@@ -467,3 +467,27 @@ def test_layernorm_split(ops, rows, C):
     # split-only form (no fp32 output)
     y0, s0, _ = ops.layernorm_split(xd, ga.to(d), be.to(d), 1e-5)
     assert y0 is None and torch.equal(s0.t.cpu().view(torch.int16), r1.t.cpu().view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,W,C,shift", [(1, 14, 20, 32, 0), (2, 12, 12, 64, 6), (1, 30, 25, 128, 6)])
+def test_swin_split_emitting_kernels(ops, B, H, W, C, shift):
+    """f16x3 forms of the Swin LN-fused kernels == the fp32 kernels followed by psalm_split_f16, bit for bit."""
+    ws = 12
+    g = torch.Generator().manual_seed(H * W + C + shift)
+    d = ops.device
+    x = (torch.randn(B * H * W, C, generator=g) * 2 + 0.5).to(d)
+    ga, be = torch.randn(C, generator=g).to(d), torch.randn(C, generator=g).to(d)
+    a = ops.swin_window_gather_split(x, ga, be, B, H, W, ws, shift)
+    ref = ops.swin_window_gather(x, ga, be, B, H, W, ws, shift).cpu().double()
+    # (the fp32 gather kernel sums the LayerNorm statistics in a different lane order: equal to fp32 round-off, not bit for bit)
+    Kp = a.Kp
+    rec = (a.t.cpu()[:, :C].double() + a.t.cpu()[:, Kp:Kp + C].double()) * a.inv_scale.cpu().double()[:, None]
+    assert (rec - ref).abs().max() <= 3e-6 * ref.abs().max()
+    assert (a.t.cpu()[:, C:Kp] == 0).all() and bool((ref.abs().sum(1) == 0).eq(rec.abs().sum(1) == 0).all())      # padded tokens: zero rows
+    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    win = torch.randn(B * nW * ws * ws, C, generator=g).to(d)
+    x1, h1 = ops.swin_window_merge_ln_split(win, x, ga, be, B, H, W, ws, shift)
+    x2, h2 = ops.swin_window_merge_ln(win, x, ga, be, B, H, W, ws, shift)
+    h2s = ops.split_f16(h2)
+    assert torch.equal(x1, x2)
+    assert torch.equal(h1.t.cpu().view(torch.int16), h2s.t.cpu().view(torch.int16)) and torch.equal(h1.inv_scale.cpu(), h2s.inv_scale.cpu())
