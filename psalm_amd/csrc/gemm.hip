@@ -288,10 +288,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // X3 = true: split-f16 operands (see GemmFastArgs::x3_kp): same 16-bit element traffic, copies and swizzle as the bf16 kernel; the K-tile
 // source columns are remapped, the matrix instruction is v_mfma_f32_32x32x16_f16 and the epilogue applies the per-row power-of-two
 // scales of A and W (as the fp8 variant does).  An fp32-class GEMM (22-bit operands, fp32 accumulate) at 1/3 of the f16 MFMA rate.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, bool X3 = false>
+// X3 = 2 ("slice" form of the split-f16 GEMM, for the tile configurations without the phased loop): instead of walking the 3 Kp-long
+// panel, a K step covers ONE 64-deep slice of the true K range and brings FOUR tiles (A hi, A lo, W hi, W lo) into the stage, from which
+// the three products hi.hi + lo.hi + hi.lo are formed: 4 instead of 6 tile copies per slice, 2/3 of the LDS fragment reads per MFMA, and
+// -- the point -- 3x the matrix work per barrier / per copy round trip.  The mid-size GEMMs of the image (Swin stage 2, pixel decoder:
+// 12..48 K steps) ran their K loops at L2 latency with X3 = 1 (r02k: 100-200 TFLOP/s algorithmic on the 128^2 / 64x128 tiles).
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, int X3 = 0>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV && !FP8), "PH8 configuration");
-    static_assert(!X3 || (BK == 64 && !CONV && !FP8), "split-f16 variant: 64-deep K tiles, plain GEMM");
+    static_assert(!X3 || (!CONV && !FP8), "split-f16 variants: plain GEMM");
+    static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
+    static_assert(X3 != 2 || (!PH8 && (BK == 64 || BK == 32)), "split-f16 slice form: generic K loop");
+    constexpr int XS = X3 == 2 ? 2 : 1;                          // operand images per stage (slice form: hi and lo)
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -303,11 +311,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     static_assert(!FP8 || (BK == 64 && !CONV), "fp8 variant: 128-byte rows, plain GEMM");
     constexpr int A_CH = BM / RPC / NW, B_CH = BN / RPC / NW;    // 1 KiB copies per wave per tile
     static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
-    constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2;      // NS-deep ring of operand tiles
+    constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2 * XS;  // NS-deep ring of operand tiles
     constexpr int EP = (BM * BN * 4 > SMEM_BYTES) ? WM : 1;     // epilogue passes (one wave-row of the tile per pass)
     static_assert(BM / EP * BN * 4 <= SMEM_BYTES, "epilogue slab must fit in the operand buffers");
     static_assert(NS >= 2 && NS <= 4, "ring depth");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK * XS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = PH8 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;   // PH8: scalar (wave-row dependent barriers)
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             asrc[i] = A + (long)b * fa.cH * fa.cW * fa.cC + kc * 8;           // + ((y*W + x)*C + c0) per K tile
         } else {
             ay[i] = ax[i] = 0;
-            asrc[i] = A + (long)m * g.lda + (X3 ? 0 : kbeg) + kc * 8;
+            asrc[i] = A + (long)m * g.lda + (X3 == 1 ? 0 : kbeg) + kc * 8;
         }
     }
     // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
@@ -350,15 +358,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int i = 0; i < B_CH; ++i) {
         const int r = b_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
-        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + (X3 ? 0 : kbeg) + kc * 8;
+        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + (X3 == 1 ? 0 : kbeg) + kc * 8;
     }
     // operand column of the K tile at offset koff of this block's K range (identity except for the split-f16 variant)
     auto x3_acol = [&](int koff) -> int {
-        if constexpr (X3) { const int k = kbeg + koff; return k < 2 * fa.x3_kp ? k : k - 2 * fa.x3_kp; }
+        if constexpr (X3 == 1) { const int k = kbeg + koff; return k < 2 * fa.x3_kp ? k : k - 2 * fa.x3_kp; }
         else return koff;
     };
     auto x3_wcol = [&](int koff) -> int {
-        if constexpr (X3) { const int k = kbeg + koff; return k < fa.x3_kp ? k : k - fa.x3_kp; }
+        if constexpr (X3 == 1) { const int k = kbeg + koff; return k < fa.x3_kp ? k : k - fa.x3_kp; }
         else return koff;
     };
     auto mma16 = [&](const bf16x8& a_, const bf16x8& b_, const f32x16& c_) -> f32x16 {
@@ -386,6 +394,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         const int kw = x3_wcol(koff);
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + kw, Bs + b_chunk(i) * RPC * BK);
+        if constexpr (X3 == 2) {                                 // slice form: the lo images of the same K slice, behind the hi images
+            bf16_t* Al = smem[buf] + (BM + BN) * BK;
+            bf16_t* Bl = Al + BM * BK;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + fa.x3_kp + koff, Al + (wave + NW * i) * RPC * BK);
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + fa.x3_kp + koff, Bl + b_chunk(i) * RPC * BK);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -404,7 +420,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     // kt .. kt+NS-2 are in flight; a counted vmcnt retires exactly tile kt (the copies of later tiles stay in flight
     // across the raw barrier), the barrier makes every wave's tile-kt data visible and proves that all waves are done
     // with the stage read in step kt-1, which is then refilled with tile kt+NS-1.
-    constexpr int LPT = A_CH + B_CH;                             // copy instructions per wave per tile
+    constexpr int LPT = (A_CH + B_CH) * XS;                      // copy instructions per wave per tile
     const int nk = (kend - kbeg) / BK;
     if constexpr (PH8) {
         // ---- PH8 schedule (256 x 256 tile, host guarantees nk >= 2).  A K tile is consumed in 4 phases, one 64 x 32 quadrant of
@@ -568,6 +584,34 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa8[i], fb8[j], acc[i][j], 0, 0, 0);
+            }
+            continue;
+        }
+        if constexpr (X3 == 2) {                                 // slice form: three products from the four images of this K slice
+            const bf16_t* Al = As + (BM + BN) * BK;
+            const bf16_t* Bl = Al + BM * BK;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
+                    al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Al[(a_row0 + 32 * i) * BK + co]));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+                    bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bl[(b_row0 + 32 * j) * BK + co]));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
+                        acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
+                    }
             }
             continue;
         }
@@ -1059,6 +1103,13 @@ static int g_ring64 = 0;
 // 74.9 -> 69.4 us, 4096^3 1007 -> 1091 TF/s, 8192^3 1053 -> 1191; bitwise equal to the 2-buffer loop on 360 / 360 repetitions);
 // 0 = the plain 2-buffer loop, 1 / 2 = the other copy placements (psalm_gemm_set_tile_policy 2560 / 2568..2570)
 static int g_ph8 = 3;
+// split-f16 GEMMs on the 128x128 / 64x128 tiles: 0 = the K-panel form (3 Kp-long loop; default), 1 = "slice" K loop (4 operand images per
+// 64-deep slice, 3 products per barrier), 2 = the same with 32-deep slices in a 4-deep ring.  psalm_gemm_set_tile_policy 3300 / 3301 / 3302.
+// r02 sweep (profiles/r02l_gemm_x3_slice_ab.json): the slice form's 128 KB / 96 KB stages leave ONE block per CU and lose to the K-panel
+// form at 2-3 blocks per CU on every short-K problem (M4096 N2048 K512: 74 vs 50 us); it wins only where a long K meets a grid that
+// 64 x 128 tiles can fill without split-K (M4096 N512 K2048, Swin stage-2 fc2: 39 vs 53 us) -- select_fast_config picks it there.
+static int g_x3_slice = 0;
+static bool g_x3_auto_slice = false;    // set by select_fast_config: this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
     if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)
@@ -1066,6 +1117,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
+    if (bm >= 3300 && bm <= 3302) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
@@ -1089,6 +1141,10 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     // tiles (r02 sweep tools/bench_gemm_x3.py, profiles/r02f_gemm_x3_policies.json: M21504 N1024 K256 105 -> 67 us, M65536 N512 K128
     // 112 -> 77, M16384 N1024 K256 67 -> 53, M1024 N4096 K1024 57 -> 42)
     if (x3 && M > 192 && (K <= 1024 || (t128 < 448 && K <= 4096))) { BM = 64; BN = 128; no_split = true; }
+    g_x3_auto_slice = false;
+    if (x3 && !g_tile_policy && M > 192 && t128 < 200 && K >= 4096 && K <= 8192 && (long)cdiv(M, 64) * cdiv(N, 128) >= 200) {
+        BM = 64; BN = 128; no_split = true; g_x3_auto_slice = true;      // long K, small grid: 64 x 128 slice form, no split-K
+    }
     if (g_tile_policy == 12864) { if (M > 192) { BM = 128; BN = 64; } }       // experiment: 48 KB LDS -> 3 blocks/CU
     else if (g_tile_policy) { BM = g_tile_policy; BN = BM == 256 ? 256 : 128; no_split = false; }
     const long tiles = (long)cdiv(M, BM) * cdiv(N, BN);
@@ -1141,12 +1197,19 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
+    int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
+    const int slice = !x3 || BM == 256 ? 0 : (g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 ? 1 : 0));
+    if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
+        g.K = fa.x3_kp;
+        kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
+        splits = cdiv(g.K, kps);
+    }
     g.tiles_m = cdiv(M, BM);
     g.tiles_n = cdiv(N, BN);
     g.row_fast = N > M ? 1 : 0;                                  // the larger operand's tiles stay in one XCD's L2
     const long tiles = (long)g.tiles_m * g.tiles_n;
     fa.g = g;
-    fa.k_per_split = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
+    fa.k_per_split = kps;
     fa.slab = splits > 1 ? (float*)workspace : nullptr;
     const long csz = c_dtype == PSALM_F32 ? 4 : 2;
     if (splits > 1) fa.vec_store = (N % 8 == 0) ? 1 : 0;                       // fp32 slab rows of N floats
@@ -1174,9 +1237,17 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
-    if (x3) {                                                     // split-f16 variant: fp32 output (or fp32 split-K slabs) only
+    if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
+#define LAUNCH_X3S(BM_, BN_, WM_, WN_, NS_, BK_) \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, BK_, false, 0, 2>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
+        if (BM == 128 && slice == 2) LAUNCH_X3S(128, 128, 2, 2, 4, 32);
+        else if (BM == 128) LAUNCH_X3S(128, 128, 2, 2, 2, 64);
+        else if (slice == 2) LAUNCH_X3S(64, 128, 2, 2, 4, 32);
+        else LAUNCH_X3S(64, 128, 2, 2, 2, 64);
+#undef LAUNCH_X3S
+    } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
 #define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_) \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
         if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
         else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
         else if (BM == 128 && g_ring_depth == 3) LAUNCH_X3(128, 128, 2, 2, 3, 0);

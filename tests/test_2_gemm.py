@@ -327,11 +327,13 @@ X3_CASES = [
     (257, 256, 64, True, False, H.ACT_NONE, 256),      # 3 K tiles: prologue + drain only
     (270, 300, 1088, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 128),   # split-K slabs (scaled partials) + reduce
     (200, 130, 704, False, False, H.ACT_NONE, 64),     # 64x128 with the 3-deep ring (K range >= 1024)
+    (1700, 256, 1408, True, True, H.ACT_GELU, 0),      # long K on a small grid: the automatic 64x128 slice form, no split-K
 ]
 
 
+@pytest.mark.parametrize("kloop", [3300, 3301, 3302])           # K-panel form (default) / slice form / 32-deep slices in a 4-deep ring
 @pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy", X3_CASES)
-def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy):
+def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy, kloop):
     """fp32-class accuracy from f16 matrix instructions: error vs the float64 product of the UNROUNDED fp32 operands within a few
     2^-22 of sum_k |a||w| (the exact-fp32 MFMA kernel sits at ~2^-24 of it; a bf16 GEMM at 2^-9)."""
     g = torch.Generator().manual_seed(M * 7 + N + K)
@@ -343,11 +345,13 @@ def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy):
     mag = (a.abs().double() @ w.abs().double().t())
     d = ops.device
     ops.gemm_tile_policy(policy)
+    ops.gemm_tile_policy(kloop)
     try:
         wsp = ops.split_f16(w.to(d))                                  # weights are split once; activations on the fly
         got = ops.gemm(a.to(d), wsp, bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()
         got2 = ops.gemm_x3(a.to(d), w.to(d), bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()
     finally:
+        ops.gemm_tile_policy(3300)
         ops.gemm_tile_policy(0)
     assert torch.equal(got, got2)
     tol = 6 * 2.0 ** -22 * mag + 4e-7 * want.abs() + 1e-6           # operand split 3 x 2^-22, fp32 accumulation / epilogue round-off

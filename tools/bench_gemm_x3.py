@@ -9,7 +9,8 @@ from psalm_amd.hip_ops import get_ops
 SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512, 2048), (5184, 1536, 512), (5184, 512, 512),
           (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256), (65536, 512, 128), (65536, 128, 512), (16384, 1024, 256),
           (1024, 4096, 1024), (100, 65536, 256), (133, 1048576, 128), (65536, 256, 2304)]
-POLICIES = [("auto", [0]), ("t256", [256]), ("t128", [128]), ("t128_ring3", [128, 1283]), ("t64", [64]), ("t64_ring3", [64, 643])]
+POLICIES = [("auto", [0]), ("auto_slice", [3301]), ("auto_slice32", [3302]), ("t128", [128]), ("t128_slice", [128, 3301]),
+            ("t64", [64]), ("t64_slice", [64, 3301]), ("t256", [256])]
 
 
 def main():
@@ -42,6 +43,7 @@ def main():
             finally:
                 ops.gemm_tile_policy(1282)
                 ops.gemm_tile_policy(640)
+                ops.gemm_tile_policy(3300)
                 ops.gemm_tile_policy(0)
         out[f"M{M} N{N} K{K}"] = row
         print(M, N, K, {k: v.get("us") for k, v in row.items()}, flush=True)
