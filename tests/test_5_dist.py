@@ -108,6 +108,10 @@ def _worker_real_model(rank, world, port, q):
 
 @pytest.mark.slow
 def test_two_rank_real_model_broadcast_and_sharded_eval():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from ops_backend import make_ops
+    make_ops("emu")                                   # build the host-emulation library ONCE here: the two workers only load it
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
