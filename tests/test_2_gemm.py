@@ -327,12 +327,14 @@ X3_CASES = [
     (257, 256, 64, True, False, H.ACT_NONE, 256),      # 3 K tiles: prologue + drain only
     (270, 300, 1088, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 128),   # split-K slabs (scaled partials) + reduce
     (200, 130, 704, False, False, H.ACT_NONE, 64),     # 64x128 with the 3-deep ring (K range >= 1024)
-    (1700, 256, 1408, True, True, H.ACT_GELU, 0),      # long K on a small grid: the automatic 64x128 slice form, no split-K
 ]
 
 
-@pytest.mark.parametrize("kloop", [3300, 3301, 3302])           # K-panel form (default) / slice form / 32-deep slices in a 4-deep ring
-@pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy", X3_CASES)
+# K loop forms: 3300 K-panel (default) on every case; 3301 slice form / 3302 32-deep slices in a 4-deep ring on the tiled (policy != 0) cases
+X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302)]
+
+
+@pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy,kloop", X3_PARAMS)
 def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy, kloop):
     """fp32-class accuracy from f16 matrix instructions: error vs the float64 product of the UNROUNDED fp32 operands within a few
     2^-22 of sum_k |a||w| (the exact-fp32 MFMA kernel sits at ~2^-24 of it; a bf16 GEMM at 2^-9)."""
@@ -402,3 +404,22 @@ def test_im2col_split_equals_im2col_then_split(ops, B, H, W, C, k, s, p):
     b = ops.split_f16(ops.im2col_nhwc(x, B, H, W, k, s, p))
     assert a.K == b.K and a.Kp == b.Kp and torch.equal(a.t.cpu().view(torch.int16), b.t.cpu().view(torch.int16))
     assert torch.equal(a.inv_scale.cpu(), b.inv_scale.cpu())
+
+
+@pytest.mark.gpu
+def test_gemm_x3_auto_slice_selection_on_gpu():
+    """Long K on a grid that 64 x 128 tiles fill without split-K (Swin stage-2 fc2 shape): select_fast_config picks the slice form by itself;
+    same result as the K-panel form to fp32 round-off."""
+    from psalm_amd.hip_ops import get_ops
+    ops = get_ops()
+    g = torch.Generator().manual_seed(11)
+    a, w = torch.randn(4096, 2048, generator=g).cuda(), torch.randn(512, 2048, generator=g).cuda()
+    assert ops.gemm_describe(4096, 512, 3 * 2048, x3=True)[:3] == (1, 64, 128)
+    auto = ops.gemm_x3(a, w)
+    ops.gemm_tile_policy(64)                       # a forced tile policy disables the automatic rule: K-panel form on the same tiles
+    try:
+        panel = ops.gemm_x3(a, w)
+    finally:
+        ops.gemm_tile_policy(0)
+    want = a.double() @ w.double().t()
+    assert (auto.double() - want).abs().max() <= 3e-6 * want.abs().max() and (auto - panel).abs().max() <= 3e-6 * want.abs().max()
