@@ -422,12 +422,16 @@ extern "C" int psalm_semantic_from_masks(const float* mask, const void* probsT_b
 // index), in descending order.  Then the reference's filtering (LP:417-446):
 //   label = idx % C, query = idx / C; keep only is_thing[label] (if is_thing != NULL);
 //   out_score = value * mask_score[query]; compacted in pick order.  count[0] = number kept.
-// Radix select on the 46-bit key (sortable value bits << 14 | (16383 - index)): keys are distinct, so the k-th largest key is a
+// Radix select on the 49-bit key (sortable value bits << 17 | (131071 - index)): keys are distinct, so the k-th largest key is a
 // sharp threshold (no tie handling) and sorting the k survivors by key reproduces "value descending, index ascending".
+// Up to 131072 candidates (100 queries x 1310 classes: the open-vocabulary evaluations with 459 / 847 class prompts fit); the keys are
+// recomputed from the values in every pass instead of being held in registers.
+#define TOPK_IDX_BITS 17
+#define TOPK_IDX_MAX ((1 << TOPK_IDX_BITS) - 1)
 __device__ __forceinline__ unsigned long long topk_key(float v, int idx) {
     unsigned u = __builtin_bit_cast(unsigned, v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                  // monotone map float -> unsigned
-    return ((unsigned long long)u << 14) | (unsigned long long)(16383 - idx);
+    return ((unsigned long long)u << TOPK_IDX_BITS) | (unsigned long long)(TOPK_IDX_MAX - idx);
 }
 
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ vals, int Q, int C, int stride, int k,
@@ -439,34 +443,26 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
     __shared__ float sel_val[128];
     __shared__ unsigned long long prefix_s;
     __shared__ int remaining_s, nsel;
-    constexpr int PER = 16;                       // up to 16384 candidates
     const int tid = threadIdx.x;
     const int n = Q * C;
     const int kk = min(min(k, n), 128);
-    float v[PER];
-    unsigned long long key[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int i = tid + j * 1024;
-        float x = 0.f;
-        if (i < n) {
-            x = vals[(long)(i / C) * stride + (i % C)];
-            if (apply_sigmoid) x = sigmoidf_(x);
-        }
-        v[j] = x;
-        key[j] = i < n ? topk_key(x, i) : 0ull;                      // 0 < every real key (real keys have bit 45 or the index field set)
-    }
+    auto value = [&](int i) -> float {
+        float x = vals[(long)(i / C) * stride + (i % C)];
+        if (apply_sigmoid) x = sigmoidf_(x);
+        return x;
+    };
     if (tid == 0) { prefix_s = 0ull; remaining_s = kk; nsel = 0; }
     __syncthreads();
-    // 6 passes over 8-bit digits, most significant first (bits 47..0 cover the 46-bit key)
-    for (int shift = 40; shift >= 0; shift -= 8) {
+    // 7 passes over 8-bit digits, most significant first (bits 55..0 cover the 49-bit key)
+    for (int shift = 48; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned long long prefix = prefix_s;
-        const unsigned long long himask = shift == 40 ? 0ull : (~0ull << (shift + 8));
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            if (key[j] != 0ull && (key[j] & himask) == prefix) atomicAdd(&hist[(int)((key[j] >> shift) & 255ull)], 1);
+        const unsigned long long himask = shift == 48 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long key = topk_key(value(i), i);
+            if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+        }
         __syncthreads();
         if (tid == 0) {                                               // walk the digits from the top: where does the k-th key fall
             int rem = remaining_s, d = 255;
@@ -480,13 +476,15 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
         __syncthreads();
     }
     const unsigned long long thr = prefix_s;                          // the kk-th largest key
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (key[j] != 0ull && key[j] >= thr && kk > 0) {
+    for (int i = tid; i < n && kk > 0; i += 1024) {
+        const float x = value(i);
+        const unsigned long long key = topk_key(x, i);
+        if (key >= thr) {
             const int slot = atomicAdd(&nsel, 1);
-            sel_key[slot] = key[j];
-            sel_val[slot] = v[j];
+            sel_key[slot] = key;
+            sel_val[slot] = x;
         }
+    }
     __syncthreads();
     for (int e = nsel + tid; e < 128; e += 1024) { sel_key[e] = 0ull; sel_val[e] = 0.f; }
     __syncthreads();
@@ -508,7 +506,7 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
     if (tid == 0) {
         int nkept = 0;
         for (int r = 0; r < kk; ++r) {
-            const int idx = 16383 - (int)(sel_key[r] & 16383ull);
+            const int idx = TOPK_IDX_MAX - (int)(sel_key[r] & (unsigned long long)TOPK_IDX_MAX);
             const int lab = idx % C, qq = idx / C;
             if (!is_thing || is_thing[lab]) {
                 out_score[nkept] = sel_val[r] * (mask_score ? mask_score[qq] : 1.f);
@@ -523,7 +521,7 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
 
 extern "C" int psalm_topk_select(const float* vals, int Q, int C, int stride, int k, const int* is_thing, const float* mask_score,
                                  float* out_score, int* out_class, int* out_query, int* count, int apply_sigmoid, void* stream) {
-    PSALM_CHECK_ARG((long)Q * C <= 16384 && k <= 128, "psalm_topk_select: at most 16384 candidates, k <= 128");
+    PSALM_CHECK_ARG((long)Q * C <= (1L << TOPK_IDX_BITS) && k <= 128, "psalm_topk_select: at most 131072 candidates, k <= 128");
     hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vals, Q, C, stride, k, is_thing, mask_score,
                        out_score, out_class, out_query, count, apply_sigmoid);
     PSALM_LAUNCH_END("psalm_topk_select");

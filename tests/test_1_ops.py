@@ -305,7 +305,8 @@ def test_swin_window_merge_ln(ops, B, H, W, C, shift):
     assert (got_h.cpu().float() - want_h).abs().max() <= tol(torch.bfloat16, want_h.abs().max())
 
 
-@pytest.mark.parametrize("Q,C,k,thing,sig", [(100, 133, 100, True, False), (100, 1, 100, False, True), (12, 9, 12, True, False), (7, 3, 30, False, False)])
+@pytest.mark.parametrize("Q,C,k,thing,sig", [(100, 133, 100, True, False), (100, 1, 100, False, True), (12, 9, 12, True, False), (7, 3, 30, False, False),
+                                           (100, 847, 100, False, False)])          # open-vocabulary class count (A-847): 84700 candidates
 def test_topk_select(ops, Q, C, k, thing, sig):
     """radix-select top-k (value descending, ties by lowest flat index) + thing filter + mask-score product, LP:407-447 / 308-324."""
     g = torch.Generator().manual_seed(Q * C + k)
