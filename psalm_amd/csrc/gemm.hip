@@ -1044,15 +1044,17 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // the bf16 skinny kernel (block = one 32 x 32 output tile, 4 wavefronts split K, fragments straight from global / L2, no K-loop barrier),
 // on v_mfma_f32_32x32x2_f32.  Lane (n, hi) contracts k = 8 c + 4 hi + i in step i of chunk c, so A and W fragments are 16-byte loads.
 // In the f16x3 mode this replaces split + split-f16 skinny GEMM (two launches, ~15 us) for these ~100 tiny GEMMs per image.
-template <typename TC>
-__global__ void __launch_bounds__(256) gemm_f32_skinny_kernel(GemmArgs g) {
-    __shared__ float part[3][32 * 32];
+template <typename TC, int NWV>
+__global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
+    // NWV wavefronts split K (16 for these latency-bound problems: the fp32 MFMA takes 64 cycles, a wave's serial chain of K / 2 / NWV of them
+    // IS the kernel's duration -- r02k: 9 us per launch with 4 waves); the partial tiles meet in LDS and every thread finishes one element.
+    __shared__ float part[NWV][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
     const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
     const float* A = (const float*)g.A + (long)min(bm + n32, g.M - 1) * g.lda + 4 * hi;
     const float* W = (const float*)g.W + (long)min(bn + n32, g.N - 1) * g.ldw + 4 * hi;
-    const int chunks = g.K / 8, cpw = (chunks + 3) / 4;
-    const int c_lo = wave * cpw, c_hi = min(chunks, c_lo + cpw);
+    const int chunks = g.K / 8, cpw = (chunks + NWV - 1) / NWV;
+    const int c_lo = min(chunks, wave * cpw), c_hi = min(chunks, c_lo + cpw);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1078,15 +1080,25 @@ __global__ void __launch_bounds__(256) gemm_f32_skinny_kernel(GemmArgs g) {
     while (c + 8 <= c_hi) group(std::integral_constant<int, 8>{});
     if (c + 4 <= c_hi) group(std::integral_constant<int, 4>{});
     while (c < c_hi) group(std::integral_constant<int, 1>{});
-    if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[wave - 1][r * 64 + lane] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) part[wave][r * 64 + lane] = acc[r];
     __syncthreads();
-    if (wave == 0) {
+    // element e = r * 64 + lane of the accumulator layout: row (r&3) + 8(r>>2) + 4(lane>>5), column lane & 31
+    for (int e = tid; e < 1024; e += 64 * NWV) {
+        const int r = e >> 6, ln = e & 63;
+        const int row = bm + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = bn + (ln & 31);
+        float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += part[0][r * 64 + lane] + part[1][r * 64 + lane] + part[2][r * 64 + lane];
-        epilogue_store<TC>(g, acc, bm, bn + n32, lane);
+        for (int w = 0; w < NWV; ++w) v += part[w][e];
+        if (row < g.M && col < g.N) {
+            const int act = g.act & 15;
+            const bool post = (g.act & ACT_POST_RESIDUAL) != 0, do_act = act != ACT_NONE && col >= g.act_col_start;
+            if (g.bias) v += g.bias[(g.act & ACT_BIAS_ROW) ? row : col];
+            if (do_act && !post) v = apply_act(v, act);
+            if (g.res) v += ldf((const TC*)g.res + (long)row * g.ldr + col);
+            if (do_act && post) v = apply_act(v, act);
+            stf((TC*)g.C + (long)row * g.ldc + col, v);
+        }
     }
 }
 
@@ -1391,8 +1403,13 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     if (a_dtype == PSALM_F32 && w_dtype == PSALM_F32 && M <= 192 && N <= 8192 && K % 8 == 0 && !g_tile_policy) {
         // ---- exact-fp32 skinny path (mask-decoder GEMMs with M = 100 query rows in the fp32 / f16x3 modes)
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
-        if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<float>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_f32_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g);
+        if (K >= 256) {                                           // 16 wavefronts split K
+            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<float, 16>), grid, dim3(1024), 0, s, g);
+            else hipLaunchKernelGGL((gemm_f32_skinny_kernel<bf16_t, 16>), grid, dim3(1024), 0, s, g);
+        } else {
+            if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<float, 4>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_f32_skinny_kernel<bf16_t, 4>), grid, dim3(256), 0, s, g);
+        }
         PSALM_LAUNCH_END("psalm_gemm");
     }
     // ---- register-staged path (fp32 activations converted on the fly, odd K, or exact fp32 arithmetic)
