@@ -374,3 +374,38 @@ def test_config5_region_1024_batch2_f16x3_and_fp8():
         e8 = float((pm - st8["pred_masks"][b]).abs().max() / st8["pred_masks"][b].abs().max())
         _report(test="config5_region_1024_b2", precision="fp8", image=b, mask_err_vs_fp8_oracle=e8)
         assert e8 < 0.15
+
+
+@pytest.mark.parametrize("task", ["semantic", "instance", "panoptic"])
+def test_open_vocab_class_count_459(task):
+    """Open-vocabulary evaluations (psalm/eval/semantic_segmentation.py:418-507: ADE-150, PC-459, A-847 class lists) change only the
+    number of class prompts: 459 classes + background = 460 class groups, L ~ 1.7 k tokens, 45 900 top-k candidates (beyond the fused
+    semantic kernel's 160-class limit and the old 16 384-candidate top-k limit).  Full-width architecture with a 2-layer LLM at 384^2,
+    headline mode vs the CPU oracle at the fp32 tolerances."""
+    from psalm_amd.model import PSALM
+    cfg = PsalmConfig(num_layers=2, seg_task=task)
+    sd = make_state_dict(cfg, seed=3)
+    inputs = make_inputs(cfg, task, size=384, batch=1, seed=3, num_classes=459)
+    want = O.eval_seg(sd, cfg, **inputs)[0]
+    got = PSALM(cfg, sd, precision="f16x3").eval_seg(**inputs)[0]
+    torch.cuda.synchronize()
+    rel = float((got["mask_pred"].cpu() - want["mask_pred"]).abs().max() / want["mask_pred"].abs().max())
+    rep = {"test": "open_vocab_459", "task": task, "mask_logit_rel_err": rel}
+    assert rel < 1e-4
+    if task in ("semantic", "panoptic"):
+        assert tuple(got["sem_seg"].shape) == (459, 384, 384)
+        top2 = want["sem_seg"].topk(2, 0).values
+        decided = (top2[0] - top2[1]) > 1e-5 * want["sem_seg"].abs().max()
+        same = got["sem_seg"].argmax(0).cpu() == want["sem_seg"].argmax(0)
+        rep["sem_argmax_agree"] = float(same.float().mean())
+        assert bool(same[decided].all()) and float(same.float().mean()) >= 0.999
+    if task in ("instance", "panoptic"):
+        gi, wi = got["instances"], want["instances"]
+        assert gi.scores.numel() == wi.scores.numel()
+        og = np.lexsort((gi.pred_classes.cpu().numpy(), -gi.scores.cpu().numpy()))
+        ow = np.lexsort((wi.pred_classes.numpy(), -wi.scores.numpy()))
+        np.testing.assert_allclose(gi.scores.cpu().numpy()[og], wi.scores.numpy()[ow], atol=2e-3)
+        rep["instances"] = int(gi.scores.numel())
+    if task == "panoptic":
+        assert float((got["panoptic_seg"][0].cpu() == want["panoptic_seg"][0]).float().mean()) >= 0.999
+    _report(**rep)
