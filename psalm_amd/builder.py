@@ -29,7 +29,9 @@ import torch
 from . import hf as _hf
 from .config import PsalmConfig, load_mask_config
 
-MODEL_MAP_NAMES = ("psalm",)            # 'psalm_video' (PSALMForDAVISEval, llava_phi.py:1477-1998) is a "next" row
+# builder.py:45-49 model_map: 'psalm' -> PSALM, 'psalm_video' -> PSALMForDAVISEval (llava_phi.py:1477-1998).  One class serves both here:
+# psalm_amd.model.PSALM carries eval_seg and eval_video.
+MODEL_MAP_NAMES = ("psalm", "psalm_video")
 
 
 def read_checkpoint(model_path: str) -> Dict[str, torch.Tensor]:

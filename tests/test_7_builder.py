@@ -58,6 +58,9 @@ def test_load_pretrained_model_roundtrip(tmp_path, kind):
     assert torch.equal(a["mask_pred"], b["mask_pred"]) and torch.equal(a["sem_seg"], b["sem_seg"])
     with pytest.raises(ValueError):
         load_pretrained_model(str(tmp_path), None, "psalm", types.SimpleNamespace(model_map_name="llava"), ops=ops)
+    _, mv, _, _ = load_pretrained_model(str(tmp_path), None, "psalm", types.SimpleNamespace(model_map_name="psalm_video", seg_task="region"),
+                                        mask_config=_mask_yaml(tmp_path, cfg), precision="fp32", use_graphs=False, ops=ops)
+    assert mv.seg_task == "region" and callable(mv.eval_video)                           # builder.py:45-49: the DAVIS evaluation class
     with pytest.raises(NotImplementedError):
         load_pretrained_model(str(tmp_path), None, "psalm", args, load_4bit=True, ops=ops)
 
