@@ -173,3 +173,28 @@ class IoUMeters:
         ciou = float(self.sum[1] / (self.sum[3] + 1e-10))      # iou_class[1], region_segmentation.py:286-287
         giou = float(self.sum[5] / max(float(self.sum[6]), 1e-5))
         return {"ciou": ciou, "giou": giou, "n": int(self.sum[6])}
+
+
+def compact_results(result: dict, gt_sem: Optional[torch.Tensor] = None, conf: Optional[ConfusionMatrix] = None, ops=None) -> dict:
+    """What the reference's panoptic / semantic / instance evaluators keep of ONE eval_seg result (panoptic_evaluation.py:114-145,179-222;
+    instance masks as COCO RLE, region_segmentation.py:282), produced on the device, so that KBs..MBs instead of ~1 GB cross PCIe:
+        "sem_labels"   (H,W) int32          from result["sem_seg"]           (+ conf.update(labels, gt_sem) when both are given)
+        "panoptic_rgb" (H,W,3) uint8, "segments_info"   from result["panoptic_seg"]
+        "instances"    {"rle": [...], "scores": (n,), "pred_classes": (n,)}  from result["instances"]
+    Keys follow what the result holds (semantic-only / instance-only tasks give the matching subset)."""
+    o = _ops(ops)
+    out = {}
+    if "sem_seg" in result:
+        out["sem_labels"] = semantic_labels(result["sem_seg"].contiguous(), ops=o)
+        if conf is not None and gt_sem is not None:
+            conf.update(out["sem_labels"], gt_sem)
+    if "panoptic_seg" in result:
+        pan, info = result["panoptic_seg"]
+        out["panoptic_rgb"] = panoptic_png_rgb(pan, ops=o)
+        out["segments_info"] = info
+    if "instances" in result and getattr(result["instances"], "pred_masks", None) is not None:
+        inst = result["instances"]
+        out["instances"] = {"rle": masks_to_rle(inst.pred_masks, ops=o), "scores": inst.scores}
+        if hasattr(inst, "pred_classes"):
+            out["instances"]["pred_classes"] = inst.pred_classes
+    return out

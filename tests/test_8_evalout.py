@@ -90,3 +90,39 @@ def test_iou_counts_and_meters(ops):
     assert abs(res["giou"] - ref["acc"][1] / 4) < 1e-9
     meters.all_reduce()                                          # no process group: identity
     assert meters.results()["n"] == 4
+
+
+def test_compact_results_equal_host_evaluator_formulas_on_model_outputs():
+    """End of the path: a tiny-model eval_seg result (kernels in the emulator) -> psalm_amd.evalout.compact_results (device) == the
+    reference evaluators' host arithmetic (oracle/evalout_ref.py) applied to the SAME tensors, exactly; and the oracle's own outputs
+    through the host formulas agree with it up to the model's fp32 round-off (labels >= 99 %, identical panoptic segments)."""
+    from ops_backend import make_ops
+    from oracle import psalm_oracle as O
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    ops = make_ops("emu")
+    cfg = PsalmConfig.tiny("panoptic")
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=4, num_classes=9)
+    torch.manual_seed(5)
+    r = PSALM(cfg, sd, ops=ops, precision="f16x3").eval_seg(**inputs)[0]
+    torch.manual_seed(5)
+    w = O.eval_seg(sd, cfg, **inputs)[0]
+    gt = torch.randint(0, 9, (96, 96), generator=torch.Generator().manual_seed(1))
+    gt[:10] = 255
+    cm = E.ConfusionMatrix(9, 255, ops=ops)
+    c = E.compact_results(r, gt_sem=gt, conf=cm, ops=ops)
+    pred_ref, conf_ref = R.semantic_confusion(r["sem_seg"].cpu().numpy(), gt.numpy(), 9, 255)
+    assert np.array_equal(c["sem_labels"].cpu().numpy(), pred_ref) and np.array_equal(cm.conf.cpu().numpy(), conf_ref)
+    assert np.array_equal(c["panoptic_rgb"].cpu().numpy(), R.id2rgb(r["panoptic_seg"][0].cpu().numpy()))
+    assert c["segments_info"] == r["panoptic_seg"][1]
+    masks = r["instances"].pred_masks.cpu().numpy()
+    assert len(c["instances"]["rle"]) == masks.shape[0]
+    for i, rle in enumerate(c["instances"]["rle"]):
+        assert rle["counts"] == R.rle_to_string(R.rle_encode(masks[i] != 0))
+    # the oracle's outputs through the host formulas: same decisions up to fp32 round-off of the model
+    pred_o, _ = R.semantic_confusion(w["sem_seg"].numpy(), gt.numpy(), 9, 255)
+    assert (pred_o == pred_ref).mean() >= 0.99
+    assert np.array_equal(R.id2rgb(w["panoptic_seg"][0].numpy()), c["panoptic_rgb"].cpu().numpy())
+    assert w["panoptic_seg"][1] == c["segments_info"]
