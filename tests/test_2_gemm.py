@@ -325,7 +325,7 @@ X3_CASES = [
     (300, 260, 128, True, True, H.ACT_GELU, 64),
     (300, 520, 192, True, True, H.ACT_GELU_NEW, 256),  # 256x256 phased K loop (9 K tiles incl. the hi/lo part boundaries)
     (257, 256, 64, True, False, H.ACT_NONE, 256),      # 3 K tiles: prologue + drain only
-    (270, 300, 1088, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 128),   # split-K slabs (scaled partials) + reduce
+    (270, 300, 704, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL, 128),    # split-K slabs (scaled partials) + reduce
     (200, 130, 704, False, False, H.ACT_NONE, 64),     # 64x128 with the 3-deep ring (K range >= 1024)
 ]
 
