@@ -20,7 +20,8 @@ def test_reference_eval_script_call_sequence(tmp_path, monkeypatch, kind):
     if kind == "hip" and not torch.cuda.is_available():
         pytest.skip("no GPU")
     import psalm_amd.hip_ops as hip_ops
-    monkeypatch.setattr(hip_ops, "get_ops", lambda: make_ops(kind))
+    ops = make_ops(kind)                              # resolved BEFORE get_ops is replaced (make_ops("hip") calls the real one)
+    monkeypatch.setattr(hip_ops, "get_ops", lambda: ops)
     cfg = PsalmConfig.tiny("panoptic")
     sd = make_state_dict(cfg, seed=3)
     _write_ckpt(tmp_path, cfg, sd)
