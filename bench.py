@@ -166,14 +166,20 @@ def main():
                 B_, H_, W_, Cin, Cout, ks, st, pd_ = a[1], a[2], a[3], a[4], a[6], a[7], a[8], a[9]
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
                 geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
-            x3 = name == "psalm_gemm_x3"
-            if x3:                                                               # split-f16 GEMM: the kernel's K range is 3*Kp
+            x3 = name in ("psalm_gemm_x3", "psalm_gemm_x3_split")
+            if name == "psalm_gemm_x3":                                          # split-f16 GEMM: the kernel's K range is 3*Kp
                 geo = (a[12], a[13], 3 * a[6], True, False, ",x3")
+            elif x3:                                                             # ... with the split-f16 output epilogue (same K loop)
+                geo = (a[10], a[11], 3 * a[6], True, False, ",x3")
             if geo is not None:
                 M, N, K, a_bf16, c_bf16, tag = geo
                 path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True, x3=x3)
                 if x3:
                     K = a[6]                                                      # ALGORITHMIC flops: 2 M N K of the fp32 product it stands for
+                if name == "psalm_gemm_x3_split":                                 # always the tiled kernel, never split-K
+                    path, splits = 1, 1
+                    if M <= 128:
+                        BM, BN = 64, 128
                 if path == 2 and name in ("psalm_gemm", "psalm_gemm_x3"):
                     kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}{tag}>"
                 elif path == 1 or path == 2:

@@ -118,6 +118,27 @@ int psalm_swin_window_merge_ln_split(const float* win, const float* shortcut, fl
 int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);
+/* psalm_gemm_x3 whose output columns >= split_col_start leave the kernel already in split form -- the A operand of the NEXT split-f16 GEMM
+ * (nn.Linear -> activation -> nn.Linear chains: Swin Mlp swin_trans.py:35-53, Phi fc1 -> fc2 modeling_phi.py:248-260, the encoder FFN
+ * msdeformattn.py:68-72) -- without the fp32 round trip and the psalm_split_f16 pass.  Value (r, n) goes to row r of split_out (row stride
+ * ld_split f16) at column split_col_off + (n - split_col_start) (hi) and split_kp columns further (lo).  The per-row power-of-two scale is
+ * derived from a magnitude BOUND that needs no pass over the output: bound_par = 4 device floats {2^14 * max_n sum_k |w_nk|, max |bias|,
+ * g1, g0};  bound_r = max(a_scale[r] * par[0] + par[1], (global_rows ? max_r a_scale[r] : 0) * g1 + g0)  (the second term: the caller's
+ * bound for values ANOTHER kernel writes into the same rows, see psalm_causal_attention_f32_split);  bound_r * scale in [2^12, 2^13);
+ * 1/scale -> split_inv[r].  Columns < split_col_start go to C (fp32) as in psalm_gemm_x3.  No residual, no split-K; N and the column
+ * arguments are multiples of 8.  Columns of split_out this call does not write (K padding) are the caller's to zero. */
+/* x = A.W^T + bias + residual (fp32 -> C) followed by LayerNorm(x) leaving as the split-f16 operand of the next GEMM (and optionally as
+ * fp32 rows ln_out): the residual GEMM + the following block's input LayerNorm of a pre-norm layer (Phi [dense | fc2] + residual, then the
+ * next input_layernorm, modeling_phi.py:263-300).  With split-K the partial-sum reduce, epilogue, LayerNorm and split are ONE row pass.
+ * N % 64 == 0, N <= 2048; split_out rows of 2*N f16 as psalm_split_f16 writes them (exact row-maximum scale), split_inv (M). */
+int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                           const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, const float* ln_gamma,
+                           const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out, float* split_inv,
+                           void* workspace, long workspace_bytes, void* stream);
+int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                        const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out, long ld_split,
+                        int split_kp, int split_col_off, int split_col_start, float* split_inv, const float* bound_par, int global_rows,
+                        void* workspace, long workspace_bytes, void* stream);
 
 /* Eval-time image pre-processing on the device: replaces detectron2 `T.ResizeShortestEdge` (= Pillow
  * `Image.resize(BILINEAR)` on uint8) + `T.FixedSizeCrop` + `(image - pixel_mean) / pixel_std` of
@@ -162,6 +183,13 @@ long psalm_causal_attention_f32_workspace(int B, int L, int heads);
 int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
                                const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace, int B, int L,
                                int heads, int head_dim, int rot, void* stream);
+/* ... whose output leaves as split-f16 operand columns of the next GEMM (Phi [dense | fc2]): row r of split_out (row stride ld_split f16)
+ * gets hi at columns split_col_off + head*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the row scales a preceding
+ * psalm_gemm_x3_split wrote for the same rows (its bound has to cover |v|: the output is a convex combination of v rows). */
+int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split, int split_kp,
+                                     int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
+                                     const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
+                                     void* stream);
 
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
@@ -220,6 +248,12 @@ int psalm_segment_mean(const void* x, int x_dtype, long ldx, const int* seg_offs
  * shifted-window -100 mask (:369-387) computed in-kernel.  qkv (B*nW*ws*ws, 3C); out (B*nW*ws*ws, C); head_dim 32. */
 int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw, int C,
                            int heads, int ws, int shift, void* stream);
+/* The fp32 / 12x12-window form whose output leaves as the split-f16 A operand of the projection GEMM (swin_trans.py:144-153 -> self.proj;
+ * f16x3 mode): split_out rows of 2*split_kp f16 (hi at column head*32 + d, lo split_kp further), split_inv (rows).  One power-of-two scale per
+ * window from a bound: a_inv = the row scales of the qkv GEMM's split-f16 A operand (rows in window order), bound_par = 2 device floats
+ * {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}; the output is a convex combination of the window's v rows. */
+int psalm_window_attention_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par, void* split_out,
+                                 int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads, int ws, int shift, void* stream);
 /* The same on the matrix cores for bf16 buffers and 12x12 windows (one block per (window, head), K / V^T / bias column
  * staged in LDS, scores of a whole 144-key row kept in MFMA accumulators). */
 int psalm_window_attention_mfma(const void* qkv, const float* bias_table, void* out, int B, int nWh, int nWw, int C, int heads,

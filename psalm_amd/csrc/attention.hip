@@ -108,9 +108,17 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
 // Only V (+ the bias column) is staged in LDS (rows padded to 36 floats: the 4-byte V reads of a step hit 64 distinct banks); the K
 // fragments -- 32 bytes per lane, each needed once per query tile -- come straight from global / L1 (a window-head's K is 18 KB).
 // 22.8 KB of LDS per wave instead of 43.6 KB: 7 instead of 3 resident waves per CU (r02: 3 waves left one SIMD in four idle).
-template <int HD, int WS>
+// SO = true: the output leaves as the split-f16 A operand of the projection GEMM: `out` is then the f16 operand buffer (rows of 2 * so_kp:
+// hi at column h*32 + d, lo so_kp further).  One power-of-two scale per WINDOW from a magnitude bound that needs no pass over the output:
+// an output row is a convex combination of the window's v rows, |v_jd| <= a_inv[j] * par[0] + par[1] (a_inv: the row scales of the qkv
+// GEMM's split-f16 A operand, par = {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}), so max_j of that bounds all of
+// them; every head's wavefront derives the same scale, head 0's writes 1/scale to so_inv.
+template <int HD, int WS, bool SO = false>
 __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
-                                                                       float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift) {
+                                                                       float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift,
+                                                                       const float* __restrict__ a_inv = nullptr,
+                                                                       const float* __restrict__ so_par = nullptr,
+                                                                       float* __restrict__ so_inv = nullptr, int so_kp = 0) {
     static_assert(HD == 32 && WS == 12, "Swin-B window geometry");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int N = WS * WS, NT = N / 16, LS = HD + 4, NB = (2 * WS - 1) * (2 * WS - 1);
@@ -125,6 +133,19 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
         *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
     }
     for (int e = lane; e < NB; e += 64) Bs[e] = bias_table[(long)e * heads + h];
+    float so_sc = 1.f;
+    if constexpr (SO) {
+        float gmax = 0.f;
+        for (int r = lane; r < N; r += 64) gmax = fmaxf(gmax, a_inv[row0 + r]);
+        gmax = wave_max(gmax);
+        float bound = fminf(fmaxf(gmax * so_par[0] + so_par[1], 7.888609e-31f), 1.2676506e30f);        // [2^-100, 2^100]
+        const unsigned eb = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;                        // bound * scale in [2^12, 2^13)
+        so_sc = __builtin_bit_cast(float, (266u - eb) << 23);
+        if (h == 0) {
+            const float inv = __builtin_bit_cast(float, (eb - 12u) << 23);
+            for (int r = lane; r < N; r += 64) so_inv[row0 + r] = inv;
+        }
+    }
     __syncthreads();
     const float scale = rsqrtf((float)HD);
     // shift-mask region label of a token (swin_trans.py:371-387): slices (0,-ws), (-ws,-shift), (-shift,None)
@@ -205,10 +226,46 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
                 o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], sc[tk][r], o1, 0, 0, 0);
             }
         const float inv = 1.f / l;
-        float* op = out + (row0 + qi) * C + h * HD + 4 * kk;
-        *reinterpret_cast<psalm_f32x4*>(op) = psalm_f32x4{o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
-        *reinterpret_cast<psalm_f32x4*>(op + 16) = psalm_f32x4{o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
+        if constexpr (SO) {
+            unsigned short* op = reinterpret_cast<unsigned short*>(out) + (row0 + qi) * 2L * so_kp + h * HD + 4 * kk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unsigned hw[2], lw[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float a0 = (t ? o1[2 * k] : o0[2 * k]) * inv * so_sc, a1 = (t ? o1[2 * k + 1] : o0[2 * k + 1]) * inv * so_sc;
+                    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                    hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                *reinterpret_cast<psalm_u32x2*>(op + 16 * t) = psalm_u32x2{hw[0], hw[1]};
+                *reinterpret_cast<psalm_u32x2*>(op + 16 * t + so_kp) = psalm_u32x2{lw[0], lw[1]};
+            }
+        } else {
+            float* op = out + (row0 + qi) * C + h * HD + 4 * kk;
+            *reinterpret_cast<psalm_f32x4*>(op) = psalm_f32x4{o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
+            *reinterpret_cast<psalm_f32x4*>(op + 16) = psalm_f32x4{o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
+        }
     }
+}
+
+// psalm_window_attention (fp32 buffers, 12 x 12 windows) whose output leaves as the split-f16 A operand of the projection GEMM
+// (swin_trans.py:144-153 -> self.proj): split_out rows of 2*split_kp f16 (hi at column head*32 + d, lo split_kp further), split_inv (rows);
+// a_inv: the row scales of the qkv GEMM's split-f16 A operand (rows in window order), bound_par: 2 device floats
+// {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}.  Columns [C, split_kp) are the caller's to zero.
+extern "C" int psalm_window_attention_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par,
+                                            void* split_out, int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads,
+                                            int ws, int shift, void* stream) {
+    PSALM_CHECK_ARG(C == heads * 32 && ws == 12, "psalm_window_attention_split: head_dim 32, 12 x 12 windows");
+    PSALM_CHECK_ARG(a_inv && bound_par && split_out && split_inv && split_kp >= C && split_kp % 8 == 0 && (uintptr_t)qkv % 16 == 0 &&
+                        (uintptr_t)split_out % 16 == 0, "psalm_window_attention_split: operand scales, bound parameters, aligned buffers");
+    const int nwin = B * nWh * nWw;
+    if (nwin == 0) return 0;
+    const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float);
+    hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream, qkv, bias_table,
+                       (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    PSALM_LAUNCH_END("psalm_window_attention_split");
 }
 
 extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, void* out, int dtype, int B, int nWh, int nWw,
@@ -553,10 +610,13 @@ __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __r
     st8(kd, k);
 }
 
+// SO = true: the output leaves as split-f16 operand columns (hi at `out` + o_off, lo so_kp f16 further; `out` is then the f16 buffer, ldo its
+// row stride in f16) under the per-row scales 1 / so_inv[row] ANOTHER kernel chose (psalm_gemm_x3_split's bound covers |v| of every row).
+template <bool SO>
 __global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr,
                                                                           const unsigned char* __restrict__ Mk, const float* __restrict__ base,
                                                                           long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
-                                                                          int heads) {
+                                                                          int heads, const float* __restrict__ so_inv, int so_kp) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
@@ -671,7 +731,24 @@ __global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const 
             const float inv = Lsum > 0.f ? 1.f / Lsum : 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] *= inv;
-            st8(out + ((long)b * L + tq) * ldo + o_off + h * HD + d0, acc);
+            if constexpr (SO) {
+                const long row = (long)b * L + tq;
+                const float sc = 1.f / so_inv[row];                      // power of two: exact
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a0 = acc[2 * k] * sc, a1 = acc[2 * k + 1] * sc;
+                    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                    hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                unsigned short* d = reinterpret_cast<unsigned short*>(out) + row * ldo + o_off + h * HD + d0;
+                *reinterpret_cast<psalm_u32x4*>(d) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+                *reinterpret_cast<psalm_u32x4*>(d + so_kp) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+            } else {
+                st8(out + ((long)b * L + tq) * ldo + o_off + h * HD + d0, acc);
+            }
         }
     }
 }
@@ -683,12 +760,14 @@ extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
 
 // Phi prefill attention for fp32 buffers, same operands as psalm_causal_attention + a workspace of psalm_causal_attention_f32_workspace
 // bytes (16-byte aligned).  head_dim 64, rotary dim 32; column offsets / row strides multiples of 4 elements.
-extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
-                                          const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
-                                          int B, int L, int heads, int head_dim, int rot, void* stream) {
+static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k_off, int v_off, void* out, long ldo, int o_off,
+                                     const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
+                                     int B, int L, int heads, int head_dim, int rot, void* stream, const float* so_inv, int so_kp,
+                                     const char* name) {
     PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_f32: head_dim 64, rotary dim 32 (Phi-1.5)");
-    PSALM_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && o_off % 4 == 0 &&
-                        (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0,
+    PSALM_CHECK_ARG(ld % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && (uintptr_t)qkv % 16 == 0 &&
+                        (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0 &&
+                        (so_inv ? (ldo % 8 == 0 && o_off % 8 == 0 && so_kp % 8 == 0) : (ldo % 4 == 0 && o_off % 4 == 0)),
                     "psalm_causal_attention_f32: 16-byte aligned rows / offsets and a workspace");
     if (B == 0 || L == 0) return 0;
     const int Lp = (L + 31) / 32 * 32;
@@ -699,9 +778,31 @@ extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phi_rope_prep_f32_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, cos_table, sin_table, key_mask,
                        Qr, Kr, Mk, L, Lp, heads, scale);
-    hipLaunchKernelGGL(causal_attention_f32_splitk_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                       (const unsigned char*)Mk, qkv, ld, v_off, out, ldo, o_off, L, Lp, heads);
-    PSALM_LAUNCH_END("psalm_causal_attention_f32");
+    if (so_inv)
+        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp);
+    else
+        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0);
+    PSALM_LAUNCH_END(name);
+}
+extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
+                                          const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
+                                          int B, int L, int heads, int head_dim, int rot, void* stream) {
+    return causal_attention_f32_impl(qkv, ld, q_off, k_off, v_off, out, ldo, o_off, cos_table, sin_table, key_mask, workspace, B, L, heads,
+                                     head_dim, rot, stream, nullptr, 0, "psalm_causal_attention_f32");
+}
+// ... whose output leaves as split-f16 operand columns of the NEXT GEMM ([dense | fc2], modeling_phi.py:189-260): row r of split_out (row
+// stride ld_split f16) receives hi at columns split_col_off + h*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the
+// row scales psalm_gemm_x3_split wrote for the same rows (its bound covers the attention output: a convex combination of v rows).
+extern "C" int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split,
+                                                int split_kp, int split_col_off, const float* split_inv, const float* cos_table,
+                                                const float* sin_table, const unsigned char* key_mask, void* workspace, int B, int L,
+                                                int heads, int head_dim, int rot, void* stream) {
+    PSALM_CHECK_ARG(split_out && split_inv && ld_split >= 2L * split_kp && split_col_off + heads * 64 <= split_kp,
+                    "psalm_causal_attention_f32_split: split buffer rows of >= 2*split_kp f16 and the row scales");
+    return causal_attention_f32_impl(qkv, ld, q_off, k_off, v_off, split_out, ld_split, split_col_off, cos_table, sin_table, key_mask, workspace,
+                                     B, L, heads, head_dim, rot, stream, split_inv, split_kp, "psalm_causal_attention_f32_split");
 }
 
 extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,

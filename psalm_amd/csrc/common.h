@@ -60,6 +60,7 @@ __device__ __forceinline__ float e4m3_to_f32(unsigned char v) {
 
 // 8 consecutive elements per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses; p must be 16-byte aligned.
 struct alignas(16) psalm_u32x4 { unsigned x, y, z, w; };
+struct alignas(8) psalm_u32x2 { unsigned x, y; };
 struct alignas(16) psalm_f32x4 { float x, y, z, w; };
 __device__ __forceinline__ void ld8(const float* p, float* d) {
     const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], b = reinterpret_cast<const psalm_f32x4*>(p)[1];

@@ -36,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct alignas(16) u32x4_s { unsigned x, y, z, w; };
+struct alignas(8) u32x2_s { unsigned x, y; };
 struct alignas(16) f32x4_g { float x, y, z, w; };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -254,7 +255,28 @@ struct GemmFastArgs {
     // split-f16 ("X3") operands: A / W rows are [hi (Kp) | lo (Kp)] f16 (psalm_split_f16); the K loop runs over the 3 Kp-long products
     // hi.hi + lo.hi + hi.lo, i.e. logical k in [0, 3Kp) reads A column (k < 2Kp ? k : k - 2Kp) and W column (k < Kp ? k : k - Kp)
     int x3_kp;
+    // split-f16 OUTPUT (X3 kernels without split-K; psalm_gemm_x3_split): the columns >= so_col_start of act(A.W^T + bias) are written, instead
+    // of to C, in the operand form the NEXT split-f16 GEMM reads -- row r of `so` (row stride ldso f16) holds hi at column
+    // so_col_off + (col - so_col_start) and lo so_kp columns further, scaled by a per-row power of two 2^(12 - e), e = floor(log2 bound_r):
+    //   bound_r = max(a_scale[r] * so_par[0] + so_par[1],  G * so_par[2] + so_par[3]),   G = max over ALL rows of a_scale (so_global != 0) or 0
+    // an upper bound of |value| in row r that needs no pass over the output: |a_rk| < 2^14 a_scale[r] (psalm_split_f16's row scaling), so with
+    // so_par[0] = 2^14 max_n sum_k |w_nk| and so_par[1] = max |bias| the first term bounds every column (|act(x)| <= |x| for the activations
+    // here); the second term is the caller's bound for values written into the same rows by ANOTHER kernel (Phi: the attention output, a
+    // convex combination of v rows).  The bound may be loose by 2^10 without loss: hi + lo keep 22 bits down to 2^-25 of the scaled range.
+    // 1 / scale goes to so_inv[r].
+    unsigned short* so = nullptr;
+    long ldso = 0;
+    int so_kp = 0, so_col_off = 0, so_col_start = 0, so_global = 0;
+    float* so_inv = nullptr;
+    const float* so_par = nullptr;
 };
+// scale / inverse scale of a split-f16 row from an upper bound of its magnitudes: bound * sc in [2^12, 2^13)
+__device__ __forceinline__ void split_scale_from_bound(float bound, float& sc, float& inv) {
+    bound = fminf(fmaxf(bound, 7.888609e-31f), 1.2676506e30f);                 // [2^-100, 2^100]: sc and inv stay normal numbers
+    const unsigned eb = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;
+    sc = __builtin_bit_cast(float, (266u - eb) << 23);
+    inv = __builtin_bit_cast(float, (eb - 12u) << 23);
+}
 
 // Tile configurations (BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32x16 MFMA tiles):
 //   256 x 256, 2 x 4 waves (512 threads, 128 KB LDS, 1 block/CU): large GEMMs -- half the L2->LDS bytes per flop of
@@ -293,8 +315,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // the three products hi.hi + lo.hi + hi.lo are formed: 4 instead of 6 tile copies per slice, 2/3 of the LDS fragment reads per MFMA, and
 // -- the point -- 3x the matrix work per barrier / per copy round trip.  The mid-size GEMMs of the image (Swin stage 2, pixel decoder:
 // 12..48 K steps) ran their K loops at L2 latency with X3 = 1 (r02k: 100-200 TFLOP/s algorithmic on the 128^2 / 64x128 tiles).
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, int X3 = 0>
+// SO = true (X3 == 1 only): the epilogue can emit split-f16 output (GemmFastArgs::so; psalm_gemm_x3_split).  A separate instantiation so that
+// the plain kernels' epilogue -- at the register limit on the 256 x 256 tile -- is untouched.
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, int X3 = 0,
+          bool SO = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+    static_assert(!SO || X3 == 1, "split-f16 output: K-panel form of the split-f16 GEMM");
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV && !FP8), "PH8 configuration");
     static_assert(!X3 || (!CONV && !FP8), "split-f16 variants: plain GEMM");
     static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
@@ -650,6 +676,17 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     TC* C = (TC*)g.C;
     const TC* R = (const TC*)g.res;
     float* P = split ? fa.slab + (long)blockIdx.y * g.M * g.N : nullptr;
+    float so_floor = 0.f;                                         // split-f16 output: the row-independent term of the magnitude bound
+    if constexpr (SO) {
+        if (fa.so != nullptr && bn + BN > fa.so_col_start) {
+            float gmax = 0.f;
+            if (fa.so_global) {
+                for (int r = lane; r < g.M; r += 64) gmax = fmaxf(gmax, fa.a_scale[r]);
+                gmax = wave_max(gmax);
+            }
+            so_floor = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax * fa.so_par[2] + fa.so_par[3])));
+        }
+    }
 #pragma unroll 1
     for (int ep = 0; ep < EP; ++ep) {
         if (ep > 0) __syncthreads();                              // previous pass fully read out
@@ -675,6 +712,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
             for (int c = 0; c < 8; ++c) wsc[c] = fa.w_scale[min(col0 + c, g.N - 1)];
         }
+        bool so_here = false;                                     // this thread's 8 columns go out in split-f16 form
+        if constexpr (SO) so_here = fa.so != nullptr && col0 >= fa.so_col_start;
         __syncthreads();
         if (col0 >= g.N) continue;
         // one store iteration (rows it * RPI + tid / TPR of the pass); false = past the last row of the matrix.  `itc` indexes the fp8
@@ -720,6 +759,26 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 if (R) x += rres[c];
                 if (do_act && post) x = apply_act(x, act);
                 v[c] = x;
+            }
+            if constexpr (SO) {
+                if (so_here) {
+                    float sc, inv;
+                    split_scale_from_bound(fmaxf(asc[itc] * fa.so_par[0] + fa.so_par[1], so_floor), sc, inv);
+                    unsigned hw[4], lw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a0 = v[2 * k] * sc, a1 = v[2 * k + 1] * sc;
+                        const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                        const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                        hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                        lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    }
+                    unsigned short* d = fa.so + (long)row * fa.ldso + fa.so_col_off + (col0 - fa.so_col_start);
+                    *reinterpret_cast<u32x4_s*>(d) = u32x4_s{hw[0], hw[1], hw[2], hw[3]};
+                    *reinterpret_cast<u32x4_s*>(d + fa.so_kp) = u32x4_s{lw[0], lw[1], lw[2], lw[3]};
+                    if (col0 == fa.so_col_start) fa.so_inv[row] = inv;
+                    return true;
+                }
             }
             TC* dst = C + (long)row * g.ldc + col0;
             if (fa.vec_store) store8(dst, v);
@@ -859,11 +918,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, const fl
 // masked afterwards) and the slab reads go in groups of 4 slabs x NV vectors: guarded loads inside the runtime z loop had compiled
 // to one s_waitcnt vmcnt(0) round trip per load (r01 ISA audit: 72 of 72), i.e. ~(splits + 3) * NV dependent L2 / HBM latencies
 // per block.  The per-element summation order (z ascending) is unchanged.
-template <typename TL, int NV>
+// SPLIT = true: the normalised row also (ln_out may be NULL: only) leaves in split-f16 operand form -- [hi | lo] f16 rows of 2 * sp_kp
+// columns with the exact row-maximum scale of psalm_split_f16 (N % 64 == 0: no K padding to zero), 1/scale in sp_inv[row].
+template <typename TL, int NV, bool SPLIT = false>
 __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const float* __restrict__ slab, int splits,
                                                                const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
-                                                               float ln_eps, TL* __restrict__ ln_out, long ld_ln) {
-    __shared__ float red[8];
+                                                               float ln_eps, TL* __restrict__ ln_out, long ld_ln,
+                                                               unsigned short* __restrict__ sp_out = nullptr, float* __restrict__ sp_inv = nullptr,
+                                                               int sp_kp = 0) {
+    __shared__ float red[12];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int act = g.act & 15;
     const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
@@ -943,15 +1006,46 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
     if (lane == 0) red[4 + wave] = q;
     __syncthreads();
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / g.N + ln_eps);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+        v[i] = f32x4_g{(v[i].x - mean) * rstd * ga[i].x + be[i].x, (v[i].y - mean) * rstd * ga[i].y + be[i].y,
+                       (v[i].z - mean) * rstd * ga[i].z + be[i].z, (v[i].w - mean) * rstd * ga[i].w + be[i].w};
         if (c0[i] < g.N) {
-            TL* o = ln_out + (long)row * ld_ln + c0[i];
-            stf(o + 0, (v[i].x - mean) * rstd * ga[i].x + be[i].x);
-            stf(o + 1, (v[i].y - mean) * rstd * ga[i].y + be[i].y);
-            stf(o + 2, (v[i].z - mean) * rstd * ga[i].z + be[i].z);
-            stf(o + 3, (v[i].w - mean) * rstd * ga[i].w + be[i].w);
+            if (ln_out) {
+                TL* o = ln_out + (long)row * ld_ln + c0[i];
+                stf(o + 0, v[i].x); stf(o + 1, v[i].y); stf(o + 2, v[i].z); stf(o + 3, v[i].w);
+            }
+            if constexpr (SPLIT) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
         }
+    }
+    if constexpr (SPLIT) {
+        amax = wave_max(amax);
+        if (lane == 0) red[8 + wave] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+        // psalm_split_f16's row scale: the row maximum into [2^13, 2^14)
+        int se = 13 - ((int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127);
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+        const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+        if (tid == 0) sp_inv[row] = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+        unsigned short* orow = sp_out + (long)row * 2 * sp_kp;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (c0[i] < g.N) {
+                const float x4[4] = {v[i].x * sc, v[i].y * sc, v[i].z * sc, v[i].w * sc};
+                unsigned hw[2], lw[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const _Float16 h0 = (_Float16)x4[2 * k], h1 = (_Float16)x4[2 * k + 1];
+                    const _Float16 l0 = (_Float16)(x4[2 * k] - (float)h0), l1 = (_Float16)(x4[2 * k + 1] - (float)h1);
+                    hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                *reinterpret_cast<u32x2_s*>(orow + c0[i]) = u32x2_s{hw[0], hw[1]};
+                *reinterpret_cast<u32x2_s*>(orow + sp_kp + c0[i]) = u32x2_s{lw[0], lw[1]};
+            }
     }
 }
 
@@ -1200,7 +1294,10 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
 }
 
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
-struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; };
+struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; };
+extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
+                                     float eps, void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2,
+                                     void* stream);
 extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 
@@ -1209,8 +1306,9 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
+    if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-    const int slice = !x3 || BM == 256 ? 0 : (g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 ? 1 : 0));
+    const int slice = !x3 || BM == 256 || fa.so ? 0 : (g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 ? 1 : 0));
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
         kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
@@ -1258,8 +1356,12 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else LAUNCH_X3S(64, 128, 2, 2, 2, 64);
 #undef LAUNCH_X3S
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
-#define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_) \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
+#define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_)                                                                                                        \
+        do {                                                                                                                                           \
+            if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1, true>), grid,               \
+                                          dim3(64 * WM_ * WN_), 0, s, fa);                                                                             \
+            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa); \
+        } while (0)
         if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
         else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
         else if (BM == 128 && g_ring_depth == 3) LAUNCH_X3(128, 128, 2, 2, 3, 0);
@@ -1310,6 +1412,14 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
 #undef LAUNCH_GLDS128
 #undef LAUNCH_GLDS8
     if (splits > 1) {
+        if (ln && ln->split_out) {                                // ... + the normalised rows in split-f16 form (psalm_gemm_x3_ln_split)
+#define RLNS_LAUNCH(NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<float, NV_, true>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
+                                            ln->gamma, ln->beta, ln->eps, (float*)ln->out, ln->ld, (unsigned short*)ln->split_out, ln->split_inv, N)
+            const int nv = N <= 1024 ? 1 : (N <= 2048 ? 2 : (N <= 4096 ? 4 : 8));
+            if (nv == 1) RLNS_LAUNCH(1); else if (nv == 2) RLNS_LAUNCH(2); else if (nv == 4) RLNS_LAUNCH(4); else RLNS_LAUNCH(8);
+#undef RLNS_LAUNCH
+            PSALM_LAUNCH_END("psalm_gemm_x3_ln_split");
+        }
         if (ln) {                                                 // reduce + epilogue + LayerNorm in one pass (fp32 C, checked by the caller)
 #define RLN_LAUNCH(TL_, NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<TL_, NV_>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
                                                 ln->gamma, ln->beta, ln->eps, (TL_*)ln->out, ln->ld)
@@ -1330,6 +1440,9 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (ln) {                                                     // un-split GEMM: the LayerNorm runs as its own (vectorised) kernel
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { psalm_set_error("psalm_gemm_ln: GEMM launch failed"); return (int)e; }
+        if (ln->split_out)
+            return psalm_layernorm_split((const float*)g.C, g.ldc, (float*)ln->out, ln->ld, ln->gamma, ln->beta, M, N, ln->eps, ln->split_out,
+                                         ln->split_inv, nullptr, 0, nullptr, nullptr, (void*)s);
         return psalm_layernorm(g.C, PSALM_F32, g.ldc, ln->out, ln->dtype, ln->ld, nullptr, 0, ln->gamma, ln->beta, M, N, ln->eps, (void*)s);
     }
     PSALM_LAUNCH_END("psalm_gemm");
@@ -1676,9 +1789,11 @@ extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, fl
 // C = act((A . W^T) + bias) + residual from split-f16 operands:  A2 (M, 2 Kp) / W2 (N, 2 Kp) f16 [hi | lo] with row strides lda / ldw
 // (elements) and per-row scales a_scale (M) / w_scale (N) as written by psalm_split_f16;  Kp % 64 == 0.  C / residual fp32.
 // Same tile selection, split-K and epilogue as psalm_gemm (on a K range of 3 Kp); M <= 128 problems take the skinny kernel.
-extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
-                             const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
-                             int act_col_start, void* workspace, long workspace_bytes, void* stream) {
+struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; };
+static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                        const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
+                        int act_col_start, void* workspace, long workspace_bytes, void* stream, const SplitOut* so, const char* name,
+                        const LnEpilogue* ln = nullptr) {
     if (M == 0 || N == 0) return 0;
     PSALM_CHECK_ARG(Kp > 0 && Kp % 64 == 0, "psalm_gemm_x3: Kp must be a positive multiple of 64");
     PSALM_CHECK_ARG((uintptr_t)A2 % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)W2 % 16 == 0 && (ldw * 2) % 16 == 0 && lda >= 2L * Kp && ldw >= 2L * Kp,
@@ -1690,15 +1805,67 @@ extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, con
     g.M = M; g.N = N; g.K = 3 * Kp; g.act = act; g.act_col_start = act_col_start;
     g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+    if (!so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
         hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
-        PSALM_LAUNCH_END("psalm_gemm_x3");
+        PSALM_LAUNCH_END(name);
     }
     GemmFastArgs fa;
     fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
     fa.zeros = nullptr;
     fa.a_scale = a_scale; fa.w_scale = w_scale;
     fa.x3_kp = Kp;
-    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, nullptr, false, true);
+    if (so) {
+        fa.so = (unsigned short*)so->so; fa.ldso = so->ldso; fa.so_kp = so->so_kp; fa.so_col_off = so->so_col_off;
+        fa.so_col_start = so->so_col_start; fa.so_global = so->so_global; fa.so_inv = so->so_inv; fa.so_par = so->so_par;
+    }
+    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, false, true);
+}
+extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                             const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
+                             int act_col_start, void* workspace, long workspace_bytes, void* stream) {
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, act, act_col_start, workspace,
+                        workspace_bytes, stream, nullptr, "psalm_gemm_x3");
+}
+
+// psalm_gemm_x3 whose output columns >= split_col_start leave the kernel as the split-f16 A operand of the NEXT GEMM (no fp32 round trip, no
+// psalm_split_f16 pass): value (r, n) goes to row r of `split_out` (row stride ld_split f16, 16-byte aligned rows) at column
+// split_col_off + (n - split_col_start) (hi) and split_kp columns further (lo), scaled by a per-row power of two derived from a magnitude
+// BOUND -- see GemmFastArgs::so.  bound_par: 4 floats on the device {2^14 max_n sum_k |w_nk|, max |bias|, g1, g0}: the row bound is
+// max(a_scale[r] * par[0] + par[1],  (global_rows ? max_r a_scale[r] : 0) * g1 + g0).  1/scale -> split_inv[r].  Columns below
+// split_col_start are written to C as usual (C may be NULL when split_col_start == 0).  No residual, no split-K; N, split_col_start,
+// split_col_off, split_kp multiples of 8.  The un-written columns of split_out (K padding of the consumer) are the caller's to zero.
+extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                                   const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out,
+                                   long ld_split, int split_kp, int split_col_off, int split_col_start, float* split_inv,
+                                   const float* bound_par, int global_rows, void* workspace, long workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(split_out && split_inv && bound_par, "psalm_gemm_x3_split: split output, scale array and bound parameters required");
+    PSALM_CHECK_ARG(N % 8 == 0 && split_col_start % 8 == 0 && split_col_start >= 0 && split_col_start < N && split_col_off % 8 == 0 &&
+                        split_col_off >= 0 && split_kp % 8 == 0 && (uintptr_t)split_out % 16 == 0 && (ld_split * 2) % 16 == 0 &&
+                        split_col_off + (N - split_col_start) <= split_kp && ld_split >= 2L * split_kp,
+                    "psalm_gemm_x3_split: N / column offsets multiples of 8, 16-byte aligned split rows of >= 2*split_kp f16");
+    PSALM_CHECK_ARG(C || split_col_start == 0, "psalm_gemm_x3_split: C required for the columns below split_col_start");
+    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
+                        stream, &so, "psalm_gemm_x3_split");
+}
+
+
+// x = (A . W^T) + bias + residual (fp32, written to C) followed by LayerNorm(x) leaving in split-f16 operand form (and, optionally, as fp32
+// rows ln_out): the residual-add GEMM + the NEXT block's input LayerNorm of a pre-norm transformer layer (Phi: [dense | fc2] + residual, then
+// input_layernorm of the following layer, modeling_phi.py:263-300).  With split-K (the usual case for this GEMM: few tiles, long K) the
+// partial-sum reduce, epilogue, LayerNorm and split run as ONE row pass; otherwise the LayerNorm is psalm_layernorm_split on C.
+// N % 64 == 0, N <= 8192; split_out rows of 2*N f16 (contiguous), split_inv (M).
+extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+                                      const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N,
+                                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out,
+                                      float* split_inv, void* workspace, long workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(N % 64 == 0 && N <= 2048 && split_out && split_inv && C, "psalm_gemm_x3_ln_split: N % 64 == 0, N <= 2048, outputs required");
+    PSALM_CHECK_ARG((uintptr_t)C % 16 == 0 && (ldc * 4) % 16 == 0 && (uintptr_t)ln_gamma % 16 == 0 && (uintptr_t)ln_beta % 16 == 0 &&
+                        (uintptr_t)split_out % 16 == 0 && (!ln_out || ((uintptr_t)ln_out % 16 == 0 && (ld_ln * 4) % 16 == 0)) &&
+                        (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * 4) % 16 == 0)),
+                    "psalm_gemm_x3_ln_split: 16-byte aligned rows");
+    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, PSALM_F32, ld_ln, split_out, split_inv};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, 0, 0, workspace, workspace_bytes, stream,
+                        nullptr, "psalm_gemm_x3_ln_split", &ln);
 }

@@ -228,6 +228,52 @@ class Ops:
         self._check(rc, "psalm_gemm_x3")
         return out
 
+    def gemm_x3_ln_split(self, a, w, bias, residual, gamma, beta, eps, want_y=False):
+        """x = a.w^T + bias + residual (float32), h = LayerNorm(x): returns (x, SplitF16(h), h float32 | None) -- the split-K reduce, the
+        LayerNorm and the split of h are one row pass (psalm_gemm_x3_ln_split)."""
+        a, w = self.split_f16(a), self.split_f16(w)
+        if a.K != w.K:
+            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        M, N = a.t.shape[0], w.t.shape[0]
+        if residual is not None and (residual.dtype != torch.float32 or tuple(residual.shape) != (M, N) or residual.stride(-1) != 1):
+            raise PsalmHipError("gemm_x3_ln_split: float32 (M,N) residual")
+        x = self.empty(M, N, dtype=torch.float32)
+        y = self.empty(M, N, dtype=torch.float32) if want_y else None
+        so, inv = self.empty(M, 2 * N, dtype=torch.float16), self.empty(M, dtype=torch.float32)
+        rc = self.lib.psalm_gemm_x3_ln_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
+                                             self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
+                                             c_long(residual.stride(0) if residual is not None else 0), self._p(x), c_long(N), M, N,
+                                             self._p(gamma), self._p(beta), c_float(eps), self._pv(y), c_long(N), self._p(so), self._p(inv),
+                                             self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_gemm_x3_ln_split")
+        return x, SplitF16(so, inv, N), y
+
+    def gemm_x3_split(self, a, w, bias, act, split_out, split_inv, bound_par, split_col_off=0, split_col_start=0, act_col_start=0,
+                      out=None, global_rows=False):
+        """gemm_x3 whose columns >= split_col_start are written as the split-f16 A operand of the next GEMM: into `split_out` (a SplitF16's
+        .t buffer (M, 2*Kp_out) f16) at columns split_col_off.. (hi) / Kp_out + split_col_off.. (lo), row scales (inverse) into split_inv;
+        bound_par: 4 device floats, see psalm_gemm_x3_split.  Columns below split_col_start go to `out` (M, >= split_col_start...) fp32."""
+        a, w = self.split_f16(a), self.split_f16(w)
+        if a.K != w.K:
+            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        M, N = a.t.shape[0], w.t.shape[0]
+        if split_out.dtype != torch.float16 or split_out.dim() != 2 or split_out.shape[0] != M or split_out.stride(1) != 1:
+            raise PsalmHipError("gemm_x3_split: split_out must be a (M, 2*Kp) float16 buffer")
+        if split_inv.dtype != torch.float32 or split_inv.numel() != M or bound_par.dtype != torch.float32 or bound_par.numel() != 4:
+            raise PsalmHipError("gemm_x3_split: split_inv (M,) / bound_par (4,) float32")
+        if split_col_start > 0 and (out is None or out.dtype != torch.float32 or out.shape[0] != M or out.stride(-1) != 1):
+            raise PsalmHipError("gemm_x3_split: float32 `out` required for the columns below split_col_start")
+        if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+            raise PsalmHipError("gemm bias must be float32 (N,)")
+        rc = self.lib.psalm_gemm_x3_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
+                                          self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(out),
+                                          c_long(out.stride(0) if out is not None else 0), M, N, act, act_col_start,
+                                          self._p(split_out), c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
+                                          split_col_start, self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
+                                          self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_gemm_x3_split")
+        return split_out
+
     def gemm_ln(self, a, w, bias, residual, gamma, beta, eps=1e-5, ln_dtype=torch.bfloat16, act=ACT_NONE):
         """(C fp32, LayerNorm(C) ln_dtype) with C = act(a @ w^T + bias) + residual; bf16 a / w, K % 64 == 0."""
         M, K = a.shape
@@ -469,6 +515,20 @@ class Ops:
         self._check(rc, "psalm_window_attention")
         return out
 
+    def window_attention_split(self, qkv, bias_table, a_inv, bound_par, B, nWh, nWw, heads, ws, shift):
+        """window_attention on a float32 qkv buffer (12 x 12 windows) -> SplitF16 (rows, C): the projection GEMM's A operand, see
+        psalm_window_attention_split.  a_inv: row scales of the qkv GEMM's A operand; bound_par: >= 2 device floats."""
+        C = qkv.shape[-1] // 3
+        if qkv.dtype != torch.float32 or ws != 12 or a_inv.numel() != qkv.shape[0]:
+            raise PsalmHipError("window_attention_split: float32 qkv, 12 x 12 windows, one operand scale per row")
+        Kp = (C + 63) // 64 * 64
+        so = (self.empty if Kp == C else self.zeros)(qkv.shape[0], 2 * Kp, dtype=torch.float16)
+        inv = self.empty(qkv.shape[0], dtype=torch.float32)
+        rc = self.lib.psalm_window_attention_split(self._p(qkv), self._p(bias_table), self._p(a_inv), self._p(bound_par), self._p(so), Kp,
+                                                   self._p(inv), B, nWh, nWw, C, heads, ws, shift, self._stream())
+        self._check(rc, "psalm_window_attention_split")
+        return SplitF16(so, inv, C)
+
     def causal_attention(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot):
         """buf (B*L, ld) holds q|k|v column blocks; out (B*L, ldo) receives the attention output at column o_off.
         bf16 buffers run on the matrix cores (psalm_causal_attention_mfma); fp32 buffers on the exact fp32 kernel."""
@@ -504,6 +564,25 @@ class Ops:
                                              heads, head_dim, rot, self._stream())
         self._check(rc, "psalm_causal_attention")
         return out
+
+    def causal_attention_split(self, buf, q_off, k_off, v_off, split_out, split_inv, split_col_off, cos, sin, key_mask, B, L, heads,
+                               head_dim, rot):
+        """causal_attention on an fp32 buffer whose output goes, in split-f16 form under the row scales 1/split_inv, into columns
+        split_col_off.. of `split_out` ((B*L, 2*Kp) float16; lo part Kp columns further) -- see psalm_causal_attention_f32_split."""
+        if buf.dtype != torch.float32 or split_out.dtype != torch.float16 or split_inv.dtype != torch.float32:
+            raise PsalmHipError("causal_attention_split: float32 qkv buffer, float16 split buffer, float32 scales")
+        self.lib.psalm_causal_attention_f32_workspace.restype = c_long
+        nbytes = self.lib.psalm_causal_attention_f32_workspace(B, L, heads)
+        key = ("causal_f32_ws", nbytes)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        rc = self.lib.psalm_causal_attention_f32_split(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._p(split_out),
+                                                       c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
+                                                       self._p(split_inv), self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
+                                                       B, L, heads, head_dim, rot, self._stream())
+        self._check(rc, "psalm_causal_attention_f32_split")
+        return split_out
 
     def mha_attention(self, q, k, v, B, Lq, Lk, heads, mask=None, row_all_masked=None):
         """q (B*Lq, D) / k, v (B*Lk, D) row-strided views, head_dim 32; mask (B,Lq,Lk) u8 1 = blocked."""

@@ -215,6 +215,22 @@ class PSALM:
     def _wop(self, t):                    # an ACTIVATION used as the W operand of a GEMM (mask features, class embeddings, ...)
         return self.ops.split_f16(t) if self.x3 and t is not None and t.shape[0] > 4096 else t
 
+    def _gemm_act_split(self, a, name, act):
+        """f16x3: act(a . W^T + b) of linear `name` straight into the split-f16 operand form of the GEMM that consumes it (no fp32 round
+        trip, no psalm_split_f16 pass); None when the shape does not allow it (caller falls back to gemm + implicit split)."""
+        o, w = self.ops, self.w
+        wt = w[name + ".w"]
+        bnd = w.get(name + ".bnd")
+        N = wt.shape[0]
+        if not self.x3 or bnd is None or N % 8 != 0 or not isinstance(wt, H.SplitF16):
+            return None
+        rows = a.shape[0]
+        Kp = (N + 63) // 64 * 64                                      # the consumer's K padding columns must read as zeros
+        so = (o.empty if Kp == N else o.zeros)(rows, 2 * Kp, dtype=torch.float16)
+        inv = o.empty(rows, dtype=torch.float32)
+        o.gemm_x3_split(a, wt, w.get(name + ".b"), act, so, inv, bnd)
+        return H.SplitF16(so, inv, N)
+
     def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
         return self._aligned(t.detach().to(torch.float32).contiguous().to(self.device))
 
@@ -230,6 +246,21 @@ class PSALM:
         def norm(dst, src):
             w[dst + ".g"] = Fp(sd[src + ".weight"])
             w[dst + ".b"] = Fp(sd[src + ".bias"])
+
+        def bound(dst, wt, bias, wt_g=None, bias_g=None):
+            """f16x3: the 4 magnitude-bound parameters of psalm_gemm_x3_split for a GEMM with weight rows `wt` / `bias` whose activated
+            output leaves in split-f16 form: {2^14 max_n sum_k |w_nk|, max |bias|, g1, g0}; (wt_g, bias_g): the rows whose outputs reach
+            the same operand rows through ANOTHER kernel (Phi: v_proj, through the attention) -> the row-independent term g1, g0."""
+            if not self.x3:
+                return
+
+            def l1(t):
+                return t.detach().to(self.device, torch.float32).abs().sum(1).max() * (1.0 + 1e-5) * 2.0 ** 14
+
+            def amax(t):
+                return t.detach().to(self.device, torch.float32).abs().max() if t is not None else torch.zeros((), device=self.device)
+            zero = torch.zeros((), device=self.device)
+            w[dst] = torch.stack([l1(wt), amax(bias), l1(wt_g) if wt_g is not None else zero, amax(bias_g)]).to(torch.float32).contiguous()
 
         # ---- Phi decoder.  Fused GEMM 1 rows: [k | v | q | fc1]  (attention output later overwrites the q columns, so
         # [attn | gelu(fc1)] is one contiguous K panel for fused GEMM 2 = [dense | fc2] with the two biases summed).
@@ -255,6 +286,7 @@ class PSALM:
                                             sd[p + "mlp.fc1.bias"]], 0))
             w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"].float() + sd[p + "mlp.fc2.bias"].float())
             norm(f"llm{i}.ln", p + "input_layernorm")
+            bound(f"llm{i}.bnd", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[a + "v_proj.weight"], sd[a + "v_proj.bias"])
         norm("llm.final", "model.final_layernorm")
 
         # ---- Swin
@@ -274,6 +306,9 @@ class PSALM:
                 lin(q + "qkv", p + "attn.qkv")
                 lin(q + "proj", p + "attn.proj")
                 lin(q + "fc1", p + "mlp.fc1")
+                bound(q + "fc1.bnd", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+                Cq = sd[p + "attn.qkv.weight"].shape[0] // 3                       # bound of the v rows: the window attention's output scale
+                bound(q + "qkv.bnd", sd[p + "attn.qkv.weight"][2 * Cq:], sd[p + "attn.qkv.bias"][2 * Cq:])
                 lin(q + "fc2", p + "mlp.fc2")
                 w[q + "rpb"] = Fp(sd[p + "attn.relative_position_bias_table"])
             if s < len(cfg.swin_depths) - 1:
@@ -319,6 +354,7 @@ class PSALM:
             lin(q + "out", p + "self_attn.output_proj")
             norm(q + "n1", p + "norm1")
             lin(q + "l1", p + "linear1")
+            bound(q + "l1.bnd", sd[p + "linear1.weight"], sd[p + "linear1.bias"])
             lin(q + "l2", p + "linear2")
             norm(q + "n2", p + "norm2")
         w["pd.adapter.w"] = W(sd[pd + "adapter_1.0.weight"].flatten(1))
@@ -420,7 +456,10 @@ class PSALM:
                 else:
                     xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
-                aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
+                if x3f and ws == 12 and isinstance(xw, H.SplitF16):      # f16x3: the output leaves as the projection GEMM's split operand
+                    aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift)
+                else:
+                    aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
                 pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)
                 if x3f:
                     x, h = o.swin_window_merge_ln_split(pw, x, w[q + "n2.g"], w[q + "n2.b"], B, Hc, Wc, ws, shift)
@@ -429,7 +468,8 @@ class PSALM:
                 else:
                     x = o.swin_window_merge(pw, x, B, Hc, Wc, ws, shift)
                     h = o.layernorm(x, w[q + "n2.g"], w[q + "n2.b"], out_dtype=self.adt)
-                h = o.gemm(h, w[q + "fc1.w"], w[q + "fc1.b"], act=H.ACT_GELU, out_dtype=self.adt)
+                hs = self._gemm_act_split(h, q + "fc1", H.ACT_GELU) if x3f else None      # f16x3: gelu(fc1) leaves as fc2's split operand
+                h = hs if hs is not None else o.gemm(h, w[q + "fc1.w"], w[q + "fc1.b"], act=H.ACT_GELU, out_dtype=self.adt)
                 x = o.gemm(h, w[q + "fc2.w"], w[q + "fc2.b"], residual=x, out_dtype=torch.float32)
             outs.append((o.layernorm(x, w[f"swin.out{s}.g"], w[f"swin.out{s}.b"], out_dtype=self.adt), Hc, Wc))
             if s < len(cfg.swin_depths) - 1:
@@ -672,7 +712,13 @@ class PSALM:
         Hd, I = cfg.hidden_size, cfg.intermediate_size
         cos, sin = self._rope(L)
         x = embeds
-        big = o.empty(B * L, 3 * Hd + I, dtype=self.adt)
+        # f16x3: gelu(fc1) (GEMM epilogue) and the attention output leave directly as the split-f16 A operand [attn | gelu(fc1)] of the
+        # [dense | fc2] GEMM -- one operand buffer, one scale per row from a magnitude bound (psalm_gemm_x3_split)
+        fuse_split = self.x3 and (Hd + I) % 64 == 0 and Hd % 8 == 0 and "llm0.bnd" in w and cfg.head_dim == 64 and cfg.rotary_dim == 32
+        big = o.empty(B * L, 3 * Hd if fuse_split else 3 * Hd + I, dtype=self.adt)
+        if fuse_split:
+            a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)
+            inv2 = o.empty(B * L, dtype=torch.float32)
         fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
         if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
             h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps)[1]
@@ -688,6 +734,18 @@ class PSALM:
                 aq, as_ = o.quantize_rows_fp8(big[:, 2 * Hd:])                    # one row scale over [attn | gelu(fc1)]
                 x = o.gemm_fp8(aq, as_, w[f"llm{i}.w2q"], w[f"llm{i}.w2s"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                 h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
+                continue
+            if fuse_split:
+                o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
+                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True)
+                o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
+                                         cfg.rotary_dim)
+                if last or Hd % 64 != 0 or Hd > 2048:
+                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                    h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \
+                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps)[1]
+                else:                                 # residual GEMM + the next layer's LayerNorm + its split: one pass after the K slices
+                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb, cfg.layer_norm_eps)
                 continue
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place
@@ -744,7 +802,9 @@ class PSALM:
                 # (linear1 input; next layer's value input = src and offset / weight input = src + pos)
                 src, src_s, _ = o.layernorm_split(o.gemm(att, w[q_ + "out.w"], w[q_ + "out.b"], residual=src, out_dtype=torch.float32),
                                                   w[q_ + "n1.g"], w[q_ + "n1.b"], want_y=True)
-                hdd = o.gemm(src_s, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
+                hdd = self._gemm_act_split(src_s, q_ + "l1", H.ACT_RELU)
+                if hdd is None:
+                    hdd = o.gemm(src_s, w[q_ + "l1.w"], w[q_ + "l1.b"], act=H.ACT_RELU, out_dtype=self.adt)
                 more = i + 1 < cfg.md_enc_layers
                 src, src_a, qin = o.layernorm_split(o.gemm(hdd, w[q_ + "l2.w"], w[q_ + "l2.b"], residual=src, out_dtype=torch.float32),
                                                     w[q_ + "n2.g"], w[q_ + "n2.b"], want_y=True, want_split=more, add=lvl_pos if more else None)

@@ -151,6 +151,35 @@ def test_window_attention(ops, dtype, B, nWh, nWw, heads, shift):
     assert (got - want).abs().max() <= tol(dtype, want.abs().max())
 
 
+@pytest.mark.parametrize("heads,shift", [(2, 0), (4, 6)])
+def test_window_attention_split_output(ops, heads, shift):
+    """psalm_window_attention_split == psalm_window_attention (fp32) followed by a split: one power-of-two scale per window from the bound
+    max_j (a_inv[j] * par[0] + par[1]) over the window's rows (>= every |v| of the window), hi + lo reproduces the fp32 output to 22 bits."""
+    B, nWh, nWw, ws, hd = 1, 2, 2, 12, 32
+    C = heads * hd
+    N, nW = ws * ws, nWh * nWw
+    rows = B * nW * N
+    g = torch.Generator().manual_seed(5 + heads)
+    qkv = torch.randn(rows, 3 * C, generator=g) * 0.7
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    a_inv = torch.exp2(torch.randint(-14, -8, (rows,), generator=g).float())
+    vmax_row = qkv[:, 2 * C:].abs().amax(1)
+    par = torch.tensor([float((vmax_row / a_inv).max()) * 1.01, 0.25])                 # a_inv[j] * par[0] + par[1] >= |v_j|
+    d = ops.device
+    ref = ops.window_attention(qkv.to(d), table.to(d), B, nWh, nWw, heads, ws, shift).cpu()
+    got = ops.window_attention_split(qkv.to(d), table.to(d), a_inv.to(d), par.to(d), B, nWh, nWw, heads, ws, shift)
+    Kp = got.Kp
+    t, inv = got.t.cpu(), got.inv_scale.cpu().double()
+    hi, lo = t[:, :C].double(), t[:, Kp:Kp + C].double()
+    assert ((hi + lo) * inv[:, None] - ref.double()).abs().max() <= 2.0 ** -21 * ref.abs().max() and hi.abs().max() < 2.0 ** 13
+    if Kp > C:
+        assert (t[:, C:Kp] == 0).all() and (t[:, Kp + C:] == 0).all()
+    bound = (a_inv * par[0] + par[1]).view(nW * B, N).amax(1).double()
+    sb = bound / inv.view(nW * B, N)[:, 0]
+    assert (inv.view(nW * B, N) == inv.view(nW * B, N)[:, :1]).all()                       # one scale per window
+    assert (sb >= 2.0 ** 12 * (1 - 1e-6)).all() and (sb < 2.0 ** 13 * (1 + 1e-6)).all()
+
+
 def _rope_tables(L, rot, theta=10000.0):
     inv = 1.0 / (theta ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
     fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
@@ -187,6 +216,39 @@ def test_causal_attention(ops, dtype, B, L, heads):
     got = out[:, 32:].cpu().float()
     assert (got - want).abs().max() <= tol(dtype, want.abs().max())
     assert out[:, :32].abs().max() == 0
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1)])
+def test_causal_attention_split_output(ops, B, L, heads):
+    """psalm_causal_attention_f32_split == psalm_causal_attention_f32 followed by a split under the given per-row scales: hi + lo reproduces
+    the fp32 output to 22 bits, in the requested columns of the operand buffer, nothing else is written."""
+    hd, rot = 64, 32
+    Hh = heads * hd
+    g = torch.Generator().manual_seed(17)
+    ld = 3 * Hh + 16
+    buf = (torch.randn(B * L, ld, generator=g) * 0.8)
+    key_mask = torch.ones(B, L, dtype=torch.uint8)
+    if B > 1:
+        key_mask[1, L - 20:] = 0
+    cos, sin = _rope_tables(L, rot)
+    d = ops.device
+    ref = torch.zeros(B * L, Hh, device=d)
+    ops.causal_attention(buf.to(d), 0, Hh + 8, 2 * Hh + 16, ref, 0, *dev(ops, cos, sin, key_mask), B, L, heads, hd, rot)
+    ref = ref.cpu()
+    vmax = buf[:, 2 * Hh + 16:3 * Hh + 16].abs().max()
+    inv = torch.exp2(torch.ceil(torch.log2(vmax)) - 12 + torch.randint(0, 4, (B * L,), generator=g).float())    # |v| / inv < 2^13
+    Kp, off = 256, 64
+    so = torch.zeros(B * L, 2 * Kp, dtype=torch.float16, device=d)
+    ops.causal_attention_split(buf.to(d), 0, Hh + 8, 2 * Hh + 16, so, inv.to(d), off, *dev(ops, cos, sin, key_mask), B, L, heads, hd, rot)
+    so = so.cpu()
+    hi, lo = so[:, off:off + Hh].double(), so[:, Kp + off:Kp + off + Hh].double()
+    rec = (hi + lo) * inv.double()[:, None]
+    assert ((rec - ref.double()).abs() <= 2.0 ** -21 * ref.abs().double() + 2.0 ** -24 * inv.double()[:, None]).all()
+    assert hi.abs().max() < 2.0 ** 13
+    mask = torch.ones(2 * Kp, dtype=torch.bool)
+    mask[off:off + Hh] = False
+    mask[Kp + off:Kp + off + Hh] = False
+    assert (so[:, mask] == 0).all()
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -361,6 +361,108 @@ def test_gemm_x3(ops, M, N, K, has_bias, has_res, act, policy, kloop):
     assert not bad.any(), f"max err {(got - want).abs().max().item()} rel-to-mag {((got - want).abs() / mag.clamp(min=1e-30)).max().item()}"
 
 
+def split_bound_par(w, bias, g1=0.0, g0=0.0):
+    """bound_par of psalm_gemm_x3_split for weight w (N,K) / bias (N,): {2^14 max_n sum_k |w_nk|, max |bias|, g1, g0}."""
+    l1 = float(w.abs().double().sum(1).max()) * (1 + 1e-5)
+    return torch.tensor([2.0 ** 14 * l1, float(bias.abs().max()) if bias is not None else 0.0, g1, g0], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,act,policy,col_start,col_off,glob", [
+    (300, 256, 128, H.ACT_GELU, 64, 0, 0, False),          # whole output in split form (Swin fc1 -> fc2)
+    (300, 264, 192, H.ACT_RELU, 128, 0, 64, False),        # 128 x 128 tiles, N % 128 != 0, written behind 64 other columns
+    (100, 72, 64, H.ACT_NONE, 64, 0, 0, False),            # M <= 128 (this form has no skinny kernel; the fp32 twin is forced onto the same tiles)
+    (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True),  # Phi layout: [k | v .. | fc1] -> fc1 columns only, row-independent floor on
+    (131, 384, 64, H.ACT_GELU_NEW, 64, 256, 8, True),
+])
+def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glob):
+    """psalm_gemm_x3_split: the columns >= col_start of act(a.w^T + b) leave the GEMM as split-f16 rows [hi | lo] under a per-row power-of-two
+    scale derived from a magnitude bound.  Checked: the bound holds (|hi| < 2^13), the scales are powers of two, hi + lo reproduces the fp32
+    result of psalm_gemm_x3 to 2^-21 (22-bit operand), the columns below col_start equal psalm_gemm_x3's bit for bit, and the NEXT GEMM on the
+    emitted operand equals the GEMM on the fp32 values split by psalm_split_f16 to fp32 round-off."""
+    g = torch.Generator().manual_seed(M + 3 * N + K + col_off)
+    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    d = ops.device
+    Ns = N - col_start
+    Kp_out = (col_off + Ns + 63) // 64 * 64
+    g1, g0 = (2.0 ** 14 * 3.0, 0.5) if glob else (0.0, 0.0)
+    par = split_bound_par(w[col_start:], bias[col_start:], g1, g0).to(d)
+    ops.gemm_tile_policy(policy)
+    try:
+        asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+        want = ops.gemm_x3(asp, wsp, bias.to(d), None, act, col_start)
+        so = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
+        inv = torch.full((M,), -1.0, device=d)
+        out = torch.full((M, N), 7.0, device=d) if col_start else None
+        ops.gemm_x3_split(asp, wsp, bias.to(d), act, so, inv, par, split_col_off=col_off, split_col_start=col_start, act_col_start=col_start,
+                          out=out, global_rows=glob)
+    finally:
+        ops.gemm_tile_policy(0)
+    so, inv, want = so.cpu(), inv.cpu(), want.cpu()
+    if col_start:
+        assert torch.equal(out.cpu()[:, :col_start], want[:, :col_start]) and (out.cpu()[:, col_start:] == 7.0).all()
+    m, e = torch.frexp(inv)
+    assert (m == 0.5).all() and (inv > 0).all()                                      # powers of two
+    hi = so[:, col_off:col_off + Ns].float()
+    lo = so[:, Kp_out + col_off:Kp_out + col_off + Ns].float()
+    assert hi.abs().max() < 2.0 ** 13
+    v = want[:, col_start:].double()
+    rec = (hi.double() + lo.double()) * inv.double()[:, None]
+    assert ((rec - v).abs() <= 2.0 ** -21 * v.abs() + 2.0 ** -24 * inv.double()[:, None]).all()
+    # the bound behind the scale: a_scale[r] * par[0] + par[1] (and the global floor) -- the scale puts it in [2^12, 2^13)
+    a_inv = asp.inv_scale.cpu().double()
+    bound = torch.maximum(a_inv * float(par[0]) + float(par[1]), a_inv.max() * g1 + g0 if glob else torch.zeros(()).double())
+    sb = bound / inv.double()
+    assert (sb >= 2.0 ** 12 * (1 - 1e-6)).all() and (sb < 2.0 ** 13 * (1 + 1e-6)).all()
+    assert (v.abs().amax(1) <= bound).all()
+    # untouched columns of the buffer stay zero (K padding of the consumer)
+    mask = torch.ones(2 * Kp_out, dtype=torch.bool)
+    mask[col_off:col_off + Ns] = False
+    mask[Kp_out + col_off:Kp_out + col_off + Ns] = False
+    assert (so[:, mask] == 0).all()
+    # consumer: GEMM over the emitted operand vs over psalm_split_f16(fp32 values)
+    w2 = torch.randn(40, col_off + Ns, generator=g)
+    x = torch.zeros(M, col_off + Ns)
+    x[:, col_off:] = want[:, col_start:]
+    a_emit = H.SplitF16(so.to(d), inv.to(d), col_off + Ns)
+    y1 = ops.gemm_x3(a_emit, w2.to(d)).cpu().double()
+    y2 = ops.gemm_x3(x.to(d), w2.to(d)).cpu().double()
+    mag = x.abs().double() @ w2.abs().double().t()
+    assert ((y1 - y2).abs() <= 8 * 2.0 ** -22 * mag + 1e-9).all()
+
+
+@pytest.mark.parametrize("M,N,K,policy,want_y", [(270, 256, 704, 128, True), (150, 128, 1408, 64, False), (300, 192, 128, 64, True)])
+def test_gemm_x3_ln_split(ops, M, N, K, policy, want_y):
+    """psalm_gemm_x3_ln_split == psalm_gemm_x3 (+ residual) followed by psalm_layernorm_split: x equal to fp32 round-off of the summation
+    order, the LayerNorm output in split form carries the exact row-maximum scale and reproduces LN(x) to 22 bits.  First two cases: split-K
+    (the fused row pass); last: un-split GEMM (LayerNorm as its own kernel)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 3, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.1
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    d = ops.device
+    ops.gemm_tile_policy(policy)
+    try:
+        asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+        x0 = ops.gemm_x3(asp, wsp, bias.to(d), res.to(d))
+        x, hs, y = ops.gemm_x3_ln_split(asp, wsp, bias.to(d), res.to(d), gamma.to(d), beta.to(d), 1e-5, want_y=want_y)
+    finally:
+        ops.gemm_tile_policy(0)
+    x0, x = x0.cpu(), x.cpu()
+    assert torch.equal(x, x0)
+    want = torch.nn.functional.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    if want_y:
+        assert (y.cpu().double() - want).abs().max() <= 4e-6 * want.abs().max()
+    inv = hs.inv_scale.cpu().double()
+    hi, lo = hs.t.cpu()[:, :N].double(), hs.t.cpu()[:, N:].double()
+    rec = (hi + lo) * inv[:, None]
+    assert (rec - want).abs().max() <= 4e-6 * want.abs().max()
+    rmax = (hi + lo).abs().amax(1)
+    assert (rmax >= 2.0 ** 13 * (1 - 1e-3)).all() and (rmax < 2.0 ** 14).all()          # psalm_split_f16's row scaling
+
+
 def test_gemm_x3_flag_routes_fp32_gemms(ops):
     """Ops.x3 = True (precision='f16x3'): float32 x float32 gemm() calls run in split-f16 arithmetic; bf16 GEMMs are untouched."""
     g = torch.Generator().manual_seed(3)

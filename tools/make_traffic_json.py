@@ -17,7 +17,8 @@ def bench_name(rk):
         a = [x.strip() for x in m.group(1).split(",")]
         tc = "bf16" if a[0] == "unsigned short" else "f32"
         conv = len(a) > 6 and a[6] == "true"
-        x3 = len(a) > 10 and a[10] == "true"                       # split-f16 variant (template parameter X3)
+        x3 = len(a) > 10 and a[10] in ("true", "1", "2")           # split-f16 variant (template parameter X3; the split-output epilogue
+        #                                                            variant, parameter SO, runs the same K loop and shares the name)
         return f"gemm_bf16_glds_kernel<{tc},{a[1]},{a[2]},{a[3]},{a[4]}{',conv' if conv else ''}{',x3' if x3 else ''}>"
     m = re.search(r"gemm_bf16_skinny_kernel<([^>]*)>", rk)
     if m:
