@@ -124,6 +124,9 @@ class PSALM:
         # gain (the LLM GEMMs fill the chip).  f16x3, r02: the 3x longer LLM GEMMs leave room (224 tiles on 256 CUs) for the decoder's ~150
         # small kernels: 28.96 -> 28.04 ms per image -> on by default in that mode.
         self.overlap_streams = precision == "f16x3"
+        # f16x3: GEMM / attention outputs that feed another GEMM leave their kernel already in split-f16 operand form (psalm_gemm_x3_split,
+        # psalm_*_attention*_split, psalm_gemm_x3_ln_split) instead of fp32 + a psalm_split_f16 pass.  False: the r02k data flow (tools/exp_modes.py A/B)
+        self.fuse_split = precision == "f16x3"
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.config = None                            # LlavaConfig when built by from_pretrained (llava_phi.py:34)
@@ -222,7 +225,7 @@ class PSALM:
         wt = w[name + ".w"]
         bnd = w.get(name + ".bnd")
         N = wt.shape[0]
-        if not self.x3 or bnd is None or N % 8 != 0 or not isinstance(wt, H.SplitF16):
+        if not self.fuse_split or bnd is None or N % 8 != 0 or not isinstance(wt, H.SplitF16):
             return None
         rows = a.shape[0]
         Kp = (N + 63) // 64 * 64                                      # the consumer's K padding columns must read as zeros
@@ -456,7 +459,7 @@ class PSALM:
                 else:
                     xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
-                if x3f and ws == 12 and isinstance(xw, H.SplitF16):      # f16x3: the output leaves as the projection GEMM's split operand
+                if x3f and self.fuse_split and ws == 12 and isinstance(xw, H.SplitF16):      # f16x3: the output leaves as the projection GEMM's split operand
                     aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift)
                 else:
                     aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
@@ -714,7 +717,7 @@ class PSALM:
         x = embeds
         # f16x3: gelu(fc1) (GEMM epilogue) and the attention output leave directly as the split-f16 A operand [attn | gelu(fc1)] of the
         # [dense | fc2] GEMM -- one operand buffer, one scale per row from a magnitude bound (psalm_gemm_x3_split)
-        fuse_split = self.x3 and (Hd + I) % 64 == 0 and Hd % 8 == 0 and "llm0.bnd" in w and cfg.head_dim == 64 and cfg.rotary_dim == 32
+        fuse_split = self.fuse_split and (Hd + I) % 64 == 0 and Hd % 8 == 0 and "llm0.bnd" in w and cfg.head_dim == 64 and cfg.rotary_dim == 32
         big = o.empty(B * L, 3 * Hd if fuse_split else 3 * Hd + I, dtype=self.adt)
         if fuse_split:
             a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)

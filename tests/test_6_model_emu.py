@@ -188,3 +188,22 @@ def test_tiny_eval_seg_f16x3_mode(queries, size):
     gi, wi = g["instances"], w["instances"]
     assert len(gi.scores) == len(wi.scores)
     assert (torch.sort(gi.scores.cpu()).values - torch.sort(wi.scores).values).abs().max() < 1e-4
+
+
+def test_tiny_f16x3_fused_split_outputs_match_unfused():
+    """The f16x3 mode's fused operand hand-over (GEMM epilogue / attention kernels emit the next GEMM's split-f16 operand under a
+    bound-derived scale) against the same model with fuse_split = False (fp32 tensors + psalm_split_f16 passes, exact row-max scales):
+    the two only differ in where hi + lo hits the f16 subnormal floor and in the split-K / LayerNorm summation order -> fp32 round-off."""
+    cfg = PsalmConfig.tiny("panoptic")
+    sd = make_state_dict(cfg, seed=21)
+    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=6, num_classes=7)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
+    assert model.fuse_split
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    torch.manual_seed(5)
+    a = model.forward_logits(**kw)[0]
+    model.fuse_split = False
+    torch.manual_seed(5)
+    b = model.forward_logits(**kw)[0]
+    for k in ("pred_masks", "pred_class_name_logits"):
+        assert _rel(a[k], b[k]) < 2e-5, k

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from psalm_amd.config import PsalmConfig
 from psalm_amd.model import PSALM
 from psalm_amd.synthetic import make_inputs, make_state_dict
-from tools.exp_x3 import metrics, clone
+from tools._metrics import metrics, clone
 
 
 def main():
@@ -23,9 +23,11 @@ def main():
     torch.cuda.empty_cache()
     out = {}
     for mode in modes:
-        overlap = mode.endswith("+overlap")
-        m = PSALM(cfg, sd, precision=mode.split("+")[0], use_graphs=True)
-        m.overlap_streams = overlap
+        parts = mode.split("+")                      # e.g. f16x3+overlap, f16x3+overlap+nofuse (split-f16 outputs of GEMMs / attention off)
+        m = PSALM(cfg, sd, precision=parts[0], use_graphs=True)
+        m.overlap_streams = "overlap" in parts
+        if "nofuse" in parts:
+            m.fuse_split = False
         for _ in range(3):
             r = m.eval_seg(**inputs)
         torch.cuda.synchronize()
@@ -45,6 +47,8 @@ def main():
         agg = {}
         for name, a, e0, e1 in recs:
             d = agg.setdefault(name, [0, 0.0]); d[0] += 1; d[1] += e0.elapsed_time(e1)
+        while mode in out:
+            mode += "'"                             # repeated modes (interleaved A/B runs) keep separate entries
         out[mode] = {"ms_per_image_graph": round(ms, 3), "images_per_s": round(1e3 / ms, 2), "vs_fp32": metrics(got, ref),
                      "breakdown_ms": {k: [v[0], round(v[1], 3)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}}
         print(mode, json.dumps(out[mode]), flush=True)

@@ -22,21 +22,7 @@ def rnd(t, m):                                   # round to nearest at m explici
     return i.view(torch.float32)
 
 
-def metrics(g, w_):
-    gm, wm = g["mask_pred"] > 0, w_["mask_pred"] > 0
-    inter = (gm & wm).flatten(1).sum(1).float()
-    union = (gm | wm).flatten(1).sum(1).float()
-    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
-    return {"iou_pooled": float(inter.sum() / union.sum()), "iou_mean": float(iou.mean()), "iou_min": float(iou.min()),
-            "pix_agree": float((gm == wm).float().mean()),
-            "sem_agree": float((g["sem_seg"].argmax(0) == w_["sem_seg"].argmax(0)).float().mean()),
-            "pan_agree": float((g["panoptic_seg"][0] == w_["panoptic_seg"][0]).float().mean())}
-
-
-def clone(r):
-    return {"mask_pred": r["mask_pred"].clone(), "sem_seg": r["sem_seg"].clone(),
-            "panoptic_seg": (r["panoptic_seg"][0].clone(), r["panoptic_seg"][1])}
-
+from tools._metrics import metrics, clone  # noqa
 
 STAGES = {"swin": ("swin",), "llm": ("projector", "llm"), "pixel_decoder": ("pixel_decoder",), "predictor": ("predictor",)}
 
@@ -80,7 +66,7 @@ def main():
             tag(n)
     ops.gemm = gemm_q
     out = {}
-    runs = [(s, m) for m in (10, 7) for s in STAGES] + [("swin+llm", 10), ("swin+llm+pixel_decoder", 10), ("all", 10)]
+    runs = [(s, 10) for s in STAGES] + [("all", 10), ("llm", 7), ("predictor", 7)]
     for s, m in runs:
         on = sum((STAGES[x] for x in (STAGES if s == "all" else s.split("+"))), ())
         state.update(on=on, m=m, n=0)
