@@ -190,20 +190,26 @@ def test_tiny_eval_seg_f16x3_mode(queries, size):
     assert (torch.sort(gi.scores.cpu()).values - torch.sort(wi.scores).values).abs().max() < 1e-4
 
 
-def test_tiny_f16x3_fused_split_outputs_match_unfused():
+@pytest.mark.parametrize("task,batch,keys", [("panoptic", 1, ("pred_masks", "pred_class_name_logits")),
+                                             ("referring", 2, ("pred_masks", "pred_SEG_logits"))])
+def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
     """The f16x3 mode's fused operand hand-over (GEMM epilogue / attention kernels emit the next GEMM's split-f16 operand under a
     bound-derived scale) against the same model with fuse_split = False (fp32 tensors + psalm_split_f16 passes, exact row-max scales):
     the two only differ in where hi + lo hits the f16 subnormal floor and in the split-K / LayerNorm summation order -> fp32 round-off."""
-    cfg = PsalmConfig.tiny("panoptic")
+    cfg = PsalmConfig.tiny(task)
     sd = make_state_dict(cfg, seed=21)
-    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=6, num_classes=7)
+    inputs = make_inputs(cfg, task, size=96, batch=batch, seed=6, num_classes=7)            # batch 2: ragged prompts, padded key mask
     model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
     assert model.fuse_split
     kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
     torch.manual_seed(5)
-    a = model.forward_logits(**kw)[0]
+    model_out_a = model.forward_logits(**kw)
     model.fuse_split = False
     torch.manual_seed(5)
-    b = model.forward_logits(**kw)[0]
-    for k in ("pred_masks", "pred_class_name_logits"):
-        assert _rel(a[k], b[k]) < 2e-5, k
+    model_out_b = model.forward_logits(**kw)
+    a, b = model_out_a[0], model_out_b[0]
+    for i in range(batch):
+        for k in keys:
+            assert _rel(a[k], b[k]) < 2e-5, (i, k)
+        if i + 1 < batch:
+            a, b = model_out_a[i + 1], model_out_b[i + 1]
