@@ -11,6 +11,7 @@
 //   psalm_attn_mask         bilinear resize of mask logits + (sigmoid < 0.5) -> u8 mask + all-masked row flags
 //                           (mask2former_transformer_decoder.py:754-759)
 #include "common.h"
+#include <cstdlib>
 
 // ============================================================================================ Swin window attention
 // qkv (B*nW*N, 3C) rows ordered like window_partition (swin_trans.py:37-49); head h uses columns
@@ -612,18 +613,28 @@ __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __r
 
 // SO = true: the output leaves as split-f16 operand columns (hi at `out` + o_off, lo so_kp f16 further; `out` is then the f16 buffer, ldo its
 // row stride in f16) under the per-row scales 1 / so_inv[row] ANOTHER kernel chose (psalm_gemm_x3_split's bound covers |v| of every row).
+// pair = 1 (default): a block takes the query tiles (nqt-1-p, p) one after the other -- nqt + 1 key tiles of work whatever p.  With one
+// tile per block (pair = 0, heaviest first) most of a Phi layer's 928 blocks are resident at once, so the order balances little and a CU
+// holding several late tiles sets the time (r02n, L = 899: 72.4 -> 61.5 us; SQ counters of the paired form: matrix pipe 37 % busy,
+// waves 52 % issue-stalled behind the partner wave's products, 31 % in s_waitcnt -- profiles/r02n_attn_*).
+// PSALM_WAVES_PER_EU(2): 138 instead of 135 + 48 accumulation registers -> 3 resident waves per SIMD (r02n: 80.4 -> 75.0 us unpaired).
 template <bool SO>
-__global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr,
-                                                                          const unsigned char* __restrict__ Mk, const float* __restrict__ base,
-                                                                          long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
-                                                                          int heads, const float* __restrict__ so_inv, int so_kp) {
+__global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(2)
+causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr, const unsigned char* __restrict__ Mk,
+                                   const float* __restrict__ base, long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
+                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
     __shared__ float Ml[4][2][32];                                        // per-wave (m, l) per query
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
-    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;      // heaviest (last) query tiles first
+    const int h = blockIdx.y, b = blockIdx.z, nqt = Lp / 32;
     const long bh = (long)b * heads + h;
+    const int npass = pair ? ((int)(nqt - 1 - blockIdx.x) > (int)blockIdx.x ? 2 : 1) : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qt = pair ? (pass == 0 ? nqt - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)(gridDim.x - 1 - blockIdx.x);
+    const int w0 = pass ? 3 - wave : wave;                                // second tile: key tiles dealt in the opposite wave order
+    if (pass) __syncthreads();                                            // the first tile's merge has been read out of Os / Ml
     const int qi = qt * 32 + n32;                                         // this lane's query column (row qi < Lp of Qr)
     float qv[32];
     {
@@ -639,7 +650,7 @@ __global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const 
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -3.0e38f, l = 0.f;
     const float* vbase = base + (long)b * L * ld + v_off + h * HD + n32;
-    for (int kt = wave; kt <= qt; kt += 4) {                              // key tiles 0..qt (the diagonal tile is qt)
+    for (int kt = w0; kt <= qt; kt += 4) {                                // key tiles 0..qt (the diagonal tile is qt)
         // ---- fragments of this tile, all loads issued up front (rows clamped: padded keys are masked below)
         psalm_f32x4 kf[8];
         {
@@ -751,6 +762,7 @@ __global__ void __launch_bounds__(256) causal_attention_f32_splitk_kernel(const 
             }
         }
     }
+    }
 }
 
 extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
@@ -778,12 +790,16 @@ static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phi_rope_prep_f32_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, cos_table, sin_table, key_mask,
                        Qr, Kr, Mk, L, Lp, heads, scale);
+    static int pair = -1;                                                 // PSALM_ATTN_PAIR=0: one query tile per block (tuning / A-B)
+    if (pair < 0) { const char* e = getenv("PSALM_ATTN_PAIR"); pair = e ? (atoi(e) != 0) : 1; }
+    const int nqt = Lp / 32;
+    const dim3 grid(pair ? (nqt + 1) / 2 : nqt, heads, B);
     if (so_inv)
-        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp);
+        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
     else
-        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, dim3(Lp / 32, heads, B), dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0);
+        hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
     PSALM_LAUNCH_END(name);
 }
 extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,

@@ -99,6 +99,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): the LDS destination is the WAVE-UNIFORM
 // `lds_wave_base` + lane*16 (hardware adds the lane offset; the base goes through M0), the global source is per lane.
 // Completion is tracked by vmcnt; a following __syncthreads() drains it.
+#ifdef PSALM_EMU_BUILD
+#define PSALM_WAVES_PER_EU(n)
+#else
+#define PSALM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))   // register budget of a kernel: at least n resident waves per SIMD
+#endif
 #ifdef PSALM_EMU_BUILD   // host build of the same kernel sources for the CPU tests (tests/emu): functional stand-in
 __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base) { emu::global_load_lds(g, lds_wave_base, 16); }
 #else
