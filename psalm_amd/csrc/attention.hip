@@ -114,8 +114,10 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
 // an output row is a convex combination of the window's v rows, |v_jd| <= a_inv[j] * par[0] + par[1] (a_inv: the row scales of the qkv
 // GEMM's split-f16 A operand, par = {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}), so max_j of that bounds all of
 // them; every head's wavefront derives the same scale, head 0's writes 1/scale to so_inv.
-template <int HD, int WS, bool SO = false>
-__global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
+// NWV wavefronts per (window, head) share the staged V / bias and take every NWV-th query tile: a Swin-B stage-3 launch has only 36 windows x
+// 16 heads = 576 (window, head) pairs for 1024 SIMDs, each a 17 us serial chain of matrix instructions when one wavefront owns all 9 tiles.
+template <int HD, int WS, bool SO = false, int NWV = 3>
+__global__ void __launch_bounds__(64 * NWV) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                        float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift,
                                                                        const float* __restrict__ a_inv = nullptr,
                                                                        const float* __restrict__ so_par = nullptr,
@@ -126,14 +128,14 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
     HIP_DYNAMIC_SHARED(float, smem)
     float* Vs = smem;                       // [N][LS]
     float* Bs = Vs + N * LS;                // [NB]
-    const int win = blockIdx.x, h = blockIdx.y, lane = threadIdx.x, n16 = lane & 15, kk = lane >> 4;
+    const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, kk = lane >> 4;
     const long row0 = (long)win * N;
-    for (int e = lane; e < N * (HD / 4); e += 64) {                      // 144 rows x 8 float4 per operand
+    for (int e = tid; e < N * (HD / 4); e += 64 * NWV) {                 // 144 rows x 8 float4 per operand
         const int r = e >> 3, c4 = (e & 7) * 4;
         const float* p = qkv + (row0 + r) * 3 * C + h * HD + c4;
         *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
     }
-    for (int e = lane; e < NB; e += 64) Bs[e] = bias_table[(long)e * heads + h];
+    for (int e = tid; e < NB; e += 64 * NWV) Bs[e] = bias_table[(long)e * heads + h];
     float so_sc = 1.f;
     if constexpr (SO) {
         float gmax = 0.f;
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
         float bound = fminf(fmaxf(gmax * so_par[0] + so_par[1], 7.888609e-31f), 1.2676506e30f);        // [2^-100, 2^100]
         const unsigned eb = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;                        // bound * scale in [2^12, 2^13)
         so_sc = __builtin_bit_cast(float, (266u - eb) << 23);
-        if (h == 0) {
+        if (h == 0 && wave == 0) {
             const float inv = __builtin_bit_cast(float, (eb - 12u) << 23);
             for (int r = lane; r < N; r += 64) so_inv[row0 + r] = inv;
         }
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(64) window_attention_f32_mfma_kernel(const flo
             for (int r = 0; r < 4; ++r) klab[tk][r] = label(16 * tk + 4 * kk + r);
     }
 #pragma unroll 1
-    for (int tq = 0; tq < NT; ++tq) {
+    for (int tq = wave; tq < NT; tq += NWV) {
         const int qi = 16 * tq + n16;                                    // this lane's query (column of S^T / O^T)
         float qf[8];
         {
@@ -264,8 +266,12 @@ extern "C" int psalm_window_attention_split(const float* qkv, const float* bias_
     const int nwin = B * nWh * nWw;
     if (nwin == 0) return 0;
     const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float);
-    hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream, qkv, bias_table,
-                       (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    if ((long)nwin * heads <= 320)                                        // wavefronts per (window, head): as psalm_window_attention
+        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 3>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream, qkv,
+                           bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    else
+        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream, qkv,
+                           bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
     PSALM_LAUNCH_END("psalm_window_attention_split");
 }
 
@@ -278,8 +284,17 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
     const int N = ws * ws;
     if (dtype == PSALM_F32 && ws == 12 && C % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {     // fp32 matrix-core kernel
         const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
-        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
-                           (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
+        // wavefronts per (window, head): 3 only when the grid cannot give every SIMD a wavefront anyway (r02n, 1024^2 image: stage 4, 288
+        // pairs: 41 -> 32 us; stage 3, 576 pairs: 48.5 -> 52.4; stage 1, 1936 pairs: 100 -> 136 -- profiles/r02n_winattn_nwv.jsonl)
+        static int nwv_env = -1;                                          // PSALM_WINATTN_NWV = 1 / 3 forces it (tuning / A-B)
+        if (nwv_env < 0) { const char* e = getenv("PSALM_WINATTN_NWV"); nwv_env = e ? atoi(e) : 0; }
+        const int nwv = nwv_env == 1 || nwv_env == 3 ? nwv_env : ((long)nwin * heads <= 320 ? 3 : 1);
+        if (nwv == 1)
+            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
+                               (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
+        else
+            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream,
+                               (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
         PSALM_LAUNCH_END("psalm_window_attention");
     }
     const size_t shmem = (size_t)(2 * N * 33 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
