@@ -166,8 +166,8 @@ def main():
                 B_, H_, W_, Cin, Cout, ks, st, pd_ = a[1], a[2], a[3], a[4], a[6], a[7], a[8], a[9]
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
                 geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
-            x3 = name in ("psalm_gemm_x3", "psalm_gemm_x3_split")
-            if name == "psalm_gemm_x3":                                          # split-f16 GEMM: the kernel's K range is 3*Kp
+            x3 = name in ("psalm_gemm_x3", "psalm_gemm_x3_split", "psalm_gemm_x3_ln_split")
+            if name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):              # split-f16 GEMM: the kernel's K range is 3*Kp
                 geo = (a[12], a[13], 3 * a[6], True, False, ",x3")
             elif x3:                                                             # ... with the split-f16 output epilogue (same K loop)
                 geo = (a[10], a[11], 3 * a[6], True, False, ",x3")
@@ -187,9 +187,11 @@ def main():
                         BM, BN, splits = (64, 128, 1)
                     kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}{tag}>"
                     if splits > 1:
-                        kname += " + splitk_reduce_ln_kernel" if name == "psalm_gemm_ln" else " + splitk_reduce_kernel"
+                        kname += " + splitk_reduce_ln_kernel" if name in ("psalm_gemm_ln", "psalm_gemm_x3_ln_split") else " + splitk_reduce_kernel"
                     elif name == "psalm_gemm_ln":
                         kname += " + layernorm_vec_kernel"
+                    elif name == "psalm_gemm_x3_ln_split":
+                        kname += " + layernorm_split_kernel"
                 else:
                     kname = f"gemm_bf16_kernel<{'bf16' if a_bf16 else 'f32'},{'bf16' if c_bf16 else 'f32'},{BM}>"
                 kd = kern.setdefault(kname, [0, 0.0, 0.0])
