@@ -12,11 +12,19 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "psalm_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# EMU_ASAN=1: AddressSanitizer build (own directory) -- every global / LDS / stack access of the kernels checked at source level.  Run as
+#   LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 EMU_ASAN=1 \
+#       python -m pytest tests -m "not gpu" -k <kernel tests>
+ASAN = os.environ.get("EMU_ASAN") == "1"
+OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
 LIB = os.path.join(OUT, "libpsalm_emu.so")
 CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DPSALM_EMU_BUILD", "-Wno-unknown-attributes", "-Wno-unknown-pragmas",
          "-Wno-pass-failed", "-I", HERE, "-I", os.path.join(ROOT, "include")]
+LDFLAGS = []
+if ASAN:
+    FLAGS += ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"]
+    LDFLAGS += ["-fsanitize=address", "-shared-libasan"]
 
 
 def build(force=False, verbose=True):
@@ -43,7 +51,7 @@ def build(force=False, verbose=True):
                 if verbose:
                     print(f"[emu] compiled {os.path.basename(s)}")
     if jobs or force or not os.path.exists(LIB):
-        r = subprocess.run([CXX, "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        r = subprocess.run([CXX, "-shared", "-fPIC", "-o", LIB] + LDFLAGS + objs, capture_output=True, text=True)
         if r.returncode:
             print(r.stderr, file=sys.stderr)
             raise RuntimeError("emu link failed")
