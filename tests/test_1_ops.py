@@ -188,7 +188,8 @@ def _rope_tables(L, rot, theta=10000.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1), (2, 300, 2), (1, 129, 1)])   # 300: three 128-query blocks, ragged last
+# 300: three 128-query blocks, ragged last;  (1, 100, 8) / (2, 70, 4): more (batch, head) pairs than the 1- and 2-head cases
+@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1), (2, 300, 2), (1, 129, 1), (1, 100, 8), (2, 70, 4)])
 def test_causal_attention(ops, dtype, B, L, heads):
     hd, rot = 64, 32
     H = heads * hd
@@ -218,7 +219,7 @@ def test_causal_attention(ops, dtype, B, L, heads):
     assert out[:, :32].abs().max() == 0
 
 
-@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1)])
+@pytest.mark.parametrize("B,L,heads", [(1, 70, 2), (2, 150, 1), (2, 70, 4)])
 def test_causal_attention_split_output(ops, B, L, heads):
     """psalm_causal_attention_f32_split == psalm_causal_attention_f32 followed by a split under the given per-row scales: hi + lo reproduces
     the fp32 output to 22 bits, in the requested columns of the operand buffer, nothing else is written."""
@@ -237,7 +238,8 @@ def test_causal_attention_split_output(ops, B, L, heads):
     ref = ref.cpu()
     vmax = buf[:, 2 * Hh + 16:3 * Hh + 16].abs().max()
     inv = torch.exp2(torch.ceil(torch.log2(vmax)) - 12 + torch.randint(0, 4, (B * L,), generator=g).float())    # |v| / inv < 2^13
-    Kp, off = 256, 64
+    off = 64
+    Kp = (off + Hh + 63) // 64 * 64 + 64
     so = torch.zeros(B * L, 2 * Kp, dtype=torch.float16, device=d)
     ops.causal_attention_split(buf.to(d), 0, Hh + 8, 2 * Hh + 16, so, inv.to(d), off, *dev(ops, cos, sin, key_mask), B, L, heads, hd, rot)
     so = so.cpu()
