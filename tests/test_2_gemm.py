@@ -432,6 +432,40 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     assert ((y1 - y2).abs() <= 8 * 2.0 ** -22 * mag + 1e-9).all()
 
 
+@pytest.mark.parametrize("loose_bits", [0, 10, 13])
+def test_gemm_x3_split_output_loose_bound(ops, loose_bits):
+    """How loose may the magnitude bound behind the output scale be?  With the bound inflated by 2^loose_bits the emitted operand still
+    stands for the fp32 values to max(2^-21 |v|, 2^(loose_bits - 36) * row bound-free maximum): hi + lo keeps 22 bits until lo reaches the
+    f16 subnormal floor, so at 2^10 the absolute error stays below 2^-26 of the row maximum (under one fp32 ulp of the largest element)
+    and the NEXT GEMM's result moves by less than its own fp32 round-off; at 2^13 it reaches the fp32 ulp (the documented limit)."""
+    M, N, K = 200, 256, 128
+    g = torch.Generator().manual_seed(31 + loose_bits)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g) * 0.1
+    d = ops.device
+    par = split_bound_par(w, bias) * torch.tensor([2.0 ** loose_bits, 2.0 ** loose_bits, 1.0, 1.0])
+    ops.gemm_tile_policy(64)
+    try:
+        asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+        want = ops.gemm_x3(asp, wsp, bias.to(d), None, H.ACT_GELU, 0).cpu().double()
+        so = torch.zeros(M, 2 * N, dtype=torch.float16, device=d)
+        inv = torch.zeros(M, device=d)
+        ops.gemm_x3_split(asp, wsp, bias.to(d), H.ACT_GELU, so, inv, par.to(d))
+    finally:
+        ops.gemm_tile_policy(0)
+    so, inv = so.cpu(), inv.cpu().double()
+    rec = (so[:, :N].double() + so[:, N:].double()) * inv[:, None]
+    rowmax = want.abs().amax(1, keepdim=True)
+    # typical looseness of the un-inflated bound on this data is ~2^5..2^6 (L1 norm vs the actual dot products)
+    assert ((rec - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** (loose_bits + 7 - 37) * rowmax).all()
+    w2 = torch.randn(48, N, generator=g)
+    y1 = ops.gemm_x3(H.SplitF16(so.to(d), inv.float().to(d), N), w2.to(d)).cpu().double()
+    y2 = want @ w2.double().t()
+    mag = want.abs() @ w2.abs().double().t()
+    assert ((y1 - y2).abs() <= (8 * 2.0 ** -22 + 2.0 ** (loose_bits + 7 - 37)) * mag + 1e-9).all()
+
+
 @pytest.mark.parametrize("M,N,K,policy,want_y", [(270, 256, 704, 128, True), (150, 128, 1408, 64, False), (300, 192, 128, 64, True)])
 def test_gemm_x3_ln_split(ops, M, N, K, policy, want_y):
     """psalm_gemm_x3_ln_split == psalm_gemm_x3 (+ residual) followed by psalm_layernorm_split: x equal to fp32 round-off of the summation
