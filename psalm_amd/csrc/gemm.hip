@@ -32,6 +32,23 @@
 #define ACT_POST_RESIDUAL 16   // flag: apply the activation AFTER adding the residual (ResNet block: relu(out + residual))
 #define ACT_BIAS_ROW 32        // flag: bias is indexed by the output ROW (C = W_x . X^T products, i.e. transposed projections)
 
+// Phase stamps for tools/experiments/gemm_timeline.py, which builds a SEPARATE copy of this library with -DPSALM_GEMM_TIMELINE (block-level
+// time line of the direct-to-LDS kernel: entry / prologue issued / first tile visible / K loop done / tile in LDS / stored); the product
+// build compiles PSALM_TL() to nothing.
+#ifdef PSALM_GEMM_TIMELINE
+__device__ unsigned long long* g_psalm_tl = nullptr;
+extern "C" int psalm_gemm_timeline_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_psalm_tl), &p, sizeof(p)); }
+#define PSALM_TL(i)                                                                                                                      \
+    do {                                                                                                                                 \
+        if (g_psalm_tl && threadIdx.x == 0)                                                                                              \
+            g_psalm_tl[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                    \
+    } while (0)
+#define PSALM_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PSALM_TL(i) do { } while (0)
+#define PSALM_TL_DRAIN() do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -344,6 +361,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS][(BM + BN) * BK * XS];
 
     const int tid = threadIdx.x, lane = tid & 63;
+    PSALM_TL(0);
     const int wave = PH8 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;   // PH8: scalar (wave-row dependent barriers)
     const int wm = wave / WN, wn = wave % WN;
     const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
@@ -551,8 +569,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         };
         stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
         stage_a(1, BK, 0); stage_b(1, BK, 1); stage_a(1, BK, 1);                       // tile 1 except B0 (6 copies)
+        PSALM_TL(1);
         wait_vmcnt_le<6>();
         PSALM_RAW_BARRIER();
+        PSALM_TL(2);
         if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
         int t = 0;
 #pragma unroll 1
@@ -567,6 +587,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk) issue(p, p * BK);
+    PSALM_TL(1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % NS;
         if constexpr (NS == 2) {
@@ -578,6 +599,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             else wait_vmcnt_le<0>();
         }
         PSALM_RAW_BARRIER();
+        if (kt == 0) PSALM_TL(2);
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
@@ -655,6 +677,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         }
     }
     }
+    PSALM_TL(3);
     __syncthreads();                                             // all waves done with the operand ring before it is reused
     // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
     // per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
@@ -715,6 +738,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         bool so_here = false;                                     // this thread's 8 columns go out in split-f16 form
         if constexpr (SO) so_here = fa.so != nullptr && col0 >= fa.so_col_start;
         __syncthreads();
+        if (ep == 0) PSALM_TL(4);
         if (col0 >= g.N) continue;
         // one store iteration (rows it * RPI + tid / TPR of the pass); false = past the last row of the matrix.  `itc` indexes the fp8
         // row-scale registers and must be a compile-time constant there (fully unrolled caller); bf16 / fp32 kernels keep the compact
@@ -798,6 +822,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 if (!store_it(it, 0)) break;
         }
     }
+    PSALM_TL_DRAIN();                                            // (timeline build: the stores have left the wave)
+    PSALM_TL(5);
 }
 
 // ------------------------------------------------------------------------------------------- skinny GEMM (M <= 128)

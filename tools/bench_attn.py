@@ -13,7 +13,7 @@ from psalm_amd import hip_ops as H
 def main():
     L, heads, hd, rot = 899, 32, 64, 32
     Hd = heads * hd
-    ops = H.get_ops()
+    ops = H.Ops(os.environ["PSALM_LIB"]) if os.environ.get("PSALM_LIB") else H.get_ops()      # PSALM_LIB: an experiment build of the library
     g = torch.Generator().manual_seed(0)
     out = {}
     for ld in (3 * Hd, 3 * Hd + 8192):                       # fused-split layout / the [k|v|q|fc1] layout
@@ -34,7 +34,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out[f"ld{ld}"] = {"us_per_call": round(e0.elapsed_time(e1) * 1e3 / 50, 2), "checksum": float(o.double().sum())}
-    print(json.dumps({"PSALM_ATTN_PAIR": os.environ.get("PSALM_ATTN_PAIR", "1"), **out}))
+    print(json.dumps({"lib": os.path.basename(ops.lib_path), "PSALM_ATTN_PAIR": os.environ.get("PSALM_ATTN_PAIR", "1"), **out}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,178 @@
+"""Experiment (not product): can part of the split-f16 GEMM's 3 products be bought back?  (VERDICT r02 "Next" #2: asymmetric splits, gated on
+several seeds.)
+
+The f16x3 GEMM computes  sa sw (Ahi.Whi + Alo.Whi + Ahi.Wlo).  The two cross terms are ~2^-11 of the main term, so THEY need only ~6-7 good
+bits for an 17-18 bit result -- candidates, all emulated here numerically (operands rounded in torch, products by an fp32 matmul; nothing of
+this is a kernel yet) on the GEMMs of ONE stage, every other stage exact fp32, against the exact-fp32 GPU result:
+
+  x3        hi.hi + lo.hi + hi.lo                      (what ships; sanity line of the emulation)
+  mx8       hi.hi + q(lo).q(hi) + q(hi).q(lo)          q = OCP MX e4m3 (block scale per 32 k): both cross terms at 2x the f16 MFMA rate
+                                                        -> 2 "f16 product equivalents" instead of 3
+  mx8w      hi.hi + lo.hi + q(hi).q(lo_w)              only the W-lo term in MX e4m3 (2.5 equivalents)
+  dropw     hi.hi + lo.hi                              A 22 bit x W 11 bit (2 products)
+  dropa     hi.hi + hi.lo                              A 11 bit x W 22 bit (2 products)
+  x1        hi.hi                                      (1 product)
+
+    python tools/exp_fp8cross.py [seeds=3] [size=1024]   -> one JSON line per (seed, stage, mode)"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from psalm_amd import hip_ops as H  # noqa: E402
+from psalm_amd.config import PsalmConfig  # noqa: E402
+from psalm_amd.model import PSALM  # noqa: E402
+from psalm_amd.synthetic import make_inputs, make_state_dict  # noqa: E402
+from tools._metrics import clone, metrics  # noqa: E402
+
+
+def split(x):
+    """psalm_split_f16: per-row power-of-two scale placing the row maximum in [2^13, 2^14); x s = hi + lo in f16."""
+    amax = x.abs().amax(1, keepdim=True)
+    _, ex = torch.frexp(amax)                        # amax = m 2^ex, m in [0.5, 1)  ->  floor(log2 amax) = ex - 1
+    s = torch.where(amax > 0, torch.exp2((14 - ex).float()), torch.ones_like(amax))
+    xs = x * s
+    hi = xs.half().float()
+    lo = (xs - hi).half().float()
+    return hi, lo, 1.0 / s
+
+
+def q_mx8(x):
+    """OCP MX e4m3: blocks of 32 along k share a power-of-two scale 2^(floor(log2 blockmax) - 8); elements rounded to nearest even at
+    3 mantissa bits (subnormal step 2^-9), saturating at 448."""
+    r, K = x.shape
+    xb = x.reshape(r, K // 32, 32)
+    bmax = xb.abs().amax(-1, keepdim=True)
+    _, ex = torch.frexp(bmax)
+    sc = torch.where(bmax > 0, torch.exp2((ex - 1 - 8).float()), torch.ones_like(bmax))
+    v = (xb / sc).clamp(-448.0, 448.0)
+    a = v.abs()
+    _, e2 = torch.frexp(a)
+    e = (e2 - 1).clamp_min(-6).float()                # exponent of the binade; below 2^-6 the subnormal step applies
+    step = torch.exp2(e - 3)
+    q = torch.round(a / step) * step
+    return (torch.sign(v) * q.clamp_max(448.0) * sc).reshape(r, K)
+
+
+def gelu_new(v):
+    return 0.5 * v * (1.0 + torch.tanh(0.7978845608028654 * (v + 0.044715 * v * v * v)))
+
+
+MODES = ("x3", "mx8", "mx8w", "dropw", "dropa", "x1")
+STAGES = {"llm": ("llm",), "swin": ("swin",), "pixel_decoder": ("pixel_decoder",), "predictor": ("predictor",), "projector": ("projector",)}
+
+
+def main():
+    nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    emu = os.environ.get("PSALM_EXP_EMU") == "1"          # dry run of this script on the host emulator (tiny model, no GPU)
+    cfg = PsalmConfig.tiny("panoptic") if emu else PsalmConfig(seg_task="panoptic")
+    if emu:
+        sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu")]
+        from ops_backend import make_ops
+    for seed in range(nseeds):
+        sd = make_state_dict(cfg, seed=seed)
+        inputs = make_inputs(cfg, "panoptic", size=size, batch=1, seed=seed)
+        if emu:
+            model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
+        else:
+            inputs["images"] = inputs["images"].cuda()
+            model = PSALM(cfg, sd, precision="fp32")
+        del sd
+        ref = clone(model.eval_seg(**inputs)[0])
+        ops = model.ops
+        orig = ops.gemm
+        state = {"stage": None, "on": (), "mode": "x3", "n": 0}
+        wkeys = {(t.data_ptr(), tuple(t.shape)) for t in model.w.values() if torch.is_tensor(t) and t.dim() == 2}
+        wcache = {}
+
+        def prep_w(w, mode):
+            key = (w.data_ptr(), tuple(w.shape), mode)
+            if key in wcache:
+                return wcache[key]
+            hi, lo, inv = split(w)
+            ent = {"hi": hi, "inv": inv}
+            if mode in ("x3", "dropa"):
+                ent["lo"] = lo
+            if mode in ("mx8", "mx8w"):
+                ent["qlo"] = q_mx8(lo)
+            if mode == "mx8":
+                ent["qhi"] = q_mx8(hi)
+            if (w.data_ptr(), tuple(w.shape)) in wkeys:
+                wcache[key] = ent
+            return ent
+
+        def gemm_q(a, w, bias=None, residual=None, act=H.ACT_NONE, act_col_start=0, out=None, out_dtype=None):
+            K = a.shape[1]
+            if not (state["stage"] in state["on"] and torch.is_tensor(w) and w.dtype == torch.float32 and a.dtype == torch.float32
+                    and K % 32 == 0 and (a.shape[0] > 192 or emu)):
+                return orig(a, w, bias, residual, act, act_col_start, out, out_dtype)
+            state["n"] += 1
+            mode = state["mode"]
+            ah, al, ainv = split(a)
+            W = prep_w(w, mode)
+            acc = ah @ W["hi"].t()
+            if mode in ("x3", "dropw", "mx8w"):
+                acc += al @ W["hi"].t()
+            if mode in ("x3", "dropa"):
+                acc += ah @ W["lo"].t()
+            if mode == "mx8":
+                acc += q_mx8(al) @ W["qhi"].t()
+            if mode in ("mx8", "mx8w"):
+                acc += q_mx8(ah) @ W["qlo"].t()
+            v = acc * ainv * W["inv"].t()
+            if bias is not None:
+                v = v + bias
+            a_ = act & 15
+            if a_ != H.ACT_NONE:
+                f = {H.ACT_RELU: torch.relu, H.ACT_GELU: lambda t: torch.nn.functional.gelu(t), H.ACT_GELU_NEW: gelu_new}[a_]
+                post = bool(act & H.ACT_POST_RESIDUAL)
+                if post and residual is not None:
+                    v = v + residual
+                v[:, act_col_start:] = f(v[:, act_col_start:])
+                if not post and residual is not None:
+                    v = v + residual
+            elif residual is not None:
+                v = v + residual
+            if out is not None:
+                out.copy_(v)
+                return out
+            return v.to(out_dtype or torch.float32)
+
+        def tag(name):
+            fn = getattr(model, name)
+
+            def wrapped(*a, **k):
+                prev, state["stage"] = state["stage"], name
+                try:
+                    return fn(*a, **k)
+                finally:
+                    state["stage"] = prev
+            setattr(model, name, wrapped)
+        for names in STAGES.values():
+            for n in names:
+                tag(n)
+        ops.gemm = gemm_q
+        runs = [("llm", m) for m in MODES] + [("swin", "mx8"), ("pixel_decoder", "mx8"), ("predictor", "mx8"),
+                                              ("llm+swin+pixel_decoder+predictor+projector", "mx8"), ("llm+swin+pixel_decoder+predictor+projector", "x3")]
+        for s, mode in runs:
+            on = sum((STAGES[x] for x in s.split("+")), ())
+            state.update(on=on, mode=mode, n=0)
+            wcache.clear()
+            got = clone(model.eval_seg(**inputs)[0])
+            if not emu:
+                torch.cuda.synchronize()
+            r = metrics(got, ref)
+            print(json.dumps({"seed": seed, "stage": s if "+" not in s else "all", "mode": mode, "gemms": state["n"],
+                              **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()}}), flush=True)
+        ops.gemm = orig
+        del model, wcache
+        if not emu:
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Experiment (not product): block-level time line of the direct-to-LDS GEMM kernel on the GEMM shapes of the f16x3 image.
+
+A SEPARATE copy of the library is built with -DPSALM_GEMM_TIMELINE (psalm_amd/csrc/gemm.hip: PSALM_TL stamps s_memrealtime, 100 MHz, by thread
+0 of every block at: 0 entry, 1 prologue copies issued, 2 first K tile visible, 3 K loop done, 4 tile transposed into LDS, 5 stores drained).
+
+    python tools/experiments/gemm_timeline.py --build          (authoring container: hipcc cross-compile -> tools/experiments/_build/)
+    python tools/experiments/gemm_timeline.py [out.json]       (GPU box)
+
+Per shape and tile policy: the launch's wall time from events, the span first-entry -> last-stamp, and the median / p90 over blocks of each
+phase -- i.e. whether a launch is prologue- (cold operands), K-loop- (copy latency per step) or epilogue- (store tail) bound, and how far the
+block starts are spread."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tools", "experiments", "_build")
+LIB = os.path.join(OUT, "libpsalm_hip_tl.so")
+
+
+def build():
+    from psalm_amd import build as B
+    B.build()                                            # product objects (everything except gemm.o is reused)
+    os.makedirs(OUT, exist_ok=True)
+    obj = os.path.join(OUT, "gemm_tl.o")
+    src = os.path.join(B.CSRC, "gemm.hip")
+    if not os.path.exists(obj) or os.path.getmtime(src) > os.path.getmtime(obj):
+        subprocess.check_call([B.HIPCC] + B.FLAGS + ["-DPSALM_GEMM_TIMELINE", "-c", src, "-o", obj])
+    objs = [o for o in glob.glob(os.path.join(B.LIBDIR, "obj", "*.o")) if os.path.basename(o) != "gemm.o"] + [obj]
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    print(LIB)
+
+
+SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512, 2048), (5184, 1536, 512), (5184, 512, 512),
+          (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256), (65536, 512, 128), (100, 65536, 256)]
+POLICIES = [("auto", [0]), ("t128", [128]), ("t64", [64]), ("t64_ring3", [64, 643]), ("t256", [256])]
+
+
+def main():
+    import ctypes
+    import torch
+    from psalm_amd import hip_ops as H
+    ops = H.Ops(LIB)
+    nslot = 1 << 16
+    tl = torch.zeros(nslot * 8, dtype=torch.int64, device="cuda")
+    assert ops._cdll_raw.psalm_gemm_timeline_buffer(ctypes.c_void_p(tl.data_ptr())) == 0
+    out = {}
+    for M, N, K in SHAPES:
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda")
+        asp, wsp = ops.split_f16(a), ops.split_f16(w)
+        c = torch.empty(M, N, device="cuda")
+        big = torch.empty(64 << 20, device="cuda")        # 256 MB: evicts the operands from the Infinity Cache between cold launches
+        row = {}
+        for name, pol in POLICIES:
+            for p in pol:
+                ops.gemm_tile_policy(p)
+            try:
+                desc = ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)
+                res = {}
+                for mode in ("warm", "cold"):
+                    for _ in range(2):
+                        ops.gemm_x3(asp, wsp, out=c)
+                    if mode == "cold":
+                        big.fill_(1.0)
+                    tl.zero_()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.gemm_x3(asp, wsp, out=c)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t = tl.view(nslot, 8).cpu()
+                    t = t[t[:, 0] > 0][:, :6].double()
+                    if desc[3] > 1:                          # split-K: the reduce kernel is outside the stamped kernel
+                        pass
+                    t0 = t[:, 0].min()
+                    us = (t - t0) / 100.0                     # 100 MHz -> us
+                    ph = us[:, 1:] - us[:, :-1]
+
+                    def q(v, f):
+                        return round(float(v.quantile(f)), 2)
+                    res[mode] = {"event_us": round(e0.elapsed_time(e1) * 1e3, 1), "blocks": int(t.shape[0]),
+                                 "span_us": round(float(us[:, 5].max()), 2),
+                                 "start_p50_p90_max": [q(us[:, 0], .5), q(us[:, 0], .9), round(float(us[:, 0].max()), 2)],
+                                 "end_p10_p50": [q(us[:, 5], .1), q(us[:, 5], .5)],
+                                 "phase_p50": {n_: q(ph[:, i], .5) for i, n_ in enumerate(("setup+issue", "first_tile", "k_loop", "to_lds", "store"))},
+                                 "phase_p90": {n_: q(ph[:, i], .9) for i, n_ in enumerate(("setup+issue", "first_tile", "k_loop", "to_lds", "store"))},
+                                 "block_total_p50": q(us[:, 5] - us[:, 0], .5)}
+                row[name] = {"describe": list(desc), **res}
+            except Exception as ex:  # noqa
+                row[name] = {"error": str(ex)[:100]}
+            finally:
+                for p in (1282, 640, 3300, 0):
+                    ops.gemm_tile_policy(p)
+        out[f"M{M} N{N} K{K}"] = row
+        print(M, N, K, json.dumps(row), flush=True)
+        del a, w, asp, wsp, c, big
+    if len(sys.argv) > 1:
+        json.dump(out, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+    else:
+        main()
