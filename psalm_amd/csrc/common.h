@@ -126,6 +126,27 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
 
+// Bounds-checked 4-byte accesses through a buffer descriptor (buffer_store_dword / buffer_load_dword ... offen): an access at a byte offset
+// >= the descriptor's size is DROPPED (store) or returns 0 (load) by the hardware -- epilogues write their ragged last row / column tiles
+// without a branch per element.  `bytes` <= 0x7fffffff; PSALM_BUF_OOB is the offset that marks a lane as out of range (instruction-level
+// immediate offsets added to it must not wrap).
+#define PSALM_BUF_OOB 0x80000000u
+#ifdef PSALM_EMU_BUILD
+struct psalm_rsrc { char* base; unsigned bytes; };
+__device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) { return psalm_rsrc{(char*)p, bytes}; }
+__device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<float*>(r.base + off) = v; }
+__device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) { return (off < r.bytes && r.bytes - off >= 4u) ? *reinterpret_cast<const float*>(r.base + off) : 0.f; }
+#else
+typedef __amdgpu_buffer_rsrc_t psalm_rsrc;
+__device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer (stride 0), 32-bit data format
+}
+__device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
+__device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+#endif
+
 // ----------------------------------------------------------------------------- host side
 extern "C" void psalm_set_error(const char* msg);
 

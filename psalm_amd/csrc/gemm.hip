@@ -678,9 +678,82 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     }
     }
     PSALM_TL(3);
+    // ---- fp32 output (C, or a split-K slab): straight from the accumulators.  In the accumulator layout a lane owns ONE column and 16 rows of
+    // a 32 x 32 tile, so a 4-byte store instruction of the wave writes two full 128-byte row segments -- as fast as 16-byte row-contiguous
+    // stores on this chip (tools/experiments/store_pattern.hip, r03b: 5.6 TB/s for the 224 tiles of Phi [k|v|q|fc1], 5.7 contiguous, 4.5 for
+    // the 16-byte stores 32 bytes apart of the LDS path below) -- with no transpose pass, no barrier and no idle wave row.  r03a time line:
+    // the LDS epilogue was 34 of 182 us of that launch and 21 of 52 us of M4096 N2048 K512.  Ragged edges: rows >= M / columns >= N are
+    // dropped by the buffer descriptor's bounds check (no branch per element).  Split-f16 OUTPUT tiles (2-byte elements) keep the LDS path.
+    if constexpr (std::is_same<TC, float>::value) {
+        const bool split = fa.slab != nullptr;
+        const int act = g.act & 15;
+        // (erf / tanh activations stay on the LDS path: its store loop is rolled, here every element would get its own inlined copy)
+        bool lds_path = !split && act != ACT_NONE && act != ACT_RELU && bn + BN > g.act_col_start;
+        if constexpr (SO) lds_path = lds_path || (fa.so != nullptr && bn + BN > fa.so_col_start);
+        if (!lds_path) {
+            const bool post = (g.act & ACT_POST_RESIDUAL) != 0, brow = (g.act & ACT_BIAS_ROW) != 0;
+            float* Cb = split ? fa.slab + (long)blockIdx.y * g.M * g.N : (float*)g.C;
+            const long ldo = split ? (long)g.N : g.ldc;
+            const int rows_here = min(g.M - bm, BM);
+            const psalm_rsrc rc = psalm_make_rsrc(Cb + (long)bm * ldo, (unsigned)min((long)rows_here * ldo * 4, 0x7ffff000L));
+            const float* R = split ? nullptr : (const float*)g.res;
+            const psalm_rsrc rr = psalm_make_rsrc(R ? R + (long)bm * g.ldr : Cb, R ? (unsigned)min((long)rows_here * g.ldr * 4, 0x7ffff000L) : 0u);
+            float wsc[TN], bias_c[TN];
+            unsigned coff[TN];
+            bool actc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = bn + wn * (BN / WN) + j * 32 + n32;
+                const bool ok = col < g.N;
+                coff[j] = ok ? (unsigned)col * 4u : PSALM_BUF_OOB;
+                wsc[j] = 1.f;
+                if constexpr (FP8 || X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
+                bias_c[j] = (!split && !brow && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
+                actc[j] = !split && act != ACT_NONE && col >= g.act_col_start;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lrow0 = wm * (BM / WM) + i * 32 + 4 * hi;          // tile-local row of accumulator element r = 0
+                float asc[16], rb[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int grow = min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    asc[r] = 1.f;
+                    if constexpr (FP8 || X3) asc[r] = fa.a_scale[grow];
+                    rb[r] = (!split && brow && g.bias) ? g.bias[grow] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float rv[16];
+                    if (R) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            rv[r] = psalm_buf_load_f32(rr, (unsigned)((long)(lrow0 + (r & 3) + 8 * (r >> 2)) * g.ldr * 4) + coff[j]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float x = acc[i][j][r];
+                        if constexpr (FP8 || X3) x *= asc[r] * wsc[j];
+                        x += bias_c[j] + rb[r];
+                        if (actc[j] && !post) x = fmaxf(x, 0.f);                 // ReLU (the only activation on this path)
+                        x += rv[r];
+                        if (actc[j] && post) x = fmaxf(x, 0.f);
+                        psalm_buf_store_f32(x, rc, (unsigned)((long)(lrow0 + (r & 3) + 8 * (r >> 2)) * ldo * 4) + coff[j]);
+                    }
+                }
+            }
+            PSALM_TL(4);
+            PSALM_TL_DRAIN();
+            PSALM_TL(5);
+            return;
+        }
+    }
     __syncthreads();                                             // all waves done with the operand ring before it is reused
-    // ---- epilogue through LDS: the accumulator layout (lane = one column, 16 scattered rows) would store 2-4 bytes
-    // per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
+    // ---- epilogue through LDS (bf16 outputs, split-f16 output tiles): the accumulator layout (lane = one column, 16 scattered rows)
+    // would store 2 bytes per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
     // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, BN/8 lanes per row.  Tiles larger than the buffers go
     // in EP passes of BM/EP rows (one wave-row each).
     float* Cs = reinterpret_cast<float*>(&smem[0][0]);
@@ -1881,7 +1954,7 @@ extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scal
 // rows ln_out): the residual-add GEMM + the NEXT block's input LayerNorm of a pre-norm transformer layer (Phi: [dense | fc2] + residual, then
 // input_layernorm of the following layer, modeling_phi.py:263-300).  With split-K (the usual case for this GEMM: few tiles, long K) the
 // partial-sum reduce, epilogue, LayerNorm and split run as ONE row pass; otherwise the LayerNorm is psalm_layernorm_split on C.
-// N % 64 == 0, N <= 8192; split_out rows of 2*N f16 (contiguous), split_inv (M).
+// N % 64 == 0, N <= 2048; split_out rows of 2*N f16 (contiguous), split_inv (M).
 extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                                       const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N,
                                       const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out,

@@ -228,6 +228,9 @@ __global__ void __launch_bounds__(256) msda_forward_kernel(const TV* __restrict_
         for (int l = 0; l < L; ++l) {
             const int Hl = DEV ? (int)shapes_dev[2 * l] : lv.H[l], Wl = DEV ? (int)shapes_dev[2 * l + 1] : lv.W[l];
             const long sl = DEV ? starts_dev[l] : (long)lv.start[l];
+            // device-side level table: never gather outside `value` on a table that does not describe it (a level that does not fit
+            // inside the S rows contributes nothing; the host wrapper reports such a table the first time it sees it)
+            if (DEV && !(Hl > 0 && Wl > 0 && sl >= 0 && sl + (long)Hl * Wl <= (long)S)) continue;
             const TV* vl = vb + sl * row_stride;
 #pragma unroll LP_UNROLL
             for (int p = 0; p < P; ++p) {
@@ -324,8 +327,9 @@ extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int6
 }
 
 // Same op with the level table on the DEVICE (the reference's own calling convention: spatial_shapes / level_start_index are CUDA
-// int64 tensors, ms_deform_attn.h:25-44): asynchronous, no host copy.  sum(H_l*W_l) == S is the caller's contract (unchecked, as in
-// the reference).
+// int64 tensors, ms_deform_attn.h:25-44): asynchronous, no host copy.  sum(H_l*W_l) == S is the caller's contract; the kernel skips a level
+// whose rows [start, start + H*W) do not lie inside the S rows of `value` (no out-of-bounds gather), and hip_ops.msda_forward_dev validates
+// each distinct table once.
 extern "C" int psalm_msda_forward_dev(const void* value, int value_dtype, const int64_t* spatial_shapes_dev,
                                       const int64_t* level_start_dev, const float* sampling_loc, const float* attn_weight, void* out,
                                       int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream) {

@@ -66,8 +66,9 @@ def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple
 
 
 def reduce_metrics(values: torch.Tensor) -> torch.Tensor:
-    """SUM all-reduce of a small fp32 vector, e.g. [intersection, union, count] -- the role of AverageMeter.all_reduce in
-    the reference's eval scripts (psalm/eval/referring_segmentation.py:58-79)."""
+    """SUM all-reduce of a small vector (float32 / float64, on the device the process group's backend reduces on), e.g.
+    [intersection, union, count] -- the role of AverageMeter.all_reduce in the reference's eval scripts
+    (psalm/eval/referring_segmentation.py:58-79)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(values, op=dist.ReduceOp.SUM)
     return values

@@ -8,12 +8,15 @@ against the reference (psalm/eval/panoptic_segmentation.py:14-21,96) runs with n
 
 Only the modules that DEFINE the replaced entry points are overridden (registered in `sys.modules` under the reference's names); every
 other `psalm.*` module -- datasets, collators, evaluators, conversation templates -- is still the reference's own when its package is
-on `sys.path`.  Where the reference package is absent (tests, the GPU box) empty parent packages are synthesised so the import
-statements themselves still work.
+on `sys.path`: the parents `psalm.model` / `psalm.model.language_model` are then registered as shell packages over the reference's
+directories (same `__path__`), because the reference's own `psalm/model/__init__.py:1` imports its CUDA model (and with it flash-attn,
+detectron2 ops, ...) -- which is exactly what the drop-in replaces.  Where the reference package is absent (tests, the GPU box) empty
+parent packages are synthesised so the import statements themselves still work.
 """
 from __future__ import annotations
 
 import importlib.util
+import os
 import sys
 import types
 
@@ -48,6 +51,20 @@ def install() -> None:
         const.CLS_TOKEN_INDEX, const.REGION_TOKEN_INDEX, const.REFER_TOKEN_INDEX = CLS_TOKEN_INDEX, REGION_TOKEN_INDEX, REFER_TOKEN_INDEX
         sys.modules.setdefault("psalm.constants", const)
         sys.modules["psalm"].constants = sys.modules["psalm.constants"]
+    else:
+        import psalm                                           # (the reference's psalm/__init__.py is empty)
+        base = os.path.dirname(os.path.abspath(psalm.__file__))
+        for name in _NAMES[1:]:
+            if name in sys.modules:                            # already imported by the caller: leave it
+                continue
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(base, *name.split(".")[1:])]   # sibling modules (datasets_mapper, mask_decoder, ...) stay importable
+            m.__package__ = name
+            sys.modules[name] = m
+            parent, _, leaf = name.rpartition(".")
+            setattr(sys.modules[parent], leaf, m)
+        if not hasattr(sys.modules["psalm.model"], "PSALM"):
+            sys.modules["psalm.model"].PSALM = model.PSALM  # `from psalm.model import *` (psalm/model/__init__.py:1)
     b = types.ModuleType("psalm.model.builder")               # psalm/model/builder.py
     b.load_pretrained_model = builder.load_pretrained_model
     b.__doc__ = "psalm_amd drop-in for psalm/model/builder.py (see psalm_amd.builder)"

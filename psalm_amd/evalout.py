@@ -28,9 +28,22 @@ def _ops(ops):
     return ops if ops is not None else H.get_ops()
 
 
+def _on_device(o, t: torch.Tensor, dtypes, what: str) -> torch.Tensor:
+    """The kernels read raw pointers: a tensor of another dtype would be misread (or read out of bounds), a host tensor -- the reference's
+    evaluators habitually hold `.cpu()` copies -- would hand the GPU a host address.  Reject the former, move the latter."""
+    if not torch.is_tensor(t) or t.dtype not in dtypes:
+        raise H.PsalmHipError(f"{what}: dtype {getattr(t, 'dtype', type(t))} not supported (expected one of {', '.join(str(d) for d in dtypes)})")
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8)
+    return t.to(o.device).contiguous()
+
+
 def semantic_labels(sem_seg: torch.Tensor, ops=None) -> torch.Tensor:
     """`sem_seg.argmax(dim=0)` for a (C,H,W) float32 class map -> (H,W) int32 (first maximal class on ties, as torch)."""
     o = _ops(ops)
+    if sem_seg.dim() != 3:
+        raise H.PsalmHipError("semantic_labels: (C,H,W) class map")
+    sem_seg = _on_device(o, sem_seg, (torch.float32,), "semantic_labels")
     C, Hh, Ww = sem_seg.shape
     out = o.empty(Hh, Ww, dtype=torch.int32)
     o._check(o.lib.psalm_semantic_labels(o._p(sem_seg), o._p(out), C, c_long(Hh * Ww), o._stream()), "psalm_semantic_labels")
@@ -51,6 +64,7 @@ class ConfusionMatrix:
         gt = gt.to(o.device, torch.int32).contiguous()
         if pred.shape != gt.shape or pred.dtype != torch.int32:
             raise H.PsalmHipError("ConfusionMatrix.update: int32 label maps of equal shape")
+        pred = pred.to(o.device).contiguous()
         o._check(o.lib.psalm_confusion_accumulate(o._p(pred), o._p(gt), c_long(pred.numel()), self.num_classes, self.ignore_label,
                                                   o._p(self.conf), o._stream()), "psalm_confusion_accumulate")
 
@@ -71,7 +85,7 @@ def panoptic_png_rgb(panoptic_ids: torch.Tensor, ops=None) -> torch.Tensor:
     o = _ops(ops)
     Hh, Ww = panoptic_ids.shape
     out = o.empty(Hh, Ww, 3, dtype=torch.uint8)
-    o._check(o.lib.psalm_panoptic_rgb(o._p(panoptic_ids.to(torch.int32).contiguous()), o._p(out), c_long(Hh * Ww), o._stream()), "psalm_panoptic_rgb")
+    o._check(o.lib.psalm_panoptic_rgb(o._p(panoptic_ids.to(o.device, torch.int32).contiguous()), o._p(out), c_long(Hh * Ww), o._stream()), "psalm_panoptic_rgb")
     return out
 
 
@@ -98,11 +112,9 @@ def masks_to_rle(masks: torch.Tensor, ops=None) -> List[dict]:
     """Binary masks (n,H,W) float32 | uint8 (nonzero = foreground) -> COCO RLE dicts, == `mask.encode(np.asfortranarray(m))` of pycocotools.
     The device finds the run boundaries (column-major); only those (4 bytes per run) are copied to the host."""
     o = _ops(ops)
-    if masks.dim() != 3 or masks.dtype not in (torch.float32, torch.uint8, torch.bool):
+    if masks.dim() != 3:
         raise H.PsalmHipError("masks_to_rle: (n,H,W) float32 / uint8 / bool masks")
-    if masks.dtype == torch.bool:
-        masks = masks.view(torch.uint8)
-    masks = masks.contiguous()
+    masks = _on_device(o, masks, (torch.float32, torch.uint8, torch.bool), "masks_to_rle")
     n, Hh, Ww = masks.shape
     if n == 0:
         return []
@@ -130,13 +142,16 @@ def iou_counts(pred_masks: torch.Tensor, gt_masks: torch.Tensor, pairs: Sequence
     pred_masks (n,H,W) float32|uint8 (nonzero = 1), gt_masks (m,H,W) uint8 with 255 = ignore.
     Returns (intersection (P,2), union (P,2), target (P,2)) int64 tensors on the device (classes: background, foreground)."""
     o = _ops(ops)
-    if pred_masks.dtype == torch.bool:
-        pred_masks = pred_masks.view(torch.uint8)
-    pred_masks = pred_masks.contiguous()
+    if pred_masks.dim() != 3 or gt_masks.dim() != 3:
+        raise H.PsalmHipError("iou_counts: (n,H,W) predictions and (m,H,W) targets")
+    pred_masks = _on_device(o, pred_masks, (torch.float32, torch.uint8, torch.bool), "iou_counts")
     gt = gt_masks.to(o.device, torch.uint8).contiguous()
     if tuple(pred_masks.shape[1:]) != tuple(gt.shape[1:]):
         raise H.PsalmHipError("iou_counts: prediction / target size mismatch")
     P = len(pairs)
+    n, m = pred_masks.shape[0], gt.shape[0]
+    if any(not (0 <= int(p) < n and 0 <= int(t) < m) for p, t in pairs):
+        raise H.PsalmHipError(f"iou_counts: pair index out of range (predictions {n}, targets {m})")
     pi = torch.tensor([p for p, _ in pairs], dtype=torch.int32, device=o.device)
     ti = torch.tensor([t for _, t in pairs], dtype=torch.int32, device=o.device)
     counts = torch.zeros(P, 6, dtype=torch.int64, device=o.device)
@@ -165,8 +180,14 @@ class IoUMeters:
         self.sum[6] += i.shape[0]
 
     def all_reduce(self, device=None) -> None:
+        """SUM over ranks in float64 (pixel counts pass 2^24 within a few images).  `device`: where the collective runs; by default the
+        current GPU under the nccl (RCCL) backend -- which reduces device tensors only, as the reference's AverageMeter.all_reduce knows
+        (`.cuda()` first) -- and the host otherwise (gloo)."""
+        import torch.distributed as dist
         from .dist import reduce_metrics
-        t = self.sum.float().to(device) if device is not None else self.sum.float()
+        if device is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = self.sum.to(device) if device is not None else self.sum.clone()
         self.sum = reduce_metrics(t).double().cpu()
 
     def results(self) -> dict:

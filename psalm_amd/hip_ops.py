@@ -116,6 +116,7 @@ class Ops:
         self.device = torch.device("cpu") if self.is_emu else torch.device("cuda", torch.cuda.current_device())
         self.lib_path = lib_path
         self._ws = {}                      # cached kernel workspaces (device buffers owned by this binding)
+        self._msda_tables = set()          # device-side MSDA level tables already validated (msda_forward_dev)
         self.x3 = False                    # True: float32 x float32 GEMMs run in split-f16 arithmetic (precision="f16x3")
 
     # ------------------------------------------------------------------ plumbing
@@ -846,6 +847,18 @@ class Ops:
         for t in (spatial_shapes, level_start):
             if t.dtype != torch.int64 or t.device != value.device:
                 raise PsalmHipError("msda_forward_dev: int64 level tensors on the value's device")
+        if tuple(spatial_shapes.shape) != (L, 2) or level_start.numel() != L:
+            raise PsalmHipError(f"msda_forward_dev: level table shapes {tuple(spatial_shapes.shape)} / {tuple(level_start.shape)} for L = {L}")
+        # each DISTINCT level table is checked against S once (one small D2H copy the first time; keyed by storage + version counter, so
+        # the steady state stays asynchronous); not during stream capture, where the kernel's own bounds guard is the safety net
+        key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start.data_ptr(), level_start._version, S, L)
+        if key not in self._msda_tables and not (value.is_cuda and torch.cuda.is_current_stream_capturing()):
+            hw, st = spatial_shapes.cpu().tolist(), level_start.reshape(-1).cpu().tolist()
+            if any(h <= 0 or w_ <= 0 or s0 < 0 or s0 + h * w_ > S for (h, w_), s0 in zip(hw, st)) or sum(h * w_ for h, w_ in hw) != S:
+                raise PsalmHipError(f"msda_forward_dev: level table {hw} / starts {st} does not describe the {S} rows of value")
+            if len(self._msda_tables) > 64:
+                self._msda_tables.clear()
+            self._msda_tables.add(key)
         out = self.empty(B, Lq, M * D, dtype=out_dtype or value.dtype)
         rc = self.lib.psalm_msda_forward_dev(self._p(value), _dt(value), self._p(spatial_shapes.contiguous()), self._p(level_start.contiguous()),
                                              self._p(loc), self._p(attw), self._p(out), _dt(out), B, S, M, D, L, Lq, P, self._stream())

@@ -559,3 +559,41 @@ def test_gemm_x3_auto_slice_selection_on_gpu():
         ops.gemm_tile_policy(0)
     want = a.double() @ w.double().t()
     assert (auto.double() - want).abs().max() <= 3e-6 * want.abs().max() and (auto - panel).abs().max() <= 3e-6 * want.abs().max()
+
+
+@pytest.mark.parametrize("policy", [256, 128, 64])
+@pytest.mark.parametrize("mode", ["relu_mid_tile", "post_residual", "bias_row", "plain_strided"])
+def test_gemm_x3_direct_epilogue_edges(ops, policy, mode):
+    """The fp32 epilogue that stores straight from the accumulators (buffer-descriptor bounds instead of per-element branches): ragged last
+    row / column tiles, a column-sliced output whose neighbours must stay untouched, ReLU starting inside a tile, ReLU after the residual,
+    per-row bias -- on every tile configuration."""
+    M, N, K = 301, 296, 128                                       # 301 = 256 + 45 rows, 296 = 256 + 40 columns (ragged both ways)
+    g = torch.Generator().manual_seed(policy + len(mode))
+    d = ops.device
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.3
+    bias = torch.randn(M if mode == "bias_row" else N, generator=g)
+    res = torch.randn(M, N, generator=g) if mode in ("post_residual", "relu_mid_tile") else None
+    act, acs = {"relu_mid_tile": (H.ACT_RELU, 72), "post_residual": (H.ACT_RELU | H.ACT_POST_RESIDUAL, 0), "bias_row": (H.ACT_BIAS_ROW, 0),
+                "plain_strided": (H.ACT_NONE, 0)}[mode]
+    big = torch.full((M + 3, N + 24), 7.0, device=d)              # sentinel-filled: rows below M and the columns either side stay 7
+    out = big[:M, 8:8 + N]
+    big_res = None
+    if res is not None:
+        big_res = torch.zeros(M, N + 16, device=d)
+        big_res[:, 4:4 + N] = res.to(d)
+    ops.gemm_tile_policy(policy)
+    try:
+        ops.gemm_x3(a.to(d), w.to(d), bias.to(d), big_res[:, 4:4 + N] if res is not None else None, act, acs, out=out)
+    finally:
+        ops.gemm_tile_policy(0)
+    y = a.double() @ w.double().t()
+    y = y + (bias.double()[:, None] if mode == "bias_row" else bias.double())
+    if mode == "post_residual":
+        y = torch.relu(y + res.double())
+    elif mode == "relu_mid_tile":
+        y = torch.cat([y[:, :acs], torch.relu(y[:, acs:])], 1) + res.double()
+    mag = a.abs().double() @ w.abs().double().t()
+    got = big.cpu().double()
+    assert ((got[:M, 8:8 + N] - y).abs() <= 6 * 2.0 ** -22 * mag + 4e-7 * y.abs() + 1e-6).all()
+    assert (got[M:] == 7).all() and (got[:, :8] == 7).all() and (got[:, 8 + N:] == 7).all()

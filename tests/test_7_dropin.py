@@ -95,3 +95,44 @@ def test_to_rejects_a_device_the_kernels_do_not_run_on():
         m.to(device="cuda")                          # emulator-backed model lives on the host; a product model refuses "cpu" the same way
     with pytest.raises(NotImplementedError):
         m.train()
+
+
+def _run_py(code, env_extra, cwd):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(cwd), root, os.path.join(root, "tests")]), **env_extra)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(cwd), timeout=600)
+
+
+def test_dropin_env_hook_and_reference_present_branch(tmp_path):
+    """(1) PSALM_AMD_DROPIN=1 + `import psalm_amd` installs the drop-in; (2) with a reference `psalm` package importable, the
+    parents are shell packages over the reference's directories: its psalm/model/__init__.py (which imports the CUDA model) never runs,
+    sibling modules still come from the reference, the replaced entry points are ours."""
+    ref = tmp_path / "psalm"
+    (ref / "model" / "language_model").mkdir(parents=True)
+    (ref / "__init__.py").write_text("")
+    (ref / "model" / "__init__.py").write_text("raise ImportError('reference psalm/model/__init__.py executed (would import the CUDA model)')\n")
+    (ref / "model" / "language_model" / "__init__.py").write_text("")
+    (ref / "model" / "language_model" / "llava_phi.py").write_text("raise ImportError('reference llava_phi imported')\n")
+    (ref / "model" / "sibling.py").write_text("X = 41\n")
+    (ref / "constants.py").write_text("IMAGE_TOKEN_INDEX = -200\n")
+    code = (
+        "import psalm_amd, sys\n"
+        "import psalm.model\n"
+        "from psalm.model.sibling import X\n"
+        "from psalm.constants import IMAGE_TOKEN_INDEX\n"
+        "from psalm.model.builder import load_pretrained_model\n"
+        "from psalm.model.language_model.llava_phi import PSALM, LlavaConfig\n"
+        "from psalm.model import PSALM as P2\n"
+        "import psalm_amd.builder, psalm_amd.model\n"
+        "assert load_pretrained_model is psalm_amd.builder.load_pretrained_model and PSALM is psalm_amd.model.PSALM is P2\n"
+        "assert X == 41 and IMAGE_TOKEN_INDEX == -200\n"
+        "print('OK', psalm.model.__path__[0])\n")
+    r = _run_py(code, {"PSALM_AMD_DROPIN": "1"}, tmp_path)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+    assert str(ref / "model") in r.stdout
+    # without the variable nothing is installed: the reference's own (here: raising) package init is what an import finds
+    r = _run_py("import psalm_amd\nimport psalm.model\n", {"PSALM_AMD_DROPIN": "0"}, tmp_path)
+    assert r.returncode != 0 and "reference psalm/model/__init__.py executed" in r.stderr

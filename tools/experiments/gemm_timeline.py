@@ -34,9 +34,12 @@ def build():
     print(LIB)
 
 
-SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512, 2048), (5184, 1536, 512), (5184, 512, 512),
-          (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256), (65536, 512, 128), (100, 65536, 256)]
-POLICIES = [("auto", [0]), ("t128", [128]), ("t64", [64]), ("t64_ring3", [64, 643]), ("t256", [256])]
+# (M, N, K, split-f16 output from column (None: fp32 output), activation)
+SHAPES = [(899, 14336, 2048, None, 0), (899, 14336, 2048, 6144, 3), (899, 2048, 10240, None, 0), (4096, 2048, 512, None, 0),
+          (4096, 2048, 512, 0, 2), (4096, 512, 2048, None, 0), (5184, 1536, 512, None, 0), (5184, 512, 512, None, 0),
+          (21504, 1024, 256, None, 0), (21504, 1024, 256, 0, 1), (21504, 256, 1024, None, 0), (21504, 256, 256, None, 0),
+          (65536, 512, 128, None, 0), (100, 65536, 256, None, 0)]
+POLICIES = [("auto", [0]), ("t128", [128]), ("t64", [64]), ("t256", [256])]
 
 
 def main():
@@ -48,11 +51,23 @@ def main():
     tl = torch.zeros(nslot * 8, dtype=torch.int64, device="cuda")
     assert ops._cdll_raw.psalm_gemm_timeline_buffer(ctypes.c_void_p(tl.data_ptr())) == 0
     out = {}
-    for M, N, K in SHAPES:
+    for M, N, K, so_from, act in SHAPES:
         a = torch.randn(M, K, device="cuda")
-        w = torch.randn(N, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.05
         asp, wsp = ops.split_f16(a), ops.split_f16(w)
         c = torch.empty(M, N, device="cuda")
+        bias = torch.randn(N, device="cuda")
+        if so_from is not None:                              # the model's fused form: columns >= so_from leave as the next GEMM's split-f16 operand
+            kp_out = (N - so_from + 2048 + 63) // 64 * 64
+            so = torch.zeros(M, 2 * kp_out, dtype=torch.float16, device="cuda")
+            so_inv = torch.empty(M, device="cuda")
+            bnd = torch.tensor([2.0 ** 14 * float(w.abs().sum(1).max()), float(bias.abs().max()), 0.0, 0.0], device="cuda")
+
+            def launch():
+                ops.gemm_x3_split(asp, wsp, bias, act, so, so_inv, bnd, split_col_off=2048, split_col_start=so_from, act_col_start=so_from, out=c)
+        else:
+            def launch():
+                ops.gemm_x3(asp, wsp, out=c)
         big = torch.empty(64 << 20, device="cuda")        # 256 MB: evicts the operands from the Infinity Cache between cold launches
         row = {}
         for name, pol in POLICIES:
@@ -63,14 +78,14 @@ def main():
                 res = {}
                 for mode in ("warm", "cold"):
                     for _ in range(2):
-                        ops.gemm_x3(asp, wsp, out=c)
+                        launch()
                     if mode == "cold":
                         big.fill_(1.0)
                     tl.zero_()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    ops.gemm_x3(asp, wsp, out=c)
+                    launch()
                     e1.record()
                     torch.cuda.synchronize()
                     t = tl.view(nslot, 8).cpu()
@@ -96,8 +111,9 @@ def main():
             finally:
                 for p in (1282, 640, 3300, 0):
                     ops.gemm_tile_policy(p)
-        out[f"M{M} N{N} K{K}"] = row
-        print(M, N, K, json.dumps(row), flush=True)
+        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "")
+        out[key] = row
+        print(key, json.dumps(row), flush=True)
         del a, w, asp, wsp, c, big
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)
