@@ -141,7 +141,9 @@ typedef __amdgpu_buffer_rsrc_t psalm_rsrc;
 __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer (stride 0), 32-bit data format
 }
-__device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
+__device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);   // (the builtin's data operand is an integer: a float argument would be VALUE-converted)
+}
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }

@@ -60,8 +60,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if (act == ACT_GELU_NEW) {
+        // 0.5 v (1 + tanh u) = v / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of the library tanhf (~4x the instructions; the
+        // activation runs once per output element in the epilogue's critical path -- 65536 per 256 x 256 tile).  exp(-2u) = inf for
+        // u << 0 gives v * 0 = -0, the limit; a few ulp from the tanh form, both a few ulp from the exact value.
         const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-        return 0.5f * v * (1.f + tanhf(u));
+        return __fdividef(v, 1.f + __expf(-2.f * u));
     }
     return v;
 }
