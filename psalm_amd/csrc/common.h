@@ -132,11 +132,16 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 // immediate offsets added to it must not wrap).
 #define PSALM_BUF_OOB 0x80000000u
 #ifdef PSALM_EMU_BUILD
+__device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) { return __shfl_xor(v, 1); }   // value of lane ^ 1
 struct psalm_rsrc { char* base; unsigned bytes; };
 __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) { return psalm_rsrc{(char*)p, bytes}; }
 __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<float*>(r.base + off) = v; }
+__device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<unsigned*>(r.base + off) = v; }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) { return (off < r.bytes && r.bytes - off >= 4u) ? *reinterpret_cast<const float*>(r.base + off) : 0.f; }
 #else
+__device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) {                              // DPP quad_perm [1,0,3,2]: no LDS crossbar
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
 typedef __amdgpu_buffer_rsrc_t psalm_rsrc;
 __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // raw buffer (stride 0), 32-bit data format
@@ -144,6 +149,7 @@ __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned by
 __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);   // (the builtin's data operand is an integer: a float argument would be VALUE-converted)
 }
+__device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }

@@ -56,9 +56,32 @@ struct alignas(16) u32x4_s { unsigned x, y, z, w; };
 struct alignas(8) u32x2_s { unsigned x, y; };
 struct alignas(16) f32x4_g { float x, y, z, w; };
 
+// erf to < 1 ulp without the library routine's divergent ranges (the activation runs once per output element in the epilogue's critical
+// path): both range polynomials are evaluated and selected per lane -- |a| > 0.9277: 1 - exp(p(|a|)), else a + a q(a^2)  (the minimax
+// polynomials of N. Juffa's vectorisable erff; checked against scipy.special.erf over [-6, 6]: 3.3e-8 relative in exact arithmetic).
+__device__ __forceinline__ float psalm_erff(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ACT_GELU) return 0.5f * v * (1.f + psalm_erff(v * 0.70710678118654752440f));
     if (act == ACT_GELU_NEW) {
         // 0.5 v (1 + tanh u) = v / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of the library tanhf (~4x the instructions; the
         // activation runs once per output element in the epilogue's critical path -- 65536 per 256 x 256 tile).  exp(-2u) = inf for
@@ -690,11 +713,12 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     if constexpr (std::is_same<TC, float>::value) {
         const bool split = fa.slab != nullptr;
         const int act = g.act & 15;
-        // (erf / tanh activations stay on the LDS path: its store loop is rolled, here every element would get its own inlined copy)
-        bool lds_path = !split && act != ACT_NONE && act != ACT_RELU && bn + BN > g.act_col_start;
+        // (erf / tanh activations stay on the LDS path: its store loop is rolled, here every element would get its own inlined copy; so
+        //  do the few per-ROW-bias GEMMs of the mask decoder: 16 more registers per lane here for a path that small GEMMs take)
+        bool lds_path = !split && ((act != ACT_NONE && act != ACT_RELU && bn + BN > g.act_col_start) || (g.act & ACT_BIAS_ROW) != 0);
         if constexpr (SO) lds_path = lds_path || (fa.so != nullptr && bn + BN > fa.so_col_start);
         if (!lds_path) {
-            const bool post = (g.act & ACT_POST_RESIDUAL) != 0, brow = (g.act & ACT_BIAS_ROW) != 0;
+            const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
             float* Cb = split ? fa.slab + (long)blockIdx.y * g.M * g.N : (float*)g.C;
             const long ldo = split ? (long)g.N : g.ldc;
             const int rows_here = min(g.M - bm, BM);
@@ -711,40 +735,154 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 coff[j] = ok ? (unsigned)col * 4u : PSALM_BUF_OOB;
                 wsc[j] = 1.f;
                 if constexpr (FP8 || X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
-                bias_c[j] = (!split && !brow && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
+                bias_c[j] = (!split && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
                 actc[j] = !split && act != ACT_NONE && col >= g.act_col_start;
             }
+            // Software-pipelined over the TM x TN accumulator tiles: per tile  compute 16 results -> issue the LOADS of the next tile
+            // (residual; row scales at a new m-tile) -> issue this tile's 16 stores.  vmcnt retires in order, so a load issued behind a
+            // tile's stores is only "landed" once those stores have completed -- the first form of this loop waited out a full store
+            // drain per tile (vmcnt(15) in front of every store of a residual GEMM).
+            auto row_off = [&](int i, int r) { return wm * (BM / WM) + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2); };   // tile-local row
+            float asc[16], rv[16];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int lrow0 = wm * (BM / WM) + i * 32 + 4 * hi;          // tile-local row of accumulator element r = 0
-                float asc[16], rb[16];
+            for (int r = 0; r < 16; ++r) {
+                asc[r] = 1.f;
+                if constexpr (FP8 || X3) asc[r] = fa.a_scale[min(bm + row_off(0, r), g.M - 1)];
+                rv[r] = R ? psalm_buf_load_f32(rr, (unsigned)((long)row_off(0, r) * g.ldr * 4) + coff[0]) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < TM * TN; ++t) {
+                const int i = t / TN, j = t % TN, i2 = (t + 1) / TN, j2 = (t + 1) % TN;
+                float x[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int grow = min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
-                    asc[r] = 1.f;
-                    if constexpr (FP8 || X3) asc[r] = fa.a_scale[grow];
-                    rb[r] = (!split && brow && g.bias) ? g.bias[grow] : 0.f;
+                    x[r] = acc[i][j][r];
+                    if constexpr (FP8 || X3) x[r] *= asc[r] * wsc[j];
+                    x[r] += bias_c[j];
+                    if (actc[j] && !post) x[r] = fmaxf(x[r], 0.f);           // ReLU (the only activation on this path)
+                    x[r] += rv[r];
+                    if (actc[j] && post) x[r] = fmaxf(x[r], 0.f);
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float rv[16];
-                    if (R) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            rv[r] = psalm_buf_load_f32(rr, (unsigned)((long)(lrow0 + (r & 3) + 8 * (r >> 2)) * g.ldr * 4) + coff[j]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-                    }
+                if (t + 1 < TM * TN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float x = acc[i][j][r];
-                        if constexpr (FP8 || X3) x *= asc[r] * wsc[j];
-                        x += bias_c[j] + rb[r];
-                        if (actc[j] && !post) x = fmaxf(x, 0.f);                 // ReLU (the only activation on this path)
-                        x += rv[r];
-                        if (actc[j] && post) x = fmaxf(x, 0.f);
-                        psalm_buf_store_f32(x, rc, (unsigned)((long)(lrow0 + (r & 3) + 8 * (r >> 2)) * ldo * 4) + coff[j]);
+                        if constexpr (FP8 || X3) { if (j2 == 0) asc[r] = fa.a_scale[min(bm + row_off(i2, r), g.M - 1)]; }
+                        if (R) rv[r] = psalm_buf_load_f32(rr, (unsigned)((long)row_off(i2, r) * g.ldr * 4) + coff[j2]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psalm_buf_store_f32(x[r], rc, (unsigned)((long)row_off(i, r) * ldo * 4) + coff[j]);
+            }
+            PSALM_TL(4);
+            PSALM_TL_DRAIN();
+            PSALM_TL(5);
+            return;
+        }
+    }
+    __syncthreads();                                             // all waves done with the operand ring before it is reused
+    // ---- split-f16 OUTPUT tiles: all arithmetic (scales, bias, activation, the hi / lo split) in the ACCUMULATOR layout -- 16 x TM x TN
+    // independent elements per lane, every wave busy, no loads in the way -- each element leaves as ONE packed word [hi | lo] for the LDS
+    // transpose, and the row-major pass only unzips 8 words into the two 16-byte operand vectors and stores them.  Time line (r03c-e,
+    // store phase of a 256 x 256 gelu_new / 128 x 128 erf-gelu / 64 x 128 relu tile): arithmetic inside the row-major store loop, one
+    // wave row idle per pass: 25 / 20 / 8 us; this form: 26 / 13 / 4.5 us; stores straight from the accumulators with adjacent lanes
+    // trading elements by DPP (4-byte stores, 64-byte row segments): 32 / 15 / 5.4 us -- measured and dropped: the 2-byte elements make
+    // every store instruction touch twice the cache lines of the fp32 tile's.  Tiles larger than the LDS go in two passes of m-tiles
+    // {2e, 2e+1} of BOTH wave rows (LDS row band b = wave row).
+    if constexpr (SO) {
+        if (fa.so != nullptr && bn + BN > fa.so_col_start) {
+            constexpr int EPS = (BM * BN * 4 > SMEM_BYTES) ? 2 : 1;   // passes
+            static_assert(TM % EPS == 0 && BM / EPS * BN * 4 <= SMEM_BYTES, "split-output epilogue: pass geometry");
+            constexpr int TMP = TM / EPS, ROWS_P = BM / EPS, BAND = ROWS_P / WM;   // m-tiles per wave / rows / rows per wave row, per pass
+            constexpr int TPR = BN / 8, RPI = NT / TPR, NIT = ROWS_P / RPI;
+            unsigned* Cw = reinterpret_cast<unsigned*>(&smem[0][0]);
+            const int act = g.act & 15;
+            float gmax = 0.f;
+            if (fa.so_global) {
+                for (int r0 = 0; r0 < g.M; r0 += 512) {              // max over ALL rows of a_scale: 8 independent loads per lane in flight
+                    float t8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t8[k] = fa.a_scale[min(r0 + 64 * k + lane, g.M - 1)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gmax = fmaxf(gmax, t8[k]);
+                }
+                gmax = wave_max(gmax);
+            }
+            const float p0 = fa.so_par[0], p1 = fa.so_par[1];
+            const float floor_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax * fa.so_par[2] + fa.so_par[3])));
+            float wsc[TN], bias_c[TN];
+            bool actc[TN], soc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = bn + wn * (BN / WN) + j * 32 + n32, cc = min(col, g.N - 1);
+                wsc[j] = fa.w_scale[cc];
+                bias_c[j] = g.bias ? g.bias[cc] : 0.f;
+                actc[j] = act != ACT_NONE && col >= g.act_col_start;
+                soc[j] = col >= fa.so_col_start;
+            }
+            const int c8 = (tid % TPR) * 8, col0 = bn + c8;
+            float* C = (float*)g.C;
+#pragma unroll                                                     // (unrolled: acc[e * TMP + ii] must be a compile-time register choice)
+            for (int e = 0; e < EPS; ++e) {
+                if (e > 0) __syncthreads();                           // previous pass read out
+#pragma unroll
+                for (int ii = 0; ii < TMP; ++ii) {
+                    const int i = e * TMP + ii;
+                    const int lrow0 = wm * (BM / WM) + i * 32 + 4 * hi;          // tile-local row of accumulator element r = 0
+                    const int prow0 = wm * BAND + ii * 32 + 4 * hi;              // its row in this pass's LDS image
+                    float asc[16], sc[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        asc[r] = fa.a_scale[min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1)];
+                        float inv_;
+                        split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float x = acc[i][j][r] * (asc[r] * wsc[j]) + bias_c[j];
+                            if (actc[j]) x = apply_act(x, act);
+                            unsigned word = __builtin_bit_cast(unsigned, x);
+                            if (soc[j]) {
+                                const float y = x * sc[r];
+                                const _Float16 h = (_Float16)y, l = (_Float16)(y - (float)h);
+                                word = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                            }
+                            Cw[(prow0 + (r & 3) + 8 * (r >> 2)) * BN + wn * (BN / WN) + j * 32 + n32] = word;
+                        }
+                }
+                __syncthreads();
+                if (col0 >= g.N) continue;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int rl = it * RPI + tid / TPR;                          // row of the LDS image -> row of the tile
+                    const int row = bm + (rl / BAND) * (BM / WM) + e * BAND + rl % BAND;
+                    const u32x4_s w0 = *reinterpret_cast<const u32x4_s*>(&Cw[rl * BN + c8]);
+                    const u32x4_s w1 = *reinterpret_cast<const u32x4_s*>(&Cw[rl * BN + c8 + 4]);
+                    if (row >= g.M) continue;
+                    if (col0 >= fa.so_col_start) {
+                        const u32x4_s hv{(w0.x & 0xffffu) | (w0.y << 16), (w0.z & 0xffffu) | (w0.w << 16), (w1.x & 0xffffu) | (w1.y << 16),
+                                         (w1.z & 0xffffu) | (w1.w << 16)};
+                        const u32x4_s lv{(w0.x >> 16) | (w0.y & 0xffff0000u), (w0.z >> 16) | (w0.w & 0xffff0000u),
+                                         (w1.x >> 16) | (w1.y & 0xffff0000u), (w1.z >> 16) | (w1.w & 0xffff0000u)};
+                        unsigned short* d = fa.so + (long)row * fa.ldso + fa.so_col_off + (col0 - fa.so_col_start);
+                        *reinterpret_cast<u32x4_s*>(d) = hv;
+                        *reinterpret_cast<u32x4_s*>(d + fa.so_kp) = lv;
+                        if (col0 == fa.so_col_start) {
+                            float sc_, inv_;
+                            split_scale_from_bound(fmaxf(fa.a_scale[row] * p0 + p1, floor_), sc_, inv_);
+                            fa.so_inv[row] = inv_;
+                        }
+                    } else {                                                       // fp32 columns of a tile that straddles so_col_start
+                        float* dst = C + (long)row * g.ldc + col0;
+                        const float v[8] = {__builtin_bit_cast(float, w0.x), __builtin_bit_cast(float, w0.y), __builtin_bit_cast(float, w0.z),
+                                            __builtin_bit_cast(float, w0.w), __builtin_bit_cast(float, w1.x), __builtin_bit_cast(float, w1.y),
+                                            __builtin_bit_cast(float, w1.z), __builtin_bit_cast(float, w1.w)};
+                        if (fa.vec_store) store8(dst, v);
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) if (col0 + c < g.N) dst[c] = v[c];
+                        }
                     }
                 }
             }
@@ -754,8 +892,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             return;
         }
     }
-    __syncthreads();                                             // all waves done with the operand ring before it is reused
-    // ---- epilogue through LDS (bf16 outputs, split-f16 output tiles): the accumulator layout (lane = one column, 16 scattered rows)
+    // ---- epilogue through LDS (bf16 outputs, erf / tanh activations on fp32 outputs): the accumulator layout (lane = one column, 16 scattered rows)
     // would store 2 bytes per lane; the tile is instead transposed through the (now idle) operand buffers and written as whole rows,
     // 8 consecutive columns (16 B bf16 / 32 B fp32) per lane, BN/8 lanes per row.  Tiles larger than the buffers go
     // in EP passes of BM/EP rows (one wave-row each).
@@ -775,14 +912,26 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     TC* C = (TC*)g.C;
     const TC* R = (const TC*)g.res;
     float* P = split ? fa.slab + (long)blockIdx.y * g.M * g.N : nullptr;
-    float so_floor = 0.f;                                         // split-f16 output: the row-independent term of the magnitude bound
+    // split-f16 output: the row-independent term of the magnitude bound and the two row-term parameters, in registers before the store loop
+    // (inside it every read of so_par was a fresh global load behind the loop's own stores -- the compiler cannot prove they do not alias --
+    // and the maximum over all rows of a_scale a chain of M / 64 dependent loads per wave: r03c time line, 23 us of store phase on the
+    // Phi [k|v|q|fc1] tiles against 10 us for the plain fp32 tiles of the same launch)
+    float so_floor = 0.f, so_p0 = 0.f, so_p1 = 0.f;
     if constexpr (SO) {
         if (fa.so != nullptr && bn + BN > fa.so_col_start) {
             float gmax = 0.f;
             if (fa.so_global) {
-                for (int r = lane; r < g.M; r += 64) gmax = fmaxf(gmax, fa.a_scale[r]);
+                for (int r0 = 0; r0 < g.M; r0 += 512) {                  // 8 independent loads per lane in flight
+                    float t8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t8[k] = fa.a_scale[min(r0 + 64 * k + lane, g.M - 1)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) gmax = fmaxf(gmax, t8[k]);
+                }
                 gmax = wave_max(gmax);
             }
+            so_p0 = fa.so_par[0];
+            so_p1 = fa.so_par[1];
             so_floor = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax * fa.so_par[2] + fa.so_par[3])));
         }
     }
@@ -863,7 +1012,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             if constexpr (SO) {
                 if (so_here) {
                     float sc, inv;
-                    split_scale_from_bound(fmaxf(asc[itc] * fa.so_par[0] + fa.so_par[1], so_floor), sc, inv);
+                    split_scale_from_bound(fmaxf(asc[itc] * so_p0 + so_p1, so_floor), sc, inv);
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

@@ -373,6 +373,8 @@ def split_bound_par(w, bias, g1=0.0, g0=0.0):
     (100, 72, 64, H.ACT_NONE, 64, 0, 0, False),            # M <= 128 (this form has no skinny kernel; the fp32 twin is forced onto the same tiles)
     (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True),  # Phi layout: [k | v .. | fc1] -> fc1 columns only, row-independent floor on
     (131, 384, 64, H.ACT_GELU_NEW, 64, 256, 8, True),
+    (300, 520, 128, H.ACT_GELU, 256, 256, 0, True),        # 256 x 256 tiles, two LDS passes (m-tiles of both wave rows per pass), ragged last tiles
+    (300, 264, 192, H.ACT_RELU, 128, 64, 0, False),        # col_start inside a tile: its fp32 columns leave through the same LDS image
 ])
 def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glob):
     """psalm_gemm_x3_split: the columns >= col_start of act(a.w^T + b) leave the GEMM as split-f16 rows [hi | lo] under a per-row power-of-two
@@ -401,7 +403,10 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
         ops.gemm_tile_policy(0)
     so, inv, want = so.cpu(), inv.cpu(), want.cpu()
     if col_start:
-        assert torch.equal(out.cpu()[:, :col_start], want[:, :col_start]) and (out.cpu()[:, col_start:] == 7.0).all()
+        # (bit for bit where whole tiles are fp32; a tile that straddles col_start forms acc * scale + bias in its own order: fp32 round-off)
+        assert torch.allclose(out.cpu()[:, :col_start], want[:, :col_start], rtol=2e-6, atol=1e-6) and (out.cpu()[:, col_start:] == 7.0).all()
+        if col_start % 256 == 0:
+            assert torch.equal(out.cpu()[:, :col_start], want[:, :col_start])
     m, e = torch.frexp(inv)
     assert (m == 0.5).all() and (inv > 0).all()                                      # powers of two
     hi = so[:, col_off:col_off + Ns].float()

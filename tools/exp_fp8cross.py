@@ -9,6 +9,9 @@ this is a kernel yet) on the GEMMs of ONE stage, every other stage exact fp32, a
   mx8       hi.hi + q(lo).q(hi) + q(hi).q(lo)          q = OCP MX e4m3 (block scale per 32 k): both cross terms at 2x the f16 MFMA rate
                                                         -> 2 "f16 product equivalents" instead of 3
   mx8w      hi.hi + lo.hi + q(hi).q(lo_w)              only the W-lo term in MX e4m3 (2.5 equivalents)
+  fx8       hi.hi + e(lo 2^6).e(hi 2^-6) + e(hi 2^-6).e(lo 2^6)   e = plain e4m3 with FIXED exponent offsets on top of the existing per-row scales
+                                                        (|hi| < 2^14 -> < 256, |lo| <= 4 -> <= 256; the offsets cancel in the product): no block scales to
+                                                        compute, store or load -- the scaled MFMA's scale operands are the constant 1
   dropw     hi.hi + lo.hi                              A 22 bit x W 11 bit (2 products)
   dropa     hi.hi + hi.lo                              A 11 bit x W 22 bit (2 products)
   x1        hi.hi                                      (1 product)
@@ -57,11 +60,20 @@ def q_mx8(x):
     return (torch.sign(v) * q.clamp_max(448.0) * sc).reshape(r, K)
 
 
+def q_e4m3(v):
+    """plain OCP e4m3 rounding (nearest even, 3 mantissa bits, subnormal step 2^-9, saturating at 448) -- no block scale"""
+    v = v.clamp(-448.0, 448.0)
+    a = v.abs()
+    _, e2 = torch.frexp(a)
+    step = torch.exp2((e2 - 1).clamp_min(-6).float() - 3)
+    return torch.sign(v) * (torch.round(a / step) * step).clamp_max(448.0)
+
+
 def gelu_new(v):
     return 0.5 * v * (1.0 + torch.tanh(0.7978845608028654 * (v + 0.044715 * v * v * v)))
 
 
-MODES = ("x3", "mx8", "mx8w", "dropw", "dropa", "x1")
+MODES = ("x3", "mx8", "fx8", "mx8w", "dropw", "dropa", "x1")
 STAGES = {"llm": ("llm",), "swin": ("swin",), "pixel_decoder": ("pixel_decoder",), "predictor": ("predictor",), "projector": ("projector",)}
 
 
@@ -73,15 +85,21 @@ def main():
     if emu:
         sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu")]
         from ops_backend import make_ops
-    for seed in range(nseeds):
-        sd = make_state_dict(cfg, seed=seed)
-        inputs = make_inputs(cfg, "panoptic", size=size, batch=1, seed=seed)
+    # PSALM_EXP_SEEDS="w:i,w:i,...": (weight seed, input seed) pairs instead of (s, s) for s < nseeds
+    pairs = [tuple(int(x) for x in p.split(":")) for p in os.environ["PSALM_EXP_SEEDS"].split(",")] if os.environ.get("PSALM_EXP_SEEDS") \
+        else [(s_, s_) for s_ in range(nseeds)]
+    sd_seed = None
+    for wseed, iseed in pairs:
+        seed = f"{wseed}:{iseed}"
+        if wseed != sd_seed:
+            sd = make_state_dict(cfg, seed=wseed)
+            sd_seed = wseed
+        inputs = make_inputs(cfg, "panoptic", size=size, batch=1, seed=iseed)
         if emu:
             model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
         else:
             inputs["images"] = inputs["images"].cuda()
             model = PSALM(cfg, sd, precision="fp32")
-        del sd
         ref = clone(model.eval_seg(**inputs)[0])
         ops = model.ops
         orig = ops.gemm
@@ -101,6 +119,8 @@ def main():
                 ent["qlo"] = q_mx8(lo)
             if mode == "mx8":
                 ent["qhi"] = q_mx8(hi)
+            if mode == "fx8":
+                ent["fhi"], ent["flo"] = q_e4m3(hi * 2.0 ** -6), q_e4m3(lo * 2.0 ** 6)
             if (w.data_ptr(), tuple(w.shape)) in wkeys:
                 wcache[key] = ent
             return ent
@@ -123,6 +143,9 @@ def main():
                 acc += q_mx8(al) @ W["qhi"].t()
             if mode in ("mx8", "mx8w"):
                 acc += q_mx8(ah) @ W["qlo"].t()
+            if mode == "fx8":
+                acc += q_e4m3(al * 2.0 ** 6) @ W["fhi"].t()
+                acc += q_e4m3(ah * 2.0 ** -6) @ W["flo"].t()
             v = acc * ainv * W["inv"].t()
             if bias is not None:
                 v = v + bias
@@ -156,8 +179,10 @@ def main():
             for n in names:
                 tag(n)
         ops.gemm = gemm_q
-        runs = [("llm", m) for m in MODES] + [("swin", "mx8"), ("pixel_decoder", "mx8"), ("predictor", "mx8"),
+        runs = [("llm", m) for m in MODES] + [("swin", "mx8"), ("pixel_decoder", "mx8"), ("predictor", "mx8"), ("swin", "fx8"), ("pixel_decoder", "fx8"),
                                               ("llm+swin+pixel_decoder+predictor+projector", "mx8"), ("llm+swin+pixel_decoder+predictor+projector", "x3")]
+        if os.environ.get("PSALM_EXP_ONLY"):
+            runs = [r for r in runs if r[1] in os.environ["PSALM_EXP_ONLY"].split(",")]
         for s, mode in runs:
             on = sum((STAGES[x] for x in s.split("+")), ())
             state.update(on=on, mode=mode, n=0)
