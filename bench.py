@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32", "fp8"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"])
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 side-line measurement (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
@@ -94,6 +94,7 @@ def main():
     cfg = PsalmConfig(seg_task="panoptic")
     sd = make_state_dict(cfg, seed=0)
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
+    model_info = type("I", (), {"llm_x8": bool(getattr(model, "llm_x8", False))})      # (the model object itself is released before the JSON line)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"
@@ -167,18 +168,19 @@ def main():
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
                 geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
             x3 = name in ("psalm_gemm_x3", "psalm_gemm_x3_split", "psalm_gemm_x3_ln_split")
-            if name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):              # split-f16 GEMM: the kernel's K range is 3*Kp
-                geo = (a[12], a[13], 3 * a[6], True, False, ",x3")
+            x8 = x3 and a[7] != 0                                                 # operand form argument (after Kp): e4m3 cross terms, K range 2*Kp
+            if name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):              # split-f16 GEMM: the kernel's K range is 3*Kp (x8: 2*Kp)
+                geo = (a[13], a[14], (2 if x8 else 3) * a[6], True, False, ",x8" if x8 else ",x3")
             elif x3:                                                             # ... with the split-f16 output epilogue (same K loop)
-                geo = (a[10], a[11], 3 * a[6], True, False, ",x3")
+                geo = (a[11], a[12], (2 if x8 else 3) * a[6], True, False, ",x8" if x8 else ",x3")
             if geo is not None:
                 M, N, K, a_bf16, c_bf16, tag = geo
-                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True, x3=x3)
+                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True, x3=x3 and not x8, x8=x8)
                 if x3:
                     K = a[6]                                                      # ALGORITHMIC flops: 2 M N K of the fp32 product it stands for
                 if name == "psalm_gemm_x3_split":                                 # always the tiled kernel, never split-K
                     path, splits = 1, 1
-                    if M <= 128:
+                    if M <= 128 and not x8:
                         BM, BN = 64, 128
                 if path == 2 and name in ("psalm_gemm", "psalm_gemm_x3"):
                     kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}{tag}>"
@@ -250,12 +252,16 @@ def main():
                     tj = json.load(f).get("kernels", {})
                 if kname in tj:
                     traffic = tj[kname].get("hbm_bytes_per_launch")
-            is_x3 = ",x3" in kname
+            is_x3 = ",x3" in kname or ",x8" in kname
+            prods = 2 if ",x8" in kname else 3                                   # f16-product equivalents issued per algorithmic product
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues 3 f16 "
-                             "MFMA products per algorithmic product (hi.hi + lo.hi + hi.lo), see `mfma_issue`") if is_x3 else None,
-                    "mfma_issue": {"TFLOPs": round(3 * ach, 1), "frac_of_f16_peak": round(3 * ach / PEAK_BF16_TFLOPS, 4)} if is_x3 else None,
+                    "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues " +
+                             ("hi.hi on the f16 matrix cores + both cross terms as one e4m3 dot product at twice the f16 rate = 2 f16-product "
+                              "equivalents" if prods == 2 else "3 f16 MFMA products (hi.hi + lo.hi + hi.lo)") +
+                             " per algorithmic product, see `mfma_issue`") if is_x3 else None,
+                    "mfma_issue": {"f16_product_equivalents": prods, "TFLOPs": round(prods * ach, 1),
+                                   "frac_of_f16_peak": round(prods * ach / PEAK_BF16_TFLOPS, 4)} if is_x3 else None,
                     "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
                     "share_of_step_ms": round(ms / nprof, 3), "event_pair_overhead_us": round(ev_over * 1e3, 2),
@@ -326,6 +332,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
+                       "arithmetic": ("GEMMs in split-f16 (22-bit operands as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulate)" +
+                                      ("; Phi decoder GEMMs: hi.hi in f16 + both cross terms as one e4m3 dot product" if getattr(model_info, "llm_x8", False) else "") +
+                                      "; fp32 norms / softmax / attention") if args.precision == "f16x3" else args.precision,
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": side, "weight_broadcast": bcast,

@@ -78,14 +78,6 @@ int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W, int w_dty
                   const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act, int act_col_start,
                   const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, int ln_dtype, long ld_ln, void* workspace,
                   long workspace_bytes, void* stream);
-/* fp8 (OCP e4m3fn) path for the Phi projections of the interactive configuration (BASELINE.json configs[4]).
- * psalm_quantize_rows_fp8: q[m,:] = e4m3(x[m,:] * 448/amax_m), scale[m] = amax_m/448 (software RNE + saturation, identical on
- * device and in the CPU test build).  psalm_gemm_fp8: C = act((Aq.Wq^T) * a_scale[m] * w_scale[n] + bias) + residual on
- * v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; K % 128 == 0; epilogue / split-K / tile selection as psalm_gemm. */
-int psalm_quantize_rows_fp8(const void* x, int x_dtype, long ldx, void* q, long ldq, float* scale, int rows, int K, void* stream);
-int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, const void* Wq, long ldw, const float* w_scale, const float* bias,
-                   const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K, int act, int act_col_start,
-                   void* workspace, long workspace_bytes, void* stream);
 /* Convolution as an implicit GEMM on the direct-to-LDS kernel (no im2col matrix in HBM): x (B,H,W,Cin) bf16 NHWC,
  * Wt (Cout, k*k*Cin) bf16 with K order (ky,kx,c); out / residual (B*Ho*Wo, Cout); Cin % 64 == 0; `zeros` = >= 16 zero bytes
  * on the device (source of the padded taps).  act as psalm_gemm.  Replaces F.conv2d at
@@ -99,8 +91,13 @@ int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* W
  * psalm_split_f16: x (rows,K) f32 -> out (rows, 2*Kp) f16 = [hi | lo], Kp = ceil64(K), x*s = hi + lo with s a per-row power of two
  *   (row max in [2^13,2^14)); inv_scale[row] = 1/s.   K % 8 == 0, 16-byte aligned rows.
  * psalm_gemm_x3: C = act(A.W^T + bias) + residual, C / residual fp32, from split operands A2 (M,2Kp) / W2 (N,2Kp) + their scales:
- *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo, fp32 accumulate, scales in the epilogue; tiles / split-K as psalm_gemm. */
-int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream);
+ *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo, fp32 accumulate, scales in the epilogue; tiles / split-K as psalm_gemm.
+ * "x8" operand form (Phi decoder GEMMs, modeling_phi.py:189-260; `form` / `x8` / `split_form` arguments below): the second half-word of an
+ *   element holds, instead of lo as f16, the pair of OCP e4m3 bytes (e(hi 2^-6), e(lo 2^6)) -- A operands, form 1 -- or (e(lo 2^6),
+ *   e(hi 2^-6)) -- W operands, form 2; Kp = ceil128(K).  With x8 != 0 the GEMM forms hi.hi on the f16 matrix cores and BOTH cross terms as
+ *   one e4m3 dot product over the 2*Kp bytes of the second halves (block-scaled 32x32x64 instruction, unit scales, twice the f16 rate): 2
+ *   instead of 3 f16-product equivalents, result ~2^-16 relative instead of 2^-21 (where that suffices: tools/exp_fp8cross.py). */
+int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, int form, void* stream);
 /* im2col (K order ky,kx,c; as psalm_im2col_nhwc) emitted directly in split form -- the convolution-as-GEMM A operand of the f16x3 mode
  * (F.conv2d at multimodal_projector/builder.py:85-111 and msdeformattn.py:248-254) without the fp32 im2col matrix in HBM. */
 int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
@@ -108,14 +105,14 @@ int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, i
  * msdeformattn.py:57-66): y = LN(x) fp32 (optional) + split(y) (optional) + split(y + add[row % add_rows]) (optional), each split as
  * psalm_split_f16 writes it (rows of 2*ceil64(C) f16 + inv_scale).  fp32 in, C % 8 == 0, C <= 2048. */
 int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C, float eps,
-                          void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, void* stream);
+                          void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, int form, void* stream);
 /* f16x3 forms of the two Swin LayerNorm-fused data-movement steps (swin_trans.py:206-227 norm1 + pad + shift + window partition;
  * :235-251 window reverse + un-shift + residual, then norm2): the normalised rows leave as the split-f16 A operand of the GEMM they feed. */
 int psalm_swin_window_gather_split(const float* x, void* out, float* inv_out, const float* gamma, const float* beta, int B, int H, int W, int C,
                                    int ws, int shift, float eps, void* stream);
 int psalm_swin_window_merge_ln_split(const float* win, const float* shortcut, float* out_x, void* h_split, float* h_inv, const float* gamma,
                                      const float* beta, int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
-int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);
 /* psalm_gemm_x3 whose output columns >= split_col_start leave the kernel already in split form -- the A operand of the NEXT split-f16 GEMM
@@ -131,14 +128,14 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
  * fp32 rows ln_out): the residual GEMM + the following block's input LayerNorm of a pre-norm layer (Phi [dense | fc2] + residual, then the
  * next input_layernorm, modeling_phi.py:263-300).  With split-K the partial-sum reduce, epilogue, LayerNorm and split are ONE row pass.
  * N % 64 == 0, N <= 2048; split_out rows of 2*N f16 as psalm_split_f16 writes them (exact row-maximum scale), split_inv (M). */
-int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                            const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, const float* ln_gamma,
-                           const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out, float* split_inv,
+                           const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out, float* split_inv, int split_form,
                            void* workspace, long workspace_bytes, void* stream);
-int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                         const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out, long ld_split,
-                        int split_kp, int split_col_off, int split_col_start, float* split_inv, const float* bound_par, int global_rows,
-                        void* workspace, long workspace_bytes, void* stream);
+                        int split_kp, int split_col_off, int split_col_start, int split_form, float* split_inv, const float* bound_par,
+                        int global_rows, void* workspace, long workspace_bytes, void* stream);
 
 /* Eval-time image pre-processing on the device: replaces detectron2 `T.ResizeShortestEdge` (= Pillow
  * `Image.resize(BILINEAR)` on uint8) + `T.FixedSizeCrop` + `(image - pixel_mean) / pixel_std` of
@@ -187,7 +184,7 @@ int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, 
  * gets hi at columns split_col_off + head*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the row scales a preceding
  * psalm_gemm_x3_split wrote for the same rows (its bound has to cover |v|: the output is a convex combination of v rows). */
 int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split, int split_kp,
-                                     int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
+                                     int split_col_off, int split_form, const float* split_inv, const float* cos_table, const float* sin_table,
                                      const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
                                      void* stream);
 

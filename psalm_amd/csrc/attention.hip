@@ -637,7 +637,7 @@ template <bool SO>
 __global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(2)
 causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr, const unsigned char* __restrict__ Mk,
                                    const float* __restrict__ base, long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
-                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
+                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair, int so_form) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
@@ -763,11 +763,11 @@ causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __
                 unsigned hw[4], lw[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float a0 = acc[2 * k] * sc, a1 = acc[2 * k + 1] * sc;
-                    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-                    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-                    hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                    lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    unsigned h0, h1, l0, l1;
+                    psalm_split_words(acc[2 * k] * sc, so_form, h0, l0);
+                    psalm_split_words(acc[2 * k + 1] * sc, so_form, h1, l1);
+                    hw[k] = h0 | (h1 << 16);
+                    lw[k] = l0 | (l1 << 16);
                 }
                 unsigned short* d = reinterpret_cast<unsigned short*>(out) + row * ldo + o_off + h * HD + d0;
                 *reinterpret_cast<psalm_u32x4*>(d) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
@@ -790,7 +790,7 @@ extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
 static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k_off, int v_off, void* out, long ldo, int o_off,
                                      const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
                                      int B, int L, int heads, int head_dim, int rot, void* stream, const float* so_inv, int so_kp,
-                                     const char* name) {
+                                     const char* name, int so_form = 0) {
     PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_f32: head_dim 64, rotary dim 32 (Phi-1.5)");
     PSALM_CHECK_ARG(ld % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && (uintptr_t)qkv % 16 == 0 &&
                         (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0 &&
@@ -811,10 +811,10 @@ static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k
     const dim3 grid(pair ? (nqt + 1) / 2 : nqt, heads, B);
     if (so_inv)
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair, so_form);
     else
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair, 0);
     PSALM_LAUNCH_END(name);
 }
 extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
@@ -827,13 +827,14 @@ extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, 
 // stride ld_split f16) receives hi at columns split_col_off + h*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the
 // row scales psalm_gemm_x3_split wrote for the same rows (its bound covers the attention output: a convex combination of v rows).
 extern "C" int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split,
-                                                int split_kp, int split_col_off, const float* split_inv, const float* cos_table,
+                                                int split_kp, int split_col_off, int split_form, const float* split_inv, const float* cos_table,
                                                 const float* sin_table, const unsigned char* key_mask, void* workspace, int B, int L,
                                                 int heads, int head_dim, int rot, void* stream) {
+    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_causal_attention_f32_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand)");
     PSALM_CHECK_ARG(split_out && split_inv && ld_split >= 2L * split_kp && split_col_off + heads * 64 <= split_kp,
                     "psalm_causal_attention_f32_split: split buffer rows of >= 2*split_kp f16 and the row scales");
     return causal_attention_f32_impl(qkv, ld, q_off, k_off, v_off, split_out, ld_split, split_col_off, cos_table, sin_table, key_mask, workspace,
-                                     B, L, heads, head_dim, rot, stream, split_inv, split_kp, "psalm_causal_attention_f32_split");
+                                     B, L, heads, head_dim, rot, stream, split_inv, split_kp, "psalm_causal_attention_f32_split", split_form);
 }
 
 extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,

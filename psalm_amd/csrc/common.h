@@ -126,6 +126,34 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
 
+// ---- split-f16 operand rows, second half-word of an element.  An operand row is [hi (Kp) | second (Kp)] 16-bit words with x s = hi + lo
+// (s: the row's power-of-two scale, |hi| < 2^14, |lo| <= ulp(hi) / 2 <= 4).  The second word is
+//   form 0 ("x3"): lo as f16 -- the GEMM forms hi.hi + lo.hi + hi.lo as three f16 products (22-bit operands);
+//   form 1 / 2 ("x8", A / W operand): the pair of OCP e4m3 bytes (e(hi 2^-6), e(lo 2^6)) for an A operand, (e(lo 2^6), e(hi 2^-6)) for
+//     a W operand: the two CROSS terms lo.hi + hi.lo then are ONE fp8 dot product over the 2 Kp bytes of the second halves (byte i of A
+//     meets byte i of W; the fixed exponent offsets cancel in the products), on the block-scaled fp8 matrix instruction at twice the f16
+//     rate with unit scales -- 2 instead of 3 f16-product equivalents per GEMM.  The cross terms are 2^-11 of the main term, so their
+//     3-bit mantissas leave the result at ~2^-16 relative (tools/exp_fp8cross.py, profiles/r03d_*: on the Phi decoder indistinguishable
+//     from the three-product form over 10 seeds; NOT on the Swin / pixel-decoder GEMMs, which keep form 0).
+#ifdef PSALM_EMU_BUILD
+__device__ __forceinline__ unsigned psalm_pk_e4m3(float a, float b) { return (unsigned)f32_to_e4m3(a) | ((unsigned)f32_to_e4m3(b) << 8); }
+#else
+__device__ __forceinline__ unsigned psalm_pk_e4m3(float a, float b) {                                // v_cvt_pk_fp8_f32 (OCP e4m3 on gfx950, RNE)
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+#endif
+// y = x s (the scaled element): hi word and second word (form as above)
+__device__ __forceinline__ void psalm_split_words(float y, int form, unsigned& hw, unsigned& sw) {
+    const _Float16 h = (_Float16)y;
+    const float lo = y - (float)h;
+    hw = (unsigned)__builtin_bit_cast(unsigned short, h);
+    if (form == 0) sw = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo);
+    else {
+        const float a = (float)h * 0.015625f, b = lo * 64.0f;
+        sw = form == 1 ? psalm_pk_e4m3(a, b) : psalm_pk_e4m3(b, a);
+    }
+}
+
 // Bounds-checked 4-byte accesses through a buffer descriptor (buffer_store_dword / buffer_load_dword ... offen): an access at a byte offset
 // >= the descriptor's size is DROPPED (store) or returns 0 (load) by the hardware -- epilogues write their ragged last row / column tiles
 // without a branch per element.  `bytes` <= 0x7fffffff; PSALM_BUF_OOB is the offset that marks a lane as out of range (instruction-level

@@ -292,7 +292,7 @@ struct GemmFastArgs {
     // k = (ky, kx, c).  Cin % 64 == 0, so one 64-deep K tile lies inside one filter tap and the tap is block-uniform.
     int cH, cW, cC, cK, cS, cP, cHo, cWo;
     const bf16_t* zeros;   // >= 16 bytes of zeros: source of the padded (out-of-image) taps
-    // fp8 (OCP e4m3) operands (FP8 kernels): per-row dequantisation scales of A (M) and W (N); acc * a_scale[m] * w_scale[n]
+    // per-row scales of A (M) and W (N) of the split-f16 forms; acc * a_scale[m] * w_scale[n]
     const float* a_scale;
     const float* w_scale;
     // split-f16 ("X3") operands: A / W rows are [hi (Kp) | lo (Kp)] f16 (psalm_split_f16); the K loop runs over the 3 Kp-long products
@@ -310,6 +310,7 @@ struct GemmFastArgs {
     unsigned short* so = nullptr;
     long ldso = 0;
     int so_kp = 0, so_col_off = 0, so_col_start = 0, so_global = 0;
+    int so_form = 0;    // second half-word of the emitted operand: 0 f16 lo, 1 e4m3 pair of an A operand (psalm_split_words)
     float* so_inv = nullptr;
     const float* so_par = nullptr;
 };
@@ -343,16 +344,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // BK = 64: 128-byte LDS rows, 8 rows per 1 KiB copy, slot p of row r holds k-chunk p ^ ((r >> 1) & 7);
 // BK = 32:  64-byte LDS rows, 16 rows per copy,       slot p of row r holds k-chunk p ^ ((r >> 2) & 3)   (same rule: the
 //           16 rows of a ds_read_b128 lane group must land on 16 distinct 16-byte slots of the 256-byte bank row).
-// FP8 = true: A and W are e4m3 bytes.  The kernel is driven with "bf16 units" (K/2, lda/2, ldw/2): a 64-unit K tile is
-// 128 fp8 = the same 128-byte LDS rows, copies and swizzle as the bf16 kernel; only the fragment reads (8 bytes per lane:
-// 16-byte slot kk, half hi) and the matrix instruction (v_mfma_f32_32x32x16_fp8_fp8, 8 k-steps per tile) differ, and the
-// epilogue applies the per-row dequantisation scales.
 // PH8 = true (256 x 256, 2 x 4 waves, BK 64, 2 buffers): the K loop below is replaced by the 4-phases-per-K-tile schedule
 // described at "PH8 schedule" further down -- the two wave rows run one barrier interval apart, so that on every SIMD one wave
 // is in a pure-MFMA segment while its partner reads fragments / issues copies, and copies stay in flight across barriers.
 // X3 = true: split-f16 operands (see GemmFastArgs::x3_kp): same 16-bit element traffic, copies and swizzle as the bf16 kernel; the K-tile
 // source columns are remapped, the matrix instruction is v_mfma_f32_32x32x16_f16 and the epilogue applies the per-row power-of-two
-// scales of A and W (as the fp8 variant does).  An fp32-class GEMM (22-bit operands, fp32 accumulate) at 1/3 of the f16 MFMA rate.
+// scales of A and W.  An fp32-class GEMM (22-bit operands, fp32 accumulate) at 1/3 of the f16 MFMA rate.
 // X3 = 2 ("slice" form of the split-f16 GEMM, for the tile configurations without the phased loop): instead of walking the 3 Kp-long
 // panel, a K step covers ONE 64-deep slice of the true K range and brings FOUR tiles (A hi, A lo, W hi, W lo) into the stage, from which
 // the three products hi.hi + lo.hi + hi.lo are formed: 4 instead of 6 tile copies per slice, 2/3 of the LDS fragment reads per MFMA, and
@@ -360,12 +357,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // 12..48 K steps) ran their K loops at L2 latency with X3 = 1 (r02k: 100-200 TFLOP/s algorithmic on the 128^2 / 64x128 tiles).
 // SO = true (X3 == 1 only): the epilogue can emit split-f16 output (GemmFastArgs::so; psalm_gemm_x3_split).  A separate instantiation so that
 // the plain kernels' epilogue -- at the register limit on the 256 x 256 tile -- is untouched.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, bool FP8 = false, int PH8 = 0, int X3 = 0,
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8 = 0, int X3 = 0,
           bool SO = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
-    static_assert(!SO || X3 == 1, "split-f16 output: K-panel form of the split-f16 GEMM");
-    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV && !FP8), "PH8 configuration");
-    static_assert(!X3 || (!CONV && !FP8), "split-f16 variants: plain GEMM");
+    static_assert(!SO || X3 == 1 || X3 == 3, "split-f16 output: K-panel / x8 form of the split-f16 GEMM");
+    static_assert(X3 != 3 || (PH8 == 3 && BK == 64), "x8 form: the phased 256 x 256 K loop");
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV), "PH8 configuration");
+    static_assert(!X3 || !CONV, "split-f16 variants: plain GEMM");
     static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
     static_assert(X3 != 2 || (!PH8 && (BK == 64 || BK == 32)), "split-f16 slice form: generic K loop");
     constexpr int XS = X3 == 2 ? 2 : 1;                          // operand images per stage (slice form: hi and lo)
@@ -377,7 +375,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     constexpr int SWS = BK == 128 ? 0 : (BK == 64 ? 1 : 2);      // swizzle: slot ^= (row >> SWS) & (SLOTS - 1)
     static_assert(BK == 128 || BK == 64 || BK == 32, "BK");
     static_assert(!CONV || BK == 64, "implicit-GEMM convolution uses 64-deep K tiles");
-    static_assert(!FP8 || (BK == 64 && !CONV), "fp8 variant: 128-byte rows, plain GEMM");
     constexpr int A_CH = BM / RPC / NW, B_CH = BN / RPC / NW;    // 1 KiB copies per wave per tile
     static_assert(A_CH >= 1 && B_CH >= 1 && TM >= 1 && TN >= 1, "tile / wave configuration");
     constexpr int SMEM_BYTES = NS * (BM + BN) * BK * 2 * XS;  // NS-deep ring of operand tiles
@@ -415,7 +412,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             asrc[i] = A + (long)b * fa.cH * fa.cW * fa.cC + kc * 8;           // + ((y*W + x)*C + c0) per K tile
         } else {
             ay[i] = ax[i] = 0;
-            asrc[i] = A + (long)m * g.lda + (X3 == 1 ? 0 : kbeg) + kc * 8;
+            asrc[i] = A + (long)m * g.lda + ((X3 == 1 || X3 == 3) ? 0 : kbeg) + kc * 8;
         }
     }
     // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
@@ -428,15 +425,17 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int i = 0; i < B_CH; ++i) {
         const int r = b_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
-        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + (X3 == 1 ? 0 : kbeg) + kc * 8;
+        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + ((X3 == 1 || X3 == 3) ? 0 : kbeg) + kc * 8;
     }
     // operand column of the K tile at offset koff of this block's K range (identity except for the split-f16 variant)
     auto x3_acol = [&](int koff) -> int {
         if constexpr (X3 == 1) { const int k = kbeg + koff; return k < 2 * fa.x3_kp ? k : k - 2 * fa.x3_kp; }
+        else if constexpr (X3 == 3) return kbeg + koff;              // x8 form: the row [hi | e4m3 pairs] is walked once, left to right
         else return koff;
     };
     auto x3_wcol = [&](int koff) -> int {
         if constexpr (X3 == 1) { const int k = kbeg + koff; return k < fa.x3_kp ? k : k - fa.x3_kp; }
+        else if constexpr (X3 == 3) return kbeg + koff;
         else return koff;
     };
     auto mma16 = [&](const bf16x8& a_, const bf16x8& b_, const f32x16& c_) -> f32x16 {
@@ -507,19 +506,32 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         //   tile t:  P1 refills B0 of the OTHER buffer with tile t+1 (last read: P4 of tile t-1);  P2 / P3 / P4 refill A0 / B1 / A1
         //   of THIS buffer with tile t+2 (last read: P1 / P2 / P3 of tile t).  Copies never drain inside the loop.
         bf16x8 af[2][BK / 16], bq[BK / 16];
-        auto read_a = [&](const bf16_t* As_, int q) {
+        // x8 form (X3 == 3): the tiles of the second half of the K range hold e4m3 bytes -- same 128-byte rows, copies and swizzle; a
+        // matrix instruction (32x32x64, block-scaled form with unit scales) contracts 64 bytes, of which a lane supplies 32 consecutive
+        // ones: fragment register kk of an fp8 tile is 16-byte chunk 4 (kk >> 1) + 2 hi + (kk & 1) instead of 2 kk + hi, and registers
+        // (2 q2, 2 q2 + 1) together are the operand of instruction q2.  F8 = std::true_type / false_type selects the tile kind.
+        typedef int v8i32 __attribute__((ext_vector_type(8)));
+        auto chunk_of = [&](auto F8, int kk) -> int {
+            if constexpr (decltype(F8)::value) return 4 * (kk >> 1) + 2 * hi + (kk & 1);
+            else return 2 * kk + hi;
+        };
+        auto cat8 = [&](const bf16x8& lo_, const bf16x8& hi_) -> v8i32 {
+            const u32x4_s a_ = __builtin_bit_cast(u32x4_s, lo_), b_ = __builtin_bit_cast(u32x4_s, hi_);
+            return v8i32{(int)a_.x, (int)a_.y, (int)a_.z, (int)a_.w, (int)b_.x, (int)b_.y, (int)b_.z, (int)b_.w};
+        };
+        auto read_a = [&](auto F8, const bf16_t* As_, int q) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                const int co = ((2 * kk + hi) ^ fsw) * 8;
+                const int co = (chunk_of(F8, kk) ^ fsw) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     af[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[(a_row0 + 32 * (2 * q + i)) * BK + co]));
             }
         };
-        auto read_b = [&](const bf16_t* Bs_, int j) {
+        auto read_b = [&](auto F8, const bf16_t* Bs_, int j) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                const int co = ((2 * kk + hi) ^ fsw) * 8;
+                const int co = (chunk_of(F8, kk) ^ fsw) * 8;
                 bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs_[(b_row0 + 32 * j) * BK + co]));
             }
         };
@@ -539,16 +551,29 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // PH8 == 2: the phase's two copies are issued INSIDE the MFMA segment (after the 2nd and the 6th MFMA: the matrix pipe is
         // busy with the MFMA just issued while the copy is accepted), not in the read segment -- r01 PMC: the copies' issue stalls
         // (~80 cycles each behind the other waves' copies) made the read segment ~1.8x the MFMA segment it runs beside.
-        auto mma = [&](int q, int j, auto&& copy) {
+        auto mma = [&](auto F8, int q, int j, auto&& copy) {
+            if constexpr (decltype(F8)::value) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
+                for (int q2 = 0; q2 < 2; ++q2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[2 * q + i][j] = mma16(af[i][kk], bq[kk], acc[2 * q + i][j]);
-                if (PH8 >= 2 && (kk == 0 || kk == 2)) {
+                    for (int i = 0; i < 2; ++i)
+                        acc[2 * q + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(af[i][2 * q2], af[i][2 * q2 + 1]), cat8(bq[2 * q2], bq[2 * q2 + 1]),
+                                                                                            acc[2 * q + i][j], 0, 0, 0, 127, 0, 127);
                     __builtin_amdgcn_sched_barrier(0);
-                    copy(kk >> 1);
+                    copy(q2);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[2 * q + i][j] = mma16(af[i][kk], bq[kk], acc[2 * q + i][j]);
+                    if (PH8 >= 2 && (kk == 0 || kk == 2)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        copy(kk >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         };
@@ -562,35 +587,35 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #define PH8_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); PH8_BAR(); \
                               __builtin_amdgcn_sched_barrier(0); } while (0)
         // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
-        auto tile_phases = [&](int t, int mode) {
+        auto tile_phases = [&](auto F8, int t, int mode) {
             const int cur = t & 1;
             const bf16_t* As_ = smem[cur];
             const bf16_t* Bs_ = smem[cur] + BM * BK;
             constexpr bool early = PH8 == 1;                     // copies in the read segment (1) or inside the MFMA segment (2)
-            read_b(Bs_, 0);                                      // P1
-            read_a(As_, 0);
+            read_b(F8, Bs_, 0);                                  // P1
+            read_a(F8, As_, 0);
             if (early && mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0);
             PH8_ENTER_MFMA();
-            mma(0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
+            mma(F8, 0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
             PH8_LEAVE_MFMA();
-            read_b(Bs_, 1);                                      // P2
+            read_b(F8, Bs_, 1);                                  // P2
             if (early && mode == 0) stage_a(cur, (t + 2) * BK, 0);
             PH8_ENTER_MFMA();
-            mma(0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
+            mma(F8, 0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
             PH8_LEAVE_MFMA();
-            read_a(As_, 1);                                      // P3
+            read_a(F8, As_, 1);                                  // P3
             if (early && mode == 0) stage_b(cur, (t + 2) * BK, 1);
             PH8_ENTER_MFMA();
-            mma(1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
+            mma(F8, 1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
             PH8_LEAVE_MFMA();
-            read_b(Bs_, 0);                                      // P4
+            read_b(F8, Bs_, 0);                                  // P4
             if (early && mode == 0) stage_a(cur, (t + 2) * BK, 1);
             // everything but the most recent halves has landed = all of tile t+1  (PH8 == 1: 3 halves issued since tile t+1's B0;
             // PH8 == 2: 2 -- this phase's copies are issued after the wait)
             if (mode == 0) { if constexpr (early) wait_vmcnt_le<6>(); else wait_vmcnt_le<4>(); }
             else if (mode == 1) wait_vmcnt_le<0>();
             PH8_ENTER_MFMA();
-            mma(1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
+            mma(F8, 1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
             PH8_LEAVE_MFMA();
         };
         stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
@@ -601,10 +626,22 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         PSALM_TL(2);
         if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
         int t = 0;
+        constexpr std::false_type F16T{};
+        constexpr std::true_type FP8T{};
+        if constexpr (X3 == 3) {
+            const int tsw = min(nk, max(0, (fa.x3_kp - kbeg) / BK));   // this block's first e4m3 tile (its K range may lie on either side)
 #pragma unroll 1
-        for (; t + 2 < nk; ++t) tile_phases(t, 0);
-        tile_phases(t, 1);
-        tile_phases(t + 1, 2);
+            for (; t + 2 < nk && t < tsw; ++t) tile_phases(F16T, t, 0);
+#pragma unroll 1
+            for (; t + 2 < nk; ++t) tile_phases(FP8T, t, 0);
+            if (t < tsw) tile_phases(F16T, t, 1); else tile_phases(FP8T, t, 1);
+            if (t + 1 < tsw) tile_phases(F16T, t + 1, 2); else tile_phases(FP8T, t + 1, 2);
+        } else {
+#pragma unroll 1
+            for (; t + 2 < nk; ++t) tile_phases(F16T, t, 0);
+            tile_phases(F16T, t, 1);
+            tile_phases(F16T, t + 1, 2);
+        }
         if (wm == 0) PSALM_RAW_BARRIER();                        // pairs with wave row 1's last barrier
 #undef PH8_ENTER_MFMA
 #undef PH8_LEAVE_MFMA
@@ -644,23 +681,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         };
         // (the scheduler otherwise sinks the reads back next to their first use to save registers; the pin costs TM+TN
         //  fragment registers, which the 256x256 configuration -- 253 VGPRs -- does not have)
-        if constexpr (FP8) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {                     // 8 k-steps of 16 fp8 per 128-byte row
-                const int co = (kk ^ fsw) * 8 + 4 * hi;          // bf16 units: 16-byte slot kk, 8-byte half hi
-                long fa8[TM], fb8[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa8[i] = *reinterpret_cast<const long*>(&As[(a_row0 + 32 * i) * BK + co]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb8[j] = *reinterpret_cast<const long*>(&Bs[(b_row0 + 32 * j) * BK + co]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa8[i], fb8[j], acc[i][j], 0, 0, 0);
-            }
-            continue;
-        }
         if constexpr (X3 == 2) {                                 // slice form: three products from the four images of this K slice
             const bf16_t* Al = As + (BM + BN) * BK;
             const bf16_t* Bl = Al + BM * BK;
@@ -734,7 +754,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const bool ok = col < g.N;
                 coff[j] = ok ? (unsigned)col * 4u : PSALM_BUF_OOB;
                 wsc[j] = 1.f;
-                if constexpr (FP8 || X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
+                if constexpr (X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
                 bias_c[j] = (!split && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
                 actc[j] = !split && act != ACT_NONE && col >= g.act_col_start;
             }
@@ -747,7 +767,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 asc[r] = 1.f;
-                if constexpr (FP8 || X3) asc[r] = fa.a_scale[min(bm + row_off(0, r), g.M - 1)];
+                if constexpr (X3) asc[r] = fa.a_scale[min(bm + row_off(0, r), g.M - 1)];
                 rv[r] = R ? psalm_buf_load_f32(rr, (unsigned)((long)row_off(0, r) * g.ldr * 4) + coff[0]) : 0.f;
             }
 #pragma unroll
@@ -757,7 +777,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     x[r] = acc[i][j][r];
-                    if constexpr (FP8 || X3) x[r] *= asc[r] * wsc[j];
+                    if constexpr (X3) x[r] *= asc[r] * wsc[j];
                     x[r] += bias_c[j];
                     if (actc[j] && !post) x[r] = fmaxf(x[r], 0.f);           // ReLU (the only activation on this path)
                     x[r] += rv[r];
@@ -766,7 +786,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 if (t + 1 < TM * TN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if constexpr (FP8 || X3) { if (j2 == 0) asc[r] = fa.a_scale[min(bm + row_off(i2, r), g.M - 1)]; }
+                        if constexpr (X3) { if (j2 == 0) asc[r] = fa.a_scale[min(bm + row_off(i2, r), g.M - 1)]; }
                         if (R) rv[r] = psalm_buf_load_f32(rr, (unsigned)((long)row_off(i2, r) * g.ldr * 4) + coff[j2]);
                     }
                 }
@@ -844,9 +864,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                             if (actc[j]) x = apply_act(x, act);
                             unsigned word = __builtin_bit_cast(unsigned, x);
                             if (soc[j]) {
-                                const float y = x * sc[r];
-                                const _Float16 h = (_Float16)y, l = (_Float16)(y - (float)h);
-                                word = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                                unsigned hw_, sw_;
+                                psalm_split_words(x * sc[r], fa.so_form, hw_, sw_);
+                                word = hw_ | (sw_ << 16);
                             }
                             Cw[(prow0 + (r & 3) + 8 * (r >> 2)) * BN + wn * (BN / WN) + j * 32 + n32] = word;
                         }
@@ -947,14 +967,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];   // (fp8: dequantised in the store loop below)
+                        Cs[row * BN + wn * (BN / WN) + j * 32 + n32] = acc[i][j][r];   // (split-f16: scaled in the store loop below)
                     }
         }
         constexpr int NIT = ROWS_E / RPI;
-        // fp8: per-row dequantisation scales -- a_scale of this thread's NIT rows and w_scale of its 8 columns, fetched once here
+        // split-f16: per-row scales -- a_scale of this thread's NIT rows and w_scale of its 8 columns, fetched once here
         // (in the accumulator -> LDS pass they were 2 loads per accumulator element: 256 per lane, and spilled)
-        float asc[(FP8 || X3) ? NIT : 1], wsc[8];
-        if constexpr (FP8 || X3) {
+        float asc[X3 ? NIT : 1], wsc[8];
+        if constexpr (X3) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) asc[it] = fa.a_scale[min(bm + ep * ROWS_E + it * RPI + tid / TPR, g.M - 1)];
 #pragma unroll
@@ -965,7 +985,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         __syncthreads();
         if (ep == 0) PSALM_TL(4);
         if (col0 >= g.N) continue;
-        // one store iteration (rows it * RPI + tid / TPR of the pass); false = past the last row of the matrix.  `itc` indexes the fp8
+        // one store iteration (rows it * RPI + tid / TPR of the pass); false = past the last row of the matrix.  `itc` indexes the
         // row-scale registers and must be a compile-time constant there (fully unrolled caller); bf16 / fp32 kernels keep the compact
         // 2x-unrolled loop (a full unroll, tried with a residual prefetch, doubles the code of every instantiation -- 2.4 -> 4.7 MB of
         // ISA; unmeasured, and the instruction-cache footprint was judged the larger risk).
@@ -976,7 +996,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             const f32x4_g v0 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8]);
             const f32x4_g v1 = *reinterpret_cast<const f32x4_g*>(&Cs[rl * BN + c8 + 4]);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if constexpr (FP8 || X3) {                            // dequantise: per-row scale of A x per-row scale of W
+            if constexpr (X3) {                            // dequantise: per-row scale of A x per-row scale of W
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] *= asc[itc] * wsc[c];
             }
@@ -1037,7 +1057,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             }
             return true;
         };
-        if constexpr (FP8 || X3) {
+        if constexpr (X3) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (!store_it(it, it)) break;
@@ -1176,7 +1196,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
                                                                const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
                                                                float ln_eps, TL* __restrict__ ln_out, long ld_ln,
                                                                unsigned short* __restrict__ sp_out = nullptr, float* __restrict__ sp_inv = nullptr,
-                                                               int sp_kp = 0) {
+                                                               int sp_kp = 0, int sp_form = 0) {
     __shared__ float red[12];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int act = g.act & 15;
@@ -1289,10 +1309,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
                 unsigned hw[2], lw[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const _Float16 h0 = (_Float16)x4[2 * k], h1 = (_Float16)x4[2 * k + 1];
-                    const _Float16 l0 = (_Float16)(x4[2 * k] - (float)h0), l1 = (_Float16)(x4[2 * k + 1] - (float)h1);
-                    hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                    lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    unsigned h0, h1, l0, l1;
+                    psalm_split_words(x4[2 * k], sp_form, h0, l0);
+                    psalm_split_words(x4[2 * k + 1], sp_form, h1, l1);
+                    hw[k] = h0 | (h1 << 16);
+                    lw[k] = l0 | (l1 << 16);
                 }
                 *reinterpret_cast<u32x2_s*>(orow + c0[i]) = u32x2_s{hw[0], hw[1]};
                 *reinterpret_cast<u32x2_s*>(orow + sp_kp + c0[i]) = u32x2_s{lw[0], lw[1]};
@@ -1521,10 +1542,30 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     }
 }
 
+// x8 form of the split-f16 GEMM (K = 2 Kp): always 256 x 256 tiles on the phased kernel; split-K slices to fill the 256 CUs.
+static int x8_splits(int M, int N, int K, bool have_ws, long workspace_bytes) {
+    const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    int splits = 1;
+    if (tiles256 < 160 && have_ws && K >= 1024) {
+        splits = (int)((256 + tiles256 - 1) / tiles256);
+        if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
+        if (splits > 32) splits = 32;
+        const long per = (long)M * N * (long)sizeof(float);
+        if ((long)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+        if (splits < 2) splits = 1;
+    }
+    if (splits > 1) { const int kps = cdiv(cdiv(K, 64), splits) * 64; splits = cdiv(K, kps); }
+    return splits;
+}
+
 // Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS, 2 skinny), out[1] = BM,
 // out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
 extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
     const bool x3 = a_dtype == 2 && w_dtype == 2;                              // dtype code 2: split-f16 operands (psalm_gemm_x3, K = 3 Kp)
+    if (a_dtype == 3 && w_dtype == 3) {                                        // dtype code 3: their x8 form (K = 2 Kp)
+        out4[0] = 1; out4[1] = 256; out4[2] = 256; out4[3] = x8_splits(M, N, K, workspace_bytes > 0, workspace_bytes);
+        return 0;
+    }
     if (x3 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;
     } else if (x3) {
@@ -1545,18 +1586,19 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
 }
 
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
-struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; };
+struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; int split_form = 0; };
 extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
                                      float eps, void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2,
-                                     void* stream);
+                                     int form, void* stream);
 extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 
 static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s,
-                       const LnEpilogue* ln = nullptr, bool fp8 = false, bool x3 = false) {
+                       const LnEpilogue* ln = nullptr, bool x3 = false, bool x8 = false) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
+    if (x8) { BM = BN = 256; splits = x8_splits(M, N, K, workspace != nullptr, workspace_bytes); }   // x8 form: the phased 256 x 256 kernel only
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
     const int slice = !x3 || BM == 256 || fa.so ? 0 : (g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 ? 1 : 0));
@@ -1593,25 +1635,24 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
         else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
     } while (0)
-#define LAUNCH_GLDS8(BM_, BN_, WM_, WN_)                                                                                     \
-    do {                                                                                                                     \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 64, true>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
-    } while (0)
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
 #define LAUNCH_X3S(BM_, BN_, WM_, WN_, NS_, BK_) \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, BK_, false, 0, 2>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, BK_, 0, 2>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
         if (BM == 128 && slice == 2) LAUNCH_X3S(128, 128, 2, 2, 4, 32);
         else if (BM == 128) LAUNCH_X3S(128, 128, 2, 2, 2, 64);
         else if (slice == 2) LAUNCH_X3S(64, 128, 2, 2, 4, 32);
         else LAUNCH_X3S(64, 128, 2, 2, 2, 64);
 #undef LAUNCH_X3S
+    } else if (x8) {                                              // split-f16 operands with e4m3 cross-term halves (K range 2 Kp)
+        if (fa.k_per_split < 128 || (K - (splits - 1) * fa.k_per_split) < 128) { psalm_set_error("psalm_gemm_x3 (x8): K range too short"); return -1; }
+        if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3, true>), grid, dim3(512), 0, s, fa);
+        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3>), grid, dim3(512), 0, s, fa);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
 #define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_)                                                                                                        \
         do {                                                                                                                                           \
-            if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1, true>), grid,               \
+            if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, PH_, 1, true>), grid,               \
                                           dim3(64 * WM_ * WN_), 0, s, fa);                                                                             \
-            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, false, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa); \
+            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa); \
         } while (0)
         if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
         else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
@@ -1620,10 +1661,6 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if ((g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2)) >= 3) LAUNCH_X3(64, 128, 2, 2, 3, 0);
         else LAUNCH_X3(64, 128, 2, 2, 2, 0);
 #undef LAUNCH_X3
-    } else if (fp8) {
-        if (BM == 256) LAUNCH_GLDS8(256, 256, 2, 4);
-        else if (BM == 128) LAUNCH_GLDS8(128, 128, 2, 2);
-        else LAUNCH_GLDS8(64, 128, 2, 2);
     } else if (conv) {
         if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, true);
         else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
@@ -1632,14 +1669,14 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (BM == 256 && g_ph8 && fa.k_per_split % 64 == 0 && K % 64 == 0 && fa.k_per_split >= 128 &&
             (K - (splits - 1) * fa.k_per_split) >= 128) {
             if (g_ph8 == 1) {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 1>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 1>), grid, dim3(512), 0, s, fa);
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 1>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 1>), grid, dim3(512), 0, s, fa);
             } else if (g_ph8 == 2) {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 2>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 2>), grid, dim3(512), 0, s, fa);
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 2>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 2>), grid, dim3(512), 0, s, fa);
             } else {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, false, 3>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, false, 3>), grid, dim3(512), 0, s, fa);
+                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3>), grid, dim3(512), 0, s, fa);
+                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 3>), grid, dim3(512), 0, s, fa);
             }
         }
         else if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
@@ -1661,11 +1698,10 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
 #undef LAUNCH_GLDS
 #undef LAUNCH_GLDS32
 #undef LAUNCH_GLDS128
-#undef LAUNCH_GLDS8
     if (splits > 1) {
         if (ln && ln->split_out) {                                // ... + the normalised rows in split-f16 form (psalm_gemm_x3_ln_split)
 #define RLNS_LAUNCH(NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<float, NV_, true>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
-                                            ln->gamma, ln->beta, ln->eps, (float*)ln->out, ln->ld, (unsigned short*)ln->split_out, ln->split_inv, N)
+                                            ln->gamma, ln->beta, ln->eps, (float*)ln->out, ln->ld, (unsigned short*)ln->split_out, ln->split_inv, N, ln->split_form)
             const int nv = N <= 1024 ? 1 : (N <= 2048 ? 2 : (N <= 4096 ? 4 : 8));
             if (nv == 1) RLNS_LAUNCH(1); else if (nv == 2) RLNS_LAUNCH(2); else if (nv == 4) RLNS_LAUNCH(4); else RLNS_LAUNCH(8);
 #undef RLNS_LAUNCH
@@ -1693,7 +1729,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (e != hipSuccess) { psalm_set_error("psalm_gemm_ln: GEMM launch failed"); return (int)e; }
         if (ln->split_out)
             return psalm_layernorm_split((const float*)g.C, g.ldc, (float*)ln->out, ln->ld, ln->gamma, ln->beta, M, N, ln->eps, ln->split_out,
-                                         ln->split_inv, nullptr, 0, nullptr, nullptr, (void*)s);
+                                         ln->split_inv, nullptr, 0, nullptr, nullptr, ln->split_form, (void*)s);
         return psalm_layernorm(g.C, PSALM_F32, g.ldc, ln->out, ln->dtype, ln->ld, nullptr, 0, ln->gamma, ln->beta, M, N, ln->eps, (void*)s);
     }
     PSALM_LAUNCH_END("psalm_gemm");
@@ -1838,78 +1874,6 @@ extern "C" int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W
     return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, &ln);
 }
 
-// ------------------------------------------------------------------------------------------- fp8 (OCP e4m3) path
-// Row-wise dynamic quantisation: q[m,:] = e4m3(x[m,:] * 448 / amax_m), scale[m] = amax_m / 448 (1 for an all-zero row).
-// One wavefront per row.  x (rows,K) f32|bf16 row stride ldx; q (rows,K) bytes row stride ldq; K % 8 == 0.
-template <typename TI>
-__global__ void __launch_bounds__(256) quantize_rows_fp8_kernel(const TI* __restrict__ x, long ldx, unsigned char* __restrict__ q,
-                                                                long ldq, float* __restrict__ scale, int rows, int K) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const TI* xr = x + row * ldx;
-    float amax = 0.f;
-    for (int c = lane * 8; c < K; c += 512) {
-        float v[8];
-        load8_f32(xr + c, v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(v[k]));
-    }
-    amax = wave_max(amax);
-    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-    const float inv = 1.0f / sc;
-    if (lane == 0) scale[row] = sc;
-    unsigned char* qr = q + row * ldq;
-    for (int c = lane * 8; c < K; c += 512) {
-        float v[8];
-        load8_f32(xr + c, v);
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo |= (unsigned)f32_to_e4m3(v[k] * inv) << (8 * k);
-            hi |= (unsigned)f32_to_e4m3(v[4 + k] * inv) << (8 * k);
-        }
-        *reinterpret_cast<unsigned long long*>(qr + c) = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    }
-}
-
-extern "C" int psalm_quantize_rows_fp8(const void* x, int x_dtype, long ldx, void* q, long ldq, float* scale, int rows, int K,
-                                       void* stream) {
-    if (rows == 0) return 0;
-    const long xs = x_dtype == PSALM_F32 ? 4 : 2;
-    PSALM_CHECK_ARG(K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * xs) % 16 == 0 && (uintptr_t)q % 8 == 0 && ldq % 8 == 0,
-                    "psalm_quantize_rows_fp8: K % 8 == 0, 16-byte aligned input rows, 8-byte aligned output rows");
-    PSALM_DISPATCH(x_dtype, TI, {
-        hipLaunchKernelGGL((quantize_rows_fp8_kernel<TI>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const TI*)x, ldx,
-                           (unsigned char*)q, ldq, scale, rows, K);
-    });
-    PSALM_LAUNCH_END("psalm_quantize_rows_fp8");
-}
-
-// C = act((Aq . Wq^T) * a_scale[m] * w_scale[n] + bias) + residual with e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8
-// (fp32 accumulation; products of e4m3 values are exact in fp32).  Aq (M,K) bytes, row stride lda; Wq (N,K) bytes, row stride ldw;
-// a_scale (M), w_scale (N) f32;  K % 128 == 0;  16-byte aligned rows.  Same epilogue / split-K / tile selection as psalm_gemm.
-extern "C" int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, const void* Wq, long ldw, const float* w_scale,
-                              const float* bias, const void* residual, long ldr, void* C, int c_dtype, long ldc, int M, int N, int K,
-                              int act, int act_col_start, void* workspace, long workspace_bytes, void* stream) {
-    if (M == 0 || N == 0) return 0;
-    PSALM_CHECK_ARG(K > 0 && K % 128 == 0, "psalm_gemm_fp8: K must be a positive multiple of 128");
-    PSALM_CHECK_ARG((uintptr_t)Aq % 16 == 0 && lda % 16 == 0 && (uintptr_t)Wq % 16 == 0 && ldw % 16 == 0, "psalm_gemm_fp8: 16-byte aligned rows");
-    PSALM_CHECK_ARG(a_scale && w_scale, "psalm_gemm_fp8: scales required");
-    PSALM_CHECK_ARG(c_dtype == PSALM_F32 || c_dtype == PSALM_BF16, "psalm_gemm_fp8: bad output dtype");
-    GemmArgs g;
-    g.A = Aq; g.W = Wq; g.bias = bias; g.res = residual; g.C = C;
-    g.lda = lda / 2; g.ldw = ldw / 2; g.ldr = ldr; g.ldc = ldc;          // "bf16 units": two fp8 per unit
-    g.M = M; g.N = N; g.K = K / 2; g.act = act; g.act_col_start = act_col_start;
-    g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
-    GemmFastArgs fa;
-    fa.cH = fa.cW = fa.cC = fa.cK = fa.cS = fa.cP = fa.cHo = fa.cWo = 0;
-    fa.zeros = nullptr;
-    fa.a_scale = a_scale; fa.w_scale = w_scale;
-    fa.x3_kp = 0;
-    return launch_fast(g, fa, false, c_dtype, workspace, workspace_bytes, (hipStream_t)stream, nullptr, true);
-}
-
 // ------------------------------------------------------------------------------------------- split-f16 ("X3") path
 // fp32-class GEMMs on the f16 matrix cores.  Plain bf16 operands (8 mantissa bits) cannot meet the reference's fp32 results to the
 // north star's tolerance (mask IoU within 1e-3, identical labels): the masked-attention feedback of the mask decoder
@@ -1927,7 +1891,7 @@ extern "C" int psalm_gemm_fp8(const void* Aq, long lda, const float* a_scale, co
 // with one wavefront per row a K = 128 row (Swin stage 0, 65536 rows) kept 16 of 64 lanes busy.
 template <int LPR>
 __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
-                                                        float* __restrict__ inv_scale, int rows, int K, int Kp) {
+                                                        float* __restrict__ inv_scale, int rows, int K, int Kp, int form) {
     constexpr int RPW = 64 / LPR;                                // rows per wavefront
     const int lane = threadIdx.x & 63, sub = lane % LPR;
     const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -1962,11 +1926,11 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = v[2 * k] * sc, a1 = v[2 * k + 1] * sc;
-            const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-            const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-            hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-            lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            unsigned h0, h1, l0, l1;
+            psalm_split_words(v[2 * k] * sc, form, h0, l0);
+            psalm_split_words(v[2 * k + 1] * sc, form, h1, l1);
+            hw[k] = h0 | (h1 << 16);
+            lw[k] = l0 | (l1 << 16);
         }
         *reinterpret_cast<u32x4_s*>(orow + c) = u32x4_s{hw[0], hw[1], hw[2], hw[3]};
         *reinterpret_cast<u32x4_s*>(orow + Kp + c) = u32x4_s{lw[0], lw[1], lw[2], lw[3]};
@@ -1976,7 +1940,7 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
 // Few, long rows (Phi: 899 tokens x 2048 / 10240 columns): a whole 256-thread block per row -- one wavefront per row was a 20-iteration
 // dependent load loop on 899 wavefronts (r02e: ~14 us per launch, 2.6 ms per image).
 __global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
-                                                            float* __restrict__ inv_scale, int K, int Kp) {
+                                                            float* __restrict__ inv_scale, int K, int Kp, int form) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const long row = blockIdx.x;
@@ -2010,53 +1974,55 @@ __global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restr
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = v[2 * k] * sc, a1 = v[2 * k + 1] * sc;
-            const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-            const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-            hw[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-            lw[k] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+            unsigned h0, h1, l0, l1;
+            psalm_split_words(v[2 * k] * sc, form, h0, l0);
+            psalm_split_words(v[2 * k + 1] * sc, form, h1, l1);
+            hw[k] = h0 | (h1 << 16);
+            lw[k] = l0 | (l1 << 16);
         }
         *reinterpret_cast<u32x4_s*>(orow + c) = u32x4_s{hw[0], hw[1], hw[2], hw[3]};
         *reinterpret_cast<u32x4_s*>(orow + Kp + c) = u32x4_s{lw[0], lw[1], lw[2], lw[3]};
     }
 }
 
-extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream) {
+extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, int form, void* stream) {
     if (rows == 0) return 0;
-    const int Kp = (K + 63) / 64 * 64;
+    PSALM_CHECK_ARG(form >= 0 && form <= 2, "psalm_split_f16: form 0 (f16 lo), 1 (e4m3 pairs, A operand) or 2 (e4m3 pairs, W operand)");
+    const int Kp = form ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;     // x8 forms: whole 128-byte e4m3 K tiles
     PSALM_CHECK_ARG(K > 0 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0, "psalm_split_f16: K % 8 == 0, 16-byte aligned input rows");
     PSALM_CHECK_ARG((uintptr_t)out % 16 == 0 && (ldo * 2) % 16 == 0 && ldo >= 2L * Kp, "psalm_split_f16: output rows of >= 2*ceil64(K) f16, 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (Kp >= 1024 && rows <= 4096) {
-        hipLaunchKernelGGL(split_f16_row_kernel, dim3(rows), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, K, Kp);
+        hipLaunchKernelGGL(split_f16_row_kernel, dim3(rows), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, K, Kp, form);
         PSALM_LAUNCH_END("psalm_split_f16");
     }
-    if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
-    else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
-    else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
+    if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
+    else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
+    else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
     PSALM_LAUNCH_END("psalm_split_f16");
 }
 
 // C = act((A . W^T) + bias) + residual from split-f16 operands:  A2 (M, 2 Kp) / W2 (N, 2 Kp) f16 [hi | lo] with row strides lda / ldw
 // (elements) and per-row scales a_scale (M) / w_scale (N) as written by psalm_split_f16;  Kp % 64 == 0.  C / residual fp32.
 // Same tile selection, split-K and epilogue as psalm_gemm (on a K range of 3 Kp); M <= 128 problems take the skinny kernel.
-struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; };
-static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; int so_form; };
+static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                         const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
                         int act_col_start, void* workspace, long workspace_bytes, void* stream, const SplitOut* so, const char* name,
                         const LnEpilogue* ln = nullptr) {
     if (M == 0 || N == 0) return 0;
     PSALM_CHECK_ARG(Kp > 0 && Kp % 64 == 0, "psalm_gemm_x3: Kp must be a positive multiple of 64");
+    PSALM_CHECK_ARG(!x8 || Kp % 128 == 0, "psalm_gemm_x3: x8 operands (e4m3 cross-term halves) need Kp % 128 == 0");
     PSALM_CHECK_ARG((uintptr_t)A2 % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)W2 % 16 == 0 && (ldw * 2) % 16 == 0 && lda >= 2L * Kp && ldw >= 2L * Kp,
                     "psalm_gemm_x3: 16-byte aligned operand rows of >= 2*Kp f16");
     PSALM_CHECK_ARG(a_scale && w_scale, "psalm_gemm_x3: scales required");
     GemmArgs g;
     g.A = A2; g.W = W2; g.bias = bias; g.res = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = 3 * Kp; g.act = act; g.act_col_start = act_col_start;
+    g.M = M; g.N = N; g.K = (x8 ? 2 : 3) * Kp; g.act = act; g.act_col_start = act_col_start;     // x8: hi.hi over Kp f16 + both cross terms over 2 Kp e4m3 bytes
     g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (!so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+    if (!x8 && !so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
         hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
         PSALM_LAUNCH_END(name);
@@ -2069,13 +2035,14 @@ static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const vo
     if (so) {
         fa.so = (unsigned short*)so->so; fa.ldso = so->ldso; fa.so_kp = so->so_kp; fa.so_col_off = so->so_col_off;
         fa.so_col_start = so->so_col_start; fa.so_global = so->so_global; fa.so_inv = so->so_inv; fa.so_par = so->so_par;
+        fa.so_form = so->so_form;
     }
-    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, false, true);
+    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, true, x8 != 0);
 }
-extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                              const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
                              int act_col_start, void* workspace, long workspace_bytes, void* stream) {
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, act, act_col_start, workspace,
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, residual, ldr, C, ldc, M, N, act, act_col_start, workspace,
                         workspace_bytes, stream, nullptr, "psalm_gemm_x3");
 }
 
@@ -2086,18 +2053,19 @@ extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, con
 // max(a_scale[r] * par[0] + par[1],  (global_rows ? max_r a_scale[r] : 0) * g1 + g0).  1/scale -> split_inv[r].  Columns below
 // split_col_start are written to C as usual (C may be NULL when split_col_start == 0).  No residual, no split-K; N, split_col_start,
 // split_col_off, split_kp multiples of 8.  The un-written columns of split_out (K padding of the consumer) are the caller's to zero.
-extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                                    const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out,
-                                   long ld_split, int split_kp, int split_col_off, int split_col_start, float* split_inv,
+                                   long ld_split, int split_kp, int split_col_off, int split_col_start, int split_form, float* split_inv,
                                    const float* bound_par, int global_rows, void* workspace, long workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_gemm_x3_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand)");
     PSALM_CHECK_ARG(split_out && split_inv && bound_par, "psalm_gemm_x3_split: split output, scale array and bound parameters required");
     PSALM_CHECK_ARG(N % 8 == 0 && split_col_start % 8 == 0 && split_col_start >= 0 && split_col_start < N && split_col_off % 8 == 0 &&
                         split_col_off >= 0 && split_kp % 8 == 0 && (uintptr_t)split_out % 16 == 0 && (ld_split * 2) % 16 == 0 &&
                         split_col_off + (N - split_col_start) <= split_kp && ld_split >= 2L * split_kp,
                     "psalm_gemm_x3_split: N / column offsets multiples of 8, 16-byte aligned split rows of >= 2*split_kp f16");
     PSALM_CHECK_ARG(C || split_col_start == 0, "psalm_gemm_x3_split: C required for the columns below split_col_start");
-    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par};
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
+    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par, split_form};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
                         stream, &so, "psalm_gemm_x3_split");
 }
 
@@ -2107,16 +2075,17 @@ extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scal
 // input_layernorm of the following layer, modeling_phi.py:263-300).  With split-K (the usual case for this GEMM: few tiles, long K) the
 // partial-sum reduce, epilogue, LayerNorm and split run as ONE row pass; otherwise the LayerNorm is psalm_layernorm_split on C.
 // N % 64 == 0, N <= 2048; split_out rows of 2*N f16 (contiguous), split_inv (M).
-extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
+extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                                       const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N,
                                       const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out,
-                                      float* split_inv, void* workspace, long workspace_bytes, void* stream) {
+                                      float* split_inv, int split_form, void* workspace, long workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(split_form == 0 || (split_form == 1 && N % 128 == 0), "psalm_gemm_x3_ln_split: split_form 0, or 1 with N % 128 == 0");
     PSALM_CHECK_ARG(N % 64 == 0 && N <= 2048 && split_out && split_inv && C, "psalm_gemm_x3_ln_split: N % 64 == 0, N <= 2048, outputs required");
     PSALM_CHECK_ARG((uintptr_t)C % 16 == 0 && (ldc * 4) % 16 == 0 && (uintptr_t)ln_gamma % 16 == 0 && (uintptr_t)ln_beta % 16 == 0 &&
                         (uintptr_t)split_out % 16 == 0 && (!ln_out || ((uintptr_t)ln_out % 16 == 0 && (ld_ln * 4) % 16 == 0)) &&
                         (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * 4) % 16 == 0)),
                     "psalm_gemm_x3_ln_split: 16-byte aligned rows");
-    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, PSALM_F32, ld_ln, split_out, split_inv};
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, 0, 0, workspace, workspace_bytes, stream,
+    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, PSALM_F32, ld_ln, split_out, split_inv, split_form};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, residual, ldr, C, ldc, M, N, 0, 0, workspace, workspace_bytes, stream,
                         nullptr, "psalm_gemm_x3_ln_split", &ln);
 }

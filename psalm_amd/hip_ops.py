@@ -85,11 +85,14 @@ class _ProfiledLib:
 
 class SplitF16:
     """A matrix in split-f16 form (psalm_split_f16): `t` (rows, 2*Kp) float16 = [hi | lo], `inv_scale` (rows,) float32, logical
-    shape (rows, K).  Either operand of `Ops.gemm` may be one; in the "f16x3" mode GEMM weights are kept in this form."""
-    __slots__ = ("t", "inv_scale", "K", "Kp")
+    shape (rows, K).  Either operand of `Ops.gemm` may be one; in the "f16x3" mode GEMM weights are kept in this form.
+    `form`: 0 = the second half-words are lo as float16 (three f16 products per GEMM); 1 / 2 = the "x8" form of an A / W operand -- pairs
+    of e4m3 bytes for the two cross terms (psalm_split_words in csrc/common.h; Kp = ceil128(K)).  A GEMM takes operands of form (0, 0) or
+    (1, 2)."""
+    __slots__ = ("t", "inv_scale", "K", "Kp", "form")
 
-    def __init__(self, t, inv_scale, K):
-        self.t, self.inv_scale, self.K, self.Kp = t, inv_scale, K, t.shape[1] // 2
+    def __init__(self, t, inv_scale, K, form=0):
+        self.t, self.inv_scale, self.K, self.Kp, self.form = t, inv_scale, K, t.shape[1] // 2, form
 
     @property
     def shape(self):
@@ -193,25 +196,39 @@ class Ops:
         self._check(rc, "psalm_gemm")
         return out
 
-    def split_f16(self, x):
-        """x (rows,K) float32 (row-strided view) -> SplitF16: x * s = hi + lo in float16 with a per-row power-of-two scale."""
+    def split_f16(self, x, form=0):
+        """x (rows,K) float32 (row-strided view) -> SplitF16: x * s = hi + lo in float16 with a per-row power-of-two scale (form 0), or with
+        the e4m3 cross-term pairs of an A (form 1) / W (form 2) operand in the second halves."""
         if isinstance(x, SplitF16):
+            if x.form != form and form != 0:
+                raise PsalmHipError(f"split_f16: operand already split in form {x.form}, form {form} wanted")
             return x
         if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
             raise PsalmHipError("split_f16: 2-D float32 input with a contiguous last dimension")
         rows, K = x.shape
-        Kp = (K + 63) // 64 * 64
+        Kp = (K + 127) // 128 * 128 if form else (K + 63) // 64 * 64
         t = self.empty(rows, 2 * Kp, dtype=torch.float16)
         inv = self.empty(rows, dtype=torch.float32)
-        rc = self.lib.psalm_split_f16(self._pv(x), c_long(x.stride(0)), self._p(t), c_long(2 * Kp), self._p(inv), rows, K, self._stream())
+        rc = self.lib.psalm_split_f16(self._pv(x), c_long(x.stride(0)), self._p(t), c_long(2 * Kp), self._p(inv), rows, K, form, self._stream())
         self._check(rc, "psalm_split_f16")
-        return SplitF16(t, inv, K)
+        return SplitF16(t, inv, K, form)
+
+    def _x3_operands(self, a, w):
+        """(a, w, x8) for a split-f16 GEMM: float32 tensors are split on the fly in the form the other operand already has."""
+        if isinstance(w, SplitF16) and w.form == 2:
+            a = self.split_f16(a, 1)
+        elif isinstance(a, SplitF16) and a.form == 1:
+            w = self.split_f16(w, 2)
+        a, w = self.split_f16(a), self.split_f16(w)
+        if (a.form, w.form) not in ((0, 0), (1, 2)):
+            raise PsalmHipError(f"split-f16 GEMM: operand forms (A {a.form}, W {w.form}); (0, 0) or (1, 2) expected")
+        if a.K != w.K or a.Kp != w.Kp:
+            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        return a, w, 1 if a.form else 0
 
     def gemm_x3(self, a, w, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=None):
         """gemm() on split-f16 operands (float32 tensors are split on the fly): fp32-class result on the f16 matrix cores."""
-        a, w = self.split_f16(a), self.split_f16(w)
-        if a.K != w.K:
-            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        a, w, x8 = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if out is None:
             if out_dtype not in (None, torch.float32):
@@ -223,18 +240,16 @@ class Ops:
         if bias is not None and (bias.dtype != torch.float32 or bias.numel() != (M if act & ACT_BIAS_ROW else N)):
             raise PsalmHipError("gemm bias must be float32 (N,) -- or (M,) with ACT_BIAS_ROW")
         rc = self.lib.psalm_gemm_x3(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                    self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
+                                    self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(residual),
                                     c_long(residual.stride(0) if residual is not None else 0), self._pv(out), c_long(out.stride(0)),
                                     M, N, act, act_col_start, self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3")
         return out
 
-    def gemm_x3_ln_split(self, a, w, bias, residual, gamma, beta, eps, want_y=False):
+    def gemm_x3_ln_split(self, a, w, bias, residual, gamma, beta, eps, want_y=False, split_form=0):
         """x = a.w^T + bias + residual (float32), h = LayerNorm(x): returns (x, SplitF16(h), h float32 | None) -- the split-K reduce, the
-        LayerNorm and the split of h are one row pass (psalm_gemm_x3_ln_split)."""
-        a, w = self.split_f16(a), self.split_f16(w)
-        if a.K != w.K:
-            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        LayerNorm and the split of h are one row pass (psalm_gemm_x3_ln_split).  split_form: form of the emitted h (0, or 1 = x8 A operand)."""
+        a, w, x8 = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if residual is not None and (residual.dtype != torch.float32 or tuple(residual.shape) != (M, N) or residual.stride(-1) != 1):
             raise PsalmHipError("gemm_x3_ln_split: float32 (M,N) residual")
@@ -242,21 +257,19 @@ class Ops:
         y = self.empty(M, N, dtype=torch.float32) if want_y else None
         so, inv = self.empty(M, 2 * N, dtype=torch.float16), self.empty(M, dtype=torch.float32)
         rc = self.lib.psalm_gemm_x3_ln_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                             self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
+                                             self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(residual),
                                              c_long(residual.stride(0) if residual is not None else 0), self._p(x), c_long(N), M, N,
                                              self._p(gamma), self._p(beta), c_float(eps), self._pv(y), c_long(N), self._p(so), self._p(inv),
-                                             self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+                                             split_form, self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_ln_split")
-        return x, SplitF16(so, inv, N), y
+        return x, SplitF16(so, inv, N, split_form), y
 
     def gemm_x3_split(self, a, w, bias, act, split_out, split_inv, bound_par, split_col_off=0, split_col_start=0, act_col_start=0,
-                      out=None, global_rows=False):
+                      out=None, global_rows=False, split_form=0):
         """gemm_x3 whose columns >= split_col_start are written as the split-f16 A operand of the next GEMM: into `split_out` (a SplitF16's
         .t buffer (M, 2*Kp_out) f16) at columns split_col_off.. (hi) / Kp_out + split_col_off.. (lo), row scales (inverse) into split_inv;
         bound_par: 4 device floats, see psalm_gemm_x3_split.  Columns below split_col_start go to `out` (M, >= split_col_start...) fp32."""
-        a, w = self.split_f16(a), self.split_f16(w)
-        if a.K != w.K:
-            raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
+        a, w, x8 = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if split_out.dtype != torch.float16 or split_out.dim() != 2 or split_out.shape[0] != M or split_out.stride(1) != 1:
             raise PsalmHipError("gemm_x3_split: split_out must be a (M, 2*Kp) float16 buffer")
@@ -267,10 +280,10 @@ class Ops:
         if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
             raise PsalmHipError("gemm bias must be float32 (N,)")
         rc = self.lib.psalm_gemm_x3_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                          self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(out),
+                                          self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(out),
                                           c_long(out.stride(0) if out is not None else 0), M, N, act, act_col_start,
                                           self._p(split_out), c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
-                                          split_col_start, self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
+                                          split_col_start, split_form, self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
                                           self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_split")
         return split_out
@@ -289,34 +302,6 @@ class Ops:
                                     c_long(N), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_ln")
         return out, ln_out
-
-    def quantize_rows_fp8(self, x):
-        """x (M,K) f32|bf16 (row-strided view) -> (q uint8 (M,K) e4m3fn bytes, scale f32 (M)): per-row dynamic quantisation."""
-        M, K = x.shape
-        q = self.empty(M, K, dtype=torch.uint8)
-        sc = self.empty(M, dtype=torch.float32)
-        rc = self.lib.psalm_quantize_rows_fp8(self._pv(x), _dt(x), c_long(x.stride(0)), self._p(q), c_long(K), self._p(sc), M, K,
-                                              self._stream())
-        self._check(rc, "psalm_quantize_rows_fp8")
-        return q, sc
-
-    def gemm_fp8(self, aq, a_scale, wq, w_scale, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=torch.bfloat16):
-        """out = act((aq @ wq^T) * a_scale[:,None] * w_scale[None,:] + bias) + residual; aq (M,K) / wq (N,K) uint8 e4m3fn."""
-        M, K = aq.shape
-        N = wq.shape[0]
-        if aq.dtype != torch.uint8 or wq.dtype != torch.uint8 or wq.shape[1] != K:
-            raise PsalmHipError("gemm_fp8: uint8 (e4m3fn) operands with matching K")
-        if out is None:
-            out = self.empty(M, N, dtype=out_dtype)
-        if residual is not None and (residual.dtype != out.dtype or residual.shape != out.shape):
-            raise PsalmHipError("gemm_fp8: residual must match the output")
-        rc = self.lib.psalm_gemm_fp8(self._pv(aq), c_long(aq.stride(0)), self._p(a_scale), self._pv(wq), c_long(wq.stride(0)),
-                                     self._p(w_scale), self._p(bias), self._pv(residual),
-                                     c_long(residual.stride(0) if residual is not None else 0), self._pv(out), _dt(out),
-                                     c_long(out.stride(0)), M, N, K, act, act_col_start, self._p(self._gemm_ws()),
-                                     c_long(self.GEMM_WS_BYTES), self._stream())
-        self._check(rc, "psalm_gemm_fp8")
-        return out
 
     def conv2d_nhwc(self, x, B, H, W, wt, ksize, stride, pad, bias=None, residual=None, act=ACT_NONE, out_dtype=None):
         """Implicit-GEMM convolution: x (B*H*W, Cin) bf16 NHWC tokens, wt (Cout, k*k*Cin) bf16 (K order ky,kx,c) -> (B*Ho*Wo, Cout)."""
@@ -337,9 +322,13 @@ class Ops:
         self._check(rc, "psalm_conv2d_nhwc")
         return out
 
-    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True, x3=False):
-        """(path, BM, BN, splits) psalm_gemm / psalm_gemm_x3 (x3=True, K = 3*Kp) uses for this problem (path 1 = direct-to-LDS kernel)."""
+    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True, x3=False, x8=False):
+        """(path, BM, BN, splits) psalm_gemm / psalm_gemm_x3 (x3=True, K = 3*Kp; x8=True, K = 2*Kp) uses for this problem (path 1 =
+        direct-to-LDS kernel)."""
         out = (c_int * 4)()
+        if x8:
+            self._cdll_raw.psalm_gemm_describe(M, N, K, 3, 3, c_long(self.GEMM_WS_BYTES), out)
+            return tuple(out)
         if x3:
             self._cdll_raw.psalm_gemm_describe(M, N, K, 2, 2, c_long(self.GEMM_WS_BYTES), out)
             return tuple(out)
@@ -370,13 +359,15 @@ class Ops:
         self._check(rc, "psalm_layernorm3")
         return out
 
-    def layernorm_split(self, x, gamma, beta, eps=1e-5, want_y=False, want_split=True, add=None):
-        """LayerNorm of float32 rows whose result leaves as the next GEMM's split-f16 A operand (f16x3 mode).
+    def layernorm_split(self, x, gamma, beta, eps=1e-5, want_y=False, want_split=True, add=None, form=0):
+        """LayerNorm of float32 rows whose result leaves as the next GEMM's split-f16 A operand (f16x3 mode; form 1: its x8 form).
         Returns (y float32 | None, SplitF16(y) | None, SplitF16(y + add[row % r]) | None)."""
         rows, C = x.shape
         if x.dtype != torch.float32 or x.stride(1) != 1:
             raise PsalmHipError("layernorm_split: float32 rows")
-        Kp = (C + 63) // 64 * 64
+        Kp = (C + 127) // 128 * 128 if form else (C + 63) // 64 * 64
+        if form and Kp != C:
+            raise PsalmHipError("layernorm_split: the x8 form needs C % 128 == 0")
         y = self.empty(rows, C, dtype=torch.float32) if want_y else None
         s1 = i1 = s2 = i2 = None
         if want_split:
@@ -387,9 +378,9 @@ class Ops:
             s2, i2 = self.empty(rows, 2 * Kp, dtype=torch.float16), self.empty(rows, dtype=torch.float32)
         rc = self.lib.psalm_layernorm_split(self._pv(x), c_long(x.stride(0)), self._p(y), c_long(C), self._p(gamma), self._p(beta), rows, C,
                                             c_float(eps), self._p(s1), self._p(i1), self._p(add), c_long(add.shape[0] if add is not None else 0),
-                                            self._p(s2), self._p(i2), self._stream())
+                                            self._p(s2), self._p(i2), form, self._stream())
         self._check(rc, "psalm_layernorm_split")
-        return y, (SplitF16(s1, i1, C) if want_split else None), (SplitF16(s2, i2, C) if add is not None else None)
+        return y, (SplitF16(s1, i1, C, form) if want_split else None), (SplitF16(s2, i2, C, form) if add is not None else None)
 
     def swin_window_gather(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5, out_dtype=None):
         """x (B*H*W, C) -> LN + pad + roll(-shift) + window partition -> (B*nW*ws*ws, C)."""
@@ -567,7 +558,7 @@ class Ops:
         return out
 
     def causal_attention_split(self, buf, q_off, k_off, v_off, split_out, split_inv, split_col_off, cos, sin, key_mask, B, L, heads,
-                               head_dim, rot):
+                               head_dim, rot, split_form=0):
         """causal_attention on an fp32 buffer whose output goes, in split-f16 form under the row scales 1/split_inv, into columns
         split_col_off.. of `split_out` ((B*L, 2*Kp) float16; lo part Kp columns further) -- see psalm_causal_attention_f32_split."""
         if buf.dtype != torch.float32 or split_out.dtype != torch.float16 or split_inv.dtype != torch.float32:
@@ -579,7 +570,7 @@ class Ops:
         if ws is None:
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         rc = self.lib.psalm_causal_attention_f32_split(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._p(split_out),
-                                                       c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
+                                                       c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off, split_form,
                                                        self._p(split_inv), self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
                                                        B, L, heads, head_dim, rot, self._stream())
         self._check(rc, "psalm_causal_attention_f32_split")

@@ -18,9 +18,9 @@ Precision modes
             bar on this network (the mask decoder's thresholded attention-mask feedback amplifies operand rounding into label flips;
             measured threshold between 15 and 17 operand bits, tools/exp_bits.py); this mode does, at 3 f16 MFMA passes instead of
             the fp32 MFMA's 16x lower rate.  Activations, norms, softmax and the attention kernels are those of "fp32".
-    "fp8" : "bf16" with the Phi projections (q/k/v/fc1 and dense/fc2, 88 % of the model's FLOPs) on v_mfma_f32_32x32x16_fp8_fp8:
-            OCP e4m3fn weights with per-output-row scales (quantised once), activations quantised per token row on the fly
-            (BASELINE.json configs[4]; an extension -- the reference has no fp8 path).
+            With `llm_cross_fp8` (default where the shapes allow): the Phi decoder's GEMMs carry their two cross terms lo.hi + hi.lo as
+            ONE OCP e4m3 dot product on the block-scaled fp8 matrix instruction (2 instead of 3 f16-product equivalents; BASELINE.json
+            configs[4] names an "fp8 MFMA LLM path" -- this is the one that keeps parity, see PSALM.__init__).
 
 Layout: activations are token-major (rows = pixels/tokens, cols = channels; NHWC for feature maps), so 1x1
 convolutions are GEMMs, 3x3 / strided convolutions are im2col + GEMM, and LayerNorm/softmax rows are contiguous.
@@ -97,13 +97,13 @@ class PSALM:
     DEFAULT_PRECISION = "f16x3"
 
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
-                 precision: str = "bf16", use_graphs: bool = False):
-        if precision not in ("bf16", "fp32", "fp8", "f16x3"):
-            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3' or 'fp8'")
+                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8: Optional[bool] = None):
+        precision = precision or self.DEFAULT_PRECISION
+        if precision not in ("bf16", "fp32", "f16x3"):
+            raise ValueError("precision must be 'f16x3', 'fp32' or 'bf16'")
         self.cfg = cfg
         self.ops = ops if ops is not None else H.get_ops()        # raises without GPU + libpsalm_hip.so
         self.precision = precision
-        self.llm_fp8 = precision == "fp8"             # Phi projections on e4m3 MFMA (per-row scales); everything else as "bf16"
         self.x3 = precision == "f16x3"                # fp32 activations, GEMM operands in split-f16 form (hip_ops.SplitF16)
         self.wdt = torch.float32 if precision in ("fp32", "f16x3") else torch.bfloat16   # weight / GEMM-operand dtype
         self.adt = self.wdt                                                     # GEMM-feeding activation dtype
@@ -127,6 +127,15 @@ class PSALM:
         # f16x3: GEMM / attention outputs that feed another GEMM leave their kernel already in split-f16 operand form (psalm_gemm_x3_split,
         # psalm_*_attention*_split, psalm_gemm_x3_ln_split) instead of fp32 + a psalm_split_f16 pass.  False: the r02k data flow (tools/exp_modes.py A/B)
         self.fuse_split = precision == "f16x3"
+        # f16x3: the Phi decoder's GEMMs form their two cross terms (lo.hi + hi.lo, 2^-11 of the result) as ONE e4m3 dot product on the
+        # block-scaled fp8 matrix instruction (operand form "x8", csrc/common.h psalm_split_words): 2 instead of 3 f16-product equivalents
+        # for 2/3 of the path's GEMM flops.  Decided on numerics first (tools/exp_fp8cross.py, profiles/r03d_*: over 10 weight / input
+        # seeds the Phi stage in this arithmetic is indistinguishable from the three-product form -- mask logits move by 5e-6 of their
+        # range, mean mask IoU vs exact fp32 >= 0.99999 -- while the Swin and pixel-decoder GEMMs are NOT tolerant and keep three
+        # products).  Needs hidden and hidden + intermediate to be multiples of 128 and the fused operand hand-over (fuse_split).
+        Hd_, I_ = cfg.hidden_size, cfg.intermediate_size
+        can_x8 = self.fuse_split and Hd_ % 128 == 0 and (Hd_ + I_) % 128 == 0 and Hd_ <= 2048 and cfg.head_dim == 64 and cfg.rotary_dim == 32
+        self.llm_x8 = can_x8 if llm_cross_fp8 is None else (bool(llm_cross_fp8) and can_x8)
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.config = None                            # LlavaConfig when built by from_pretrained (llava_phi.py:34)
@@ -275,13 +284,9 @@ class PSALM:
             a = p + "self_attn."
             w1 = torch.cat([sd[a + "k_proj.weight"], sd[a + "v_proj.weight"], sd[a + "q_proj.weight"], sd[p + "mlp.fc1.weight"]], 0)
             w2 = torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1)
-            if self.llm_fp8:                          # e4m3fn bytes + per-row scales (bf16-rounded weights, like the bf16 mode sees them)
+            if self.llm_x8:                        # split-f16 with e4m3 cross-term halves (W operand form)
                 for nm, mat in (("w1", w1), ("w2", w2)):
-                    m = mat.detach().float().bfloat16().float()
-                    amax = m.abs().amax(1, keepdim=True)
-                    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-                    w[f"llm{i}.{nm}q"] = self._aligned((m * (1.0 / sc)).to(torch.float8_e4m3fn).view(torch.uint8).contiguous().to(self.device))
-                    w[f"llm{i}.{nm}s"] = Fp(sc.view(-1))
+                    w[f"llm{i}.{nm}"] = self.ops.split_f16(self._aligned(mat.detach().to(torch.float32).contiguous().to(self.device)), 2)
             else:
                 w[f"llm{i}.w1"] = W(w1)
                 w[f"llm{i}.w2"] = W(w2)
@@ -723,32 +728,28 @@ class PSALM:
             a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)
             inv2 = o.empty(B * L, dtype=torch.float32)
         fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
+        x8 = 1 if (self.llm_x8 and fuse_split) else 0   # operand form of this decoder's GEMMs (weights were prepared to match)
+        if self.llm_x8 and not fuse_split:
+            raise H.PsalmHipError("llm_cross_fp8: the Phi weights are in the x8 form but the fused operand hand-over is off")
         if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
-            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps)[1]
+            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, form=x8)[1]
         else:
             h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
             last = i == cfg.num_layers - 1
             ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
-            if self.llm_fp8:
-                hq, hs = o.quantize_rows_fp8(h)
-                o.gemm_fp8(hq, hs, w[f"llm{i}.w1q"], w[f"llm{i}.w1s"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
-                o.causal_attention(big, 2 * Hd, 0, Hd, big, 2 * Hd, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim, cfg.rotary_dim)
-                aq, as_ = o.quantize_rows_fp8(big[:, 2 * Hd:])                    # one row scale over [attn | gelu(fc1)]
-                x = o.gemm_fp8(aq, as_, w[f"llm{i}.w2q"], w[f"llm{i}.w2s"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
-                h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32 if last else self.adt)
-                continue
             if fuse_split:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
-                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True)
+                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=x8)
                 o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                         cfg.rotary_dim)
+                                         cfg.rotary_dim, split_form=x8)
                 if last or Hd % 64 != 0 or Hd > 2048:
-                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I, x8), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                     h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \
-                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps)[1]
+                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps, form=x8)[1]
                 else:                                 # residual GEMM + the next layer's LayerNorm + its split: one pass after the K slices
-                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb, cfg.layer_norm_eps)
+                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I, x8), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb,
+                                                 cfg.layer_norm_eps, split_form=x8)
                 continue
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place

@@ -35,7 +35,8 @@ def build():
 
 
 # (M, N, K, split-f16 output from column (None: fp32 output), activation)
-SHAPES = [(899, 14336, 2048, None, 0), (899, 14336, 2048, 6144, 3), (899, 2048, 10240, None, 0), (4096, 2048, 512, None, 0),
+SHAPES = [(899, 14336, 2048, None, 0), (899, 14336, 2048, 6144, 3), (899, 14336, 2048, 6144, 3, 1), (899, 2048, 10240, None, 0),
+          (899, 2048, 10240, None, 0, 1), (4096, 2048, 512, None, 0),
           (4096, 2048, 512, 0, 2), (4096, 512, 2048, None, 0), (5184, 1536, 512, None, 0), (5184, 512, 512, None, 0),
           (21504, 1024, 256, None, 0), (21504, 1024, 256, 0, 1), (21504, 256, 1024, None, 0), (21504, 256, 256, None, 0),
           (65536, 512, 128, None, 0), (100, 65536, 256, None, 0)]
@@ -51,10 +52,12 @@ def main():
     tl = torch.zeros(nslot * 8, dtype=torch.int64, device="cuda")
     assert ops._cdll_raw.psalm_gemm_timeline_buffer(ctypes.c_void_p(tl.data_ptr())) == 0
     out = {}
-    for M, N, K, so_from, act in SHAPES:
+    for shape in SHAPES:
+        M, N, K, so_from, act = shape[:5]
+        x8 = len(shape) > 5 and shape[5]                     # operands (and the emitted operand) in the x8 form: e4m3 cross terms
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
-        asp, wsp = ops.split_f16(a), ops.split_f16(w)
+        asp, wsp = (ops.split_f16(a, 1), ops.split_f16(w, 2)) if x8 else (ops.split_f16(a), ops.split_f16(w))
         c = torch.empty(M, N, device="cuda")
         bias = torch.randn(N, device="cuda")
         if so_from is not None:                              # the model's fused form: columns >= so_from leave as the next GEMM's split-f16 operand
@@ -64,17 +67,18 @@ def main():
             bnd = torch.tensor([2.0 ** 14 * float(w.abs().sum(1).max()), float(bias.abs().max()), 0.0, 0.0], device="cuda")
 
             def launch():
-                ops.gemm_x3_split(asp, wsp, bias, act, so, so_inv, bnd, split_col_off=2048, split_col_start=so_from, act_col_start=so_from, out=c)
+                ops.gemm_x3_split(asp, wsp, bias, act, so, so_inv, bnd, split_col_off=2048, split_col_start=so_from, act_col_start=so_from, out=c,
+                                  split_form=1 if x8 else 0)
         else:
             def launch():
                 ops.gemm_x3(asp, wsp, out=c)
         big = torch.empty(64 << 20, device="cuda")        # 256 MB: evicts the operands from the Infinity Cache between cold launches
         row = {}
-        for name, pol in POLICIES:
+        for name, pol in (POLICIES[:1] if x8 else POLICIES):
             for p in pol:
                 ops.gemm_tile_policy(p)
             try:
-                desc = ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)
+                desc = ops.gemm_describe(M, N, 2 * asp.Kp, x8=True) if x8 else ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)
                 res = {}
                 for mode in ("warm", "cold"):
                     for _ in range(2):
@@ -111,7 +115,7 @@ def main():
             finally:
                 for p in (1282, 640, 3300, 0):
                     ops.gemm_tile_policy(p)
-        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "")
+        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "") + (" x8" if x8 else "")
         out[key] = row
         print(key, json.dumps(row), flush=True)
         del a, w, asp, wsp, c, big
