@@ -1,0 +1,87 @@
+"""Parity of the GPU path against the CPU oracle over several (weight seed, input seed) pairs -- VERDICT r02 weak #1: one image per config is
+a noisy gate (0.3 % positive pixels, ~10 empty reference masks, a 16-pixel mask whose logits sit inside fp32 summation noise flips under ANY
+reordering).  Per pair and mode: mean / min / pooled mask IoU, pixel, semantic-argmax and panoptic-id agreement, mask-logit error, and the
+number of reference masks below 64 pixels (whose IoU is quantised in steps of 1/area).
+
+    python tools/parity_seeds.py [task=panoptic] [size=1024] [pairs=0:0,0:1,0:2,1:1,2:2]  -> one JSON line per (pair, mode) + a summary line
+Modes: "f16x3" (default product mode: Phi GEMM cross terms in e4m3) and "f16x3-3p" (three f16 products everywhere)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def compare(g, w_):
+    gm, wm = g["mask_pred"].cpu() > 0, w_["mask_pred"] > 0
+    inter = (gm & wm).flatten(1).sum(1).float()
+    union = (gm | wm).flatten(1).sum(1).float()
+    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
+    area = wm.flatten(1).sum(1)
+    big = area >= 64
+    out = {"mask_iou_mean": round(float(iou.mean()), 6), "mask_iou_min": round(float(iou.min()), 5),
+           "mask_iou_mean_area_ge_64": round(float(iou[big].mean()), 6) if bool(big.any()) else None,
+           "mask_iou_pooled": round(float(inter.sum() / union.sum().clamp(min=1)), 6),
+           "flipped_pixels": int((gm != wm).sum()), "ref_positive_pixels": int(wm.sum()), "ref_masks_empty": int((area == 0).sum()),
+           "ref_masks_lt_64px": int(((area > 0) & ~big).sum()),
+           "mask_logit_rel_err": float(f"{((g['mask_pred'].cpu() - w_['mask_pred']).abs().max() / w_['mask_pred'].abs().max()).item():.3e}"),
+           "mask_pixel_agreement": round(float((gm == wm).float().mean()), 7)}
+    if "sem_seg" in g:
+        out["semantic_argmax_agreement"] = round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6)
+    if "panoptic_seg" in g:
+        out["panoptic_id_agreement"] = round(float((g["panoptic_seg"][0].cpu() == w_["panoptic_seg"][0]).float().mean()), 6)
+        out["panoptic_segments"] = [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]
+    return out
+
+
+def main():
+    task = sys.argv[1] if len(sys.argv) > 1 else "panoptic"
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    pairs = [tuple(int(x) for x in p.split(":")) for p in (sys.argv[3] if len(sys.argv) > 3 else "0:0,0:1,0:2,1:1,2:2").split(",")]
+    batch = int(os.environ.get("PARITY_BATCH", "1"))
+    from oracle import psalm_oracle as O
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = PsalmConfig(seg_task=task)
+    rows, sd_seed, models = [], None, {}
+    for wseed, iseed in pairs:
+        if wseed != sd_seed:
+            models.clear()
+            torch.cuda.empty_cache()
+            sd = make_state_dict(cfg, seed=wseed)
+            sd_seed = wseed
+            models = {"f16x3": PSALM(cfg, sd, precision="f16x3"), "f16x3-3p": PSALM(cfg, sd, precision="f16x3", llm_cross_fp8=False)}
+        inputs = make_inputs(cfg, task, size=size, batch=batch, seed=iseed)
+        t0 = time.perf_counter()
+        torch.manual_seed(1234)
+        want = O.eval_seg(sd, cfg, **inputs)
+        t_cpu = time.perf_counter() - t0
+        for mode, m in models.items():
+            torch.manual_seed(1234)
+            got = m.eval_seg(**inputs)
+            torch.cuda.synchronize()
+            for b in range(len(got)):
+                r = {"task": task, "size": size, "weights_seed": wseed, "inputs_seed": iseed, "image": b, "mode": mode, "llm_x8": bool(m.llm_x8),
+                     **compare(got[b], want[b]), "oracle_seconds": round(t_cpu, 1)}
+                rows.append(r)
+                print(json.dumps(r), flush=True)
+    summ = {}
+    for mode in ("f16x3", "f16x3-3p"):
+        rs = [r for r in rows if r["mode"] == mode]
+        summ[mode] = {"pairs": len(rs), "mask_iou_mean_min_over_seeds": min(r["mask_iou_mean"] for r in rs),
+                      "mask_iou_pooled_min_over_seeds": min(r["mask_iou_pooled"] for r in rs),
+                      "mask_iou_mean_area_ge_64_min_over_seeds": min((r["mask_iou_mean_area_ge_64"] for r in rs if r["mask_iou_mean_area_ge_64"] is not None), default=None),
+                      "mask_logit_rel_err_max": max(r["mask_logit_rel_err"] for r in rs),
+                      "semantic_argmax_agreement_min": min((r.get("semantic_argmax_agreement", 1.0) for r in rs)),
+                      "panoptic_id_agreement_min": min((r.get("panoptic_id_agreement", 1.0) for r in rs))}
+    print(json.dumps({"summary": summ}))
+
+
+if __name__ == "__main__":
+    main()
