@@ -26,7 +26,11 @@ import os
 import sys
 import time
 
-import torch
+# RCCL's inter-process buffers travel as dmabuf handles on this stack; the legacy IPC mode fails with `hipIpcGetMemHandle: invalid
+# argument`.  Set before the HIP / HSA runtime initialises (first GPU call) -- for ranks launched by the driver's own torchrun line too.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -87,12 +91,14 @@ def main():
         assert dist.get_world_size() == args.gpus
 
     from psalm_amd.config import PsalmConfig
-    from psalm_amd.dist import broadcast_weights
+    from psalm_amd.dist import broadcast_weights, check_weights_identical
     from psalm_amd.model import PSALM
     from psalm_amd.synthetic import make_inputs, make_state_dict
 
     cfg = PsalmConfig(seg_task="panoptic")
-    sd = make_state_dict(cfg, seed=0)
+    # rank 0 owns the (seeded) checkpoint; the other ranks build their weight arena from placeholders of the same shapes and receive
+    # rank 0's prepared weights through the broadcast -- which is thereby real, not a copy of identical data onto itself
+    sd = make_state_dict(cfg, seed=0, shapes_only=rank != 0)
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
     model_info = type("I", (), {"llm_x8": bool(getattr(model, "llm_x8", False))})      # (the model object itself is released before the JSON line)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
@@ -103,7 +109,13 @@ def main():
     bcast = None
     if world > 1:
         nbytes, secs = broadcast_weights(model, src=0)          # RCCL over xGMI, one-off
-        bcast = {"bytes": int(nbytes), "seconds": round(secs, 4), "GB_per_s": round(nbytes / max(secs, 1e-9) / 1e9, 1)}
+        same, csum = check_weights_identical(model)             # MIN / MAX all-reduce of a checksum over every weight byte
+        bcast = {"bytes": int(nbytes), "seconds": round(secs, 4), "GB_per_s": round(nbytes / max(secs, 1e-9) / 1e9, 1),
+                 "weights_identical": bool(same), "checksum": csum}
+        if not same:
+            raise SystemExit(f"bench.py: rank {rank}: weights differ across ranks after the broadcast")
+        if rank != 0:
+            del sd                                              # placeholders are not needed any more
     inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
     inputs["images"] = inputs["images"].cuda()                  # inputs resident in HBM before the timed region
 
@@ -124,10 +136,13 @@ def main():
         out = model.eval_seg(**inputs)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                            # each rank's own wall time for its K steps
+        per_rank = [args.steps / float(t_.item()) for t_ in every]
+        dt = max(float(t_.item()) for t_ in every)              # the job is done when its slowest rank is
 
     # ---- instrumented steps (not part of `value`): HIP events (torch's current stream = the launch stream) around every
     # C-ABI launch, attributed to kernel instantiations through psalm_gemm_describe (the library's own selection function)
@@ -338,6 +353,7 @@ def main():
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": side, "weight_broadcast": bcast,
+            "per_rank_images_per_s": ({"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)} if per_rank else None),
         }
         print(json.dumps(line))
     if world > 1:

@@ -65,6 +65,43 @@ def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple
     return total, time.perf_counter() - t0
 
 
+def _flat_weights(model):
+    W = {}
+    for k, v in model.w.items():
+        if hasattr(v, "inv_scale"):          # hip_ops.SplitF16 (precision="f16x3")
+            W[k + "#f16"], W[k + "#inv_scale"] = v.t, v.inv_scale
+        elif torch.is_tensor(v):
+            W[k] = v
+    return W
+
+
+def weights_checksum(model) -> int:
+    """Order-independent integer checksum of every prepared weight tensor's BYTES (sum of the 16-bit words, per tensor weighted by a
+    name hash): equal on two ranks iff -- up to a 2^-60-ish collision -- their weight arenas are bit-identical."""
+    total = 0
+    for k, t in sorted(_flat_weights(model).items()):
+        t = t.contiguous()
+        nb = t.numel() * t.element_size()
+        words = t.view(torch.int16) if nb % 2 == 0 else t.view(torch.uint8)
+        h = sum((i + 1) * ord(c) for i, c in enumerate(k)) % 1000003 + 1
+        total = (total + h * int(words.sum(dtype=torch.int64).item())) % (1 << 61)
+    return total
+
+
+def check_weights_identical(model, device=None) -> Tuple[bool, int]:
+    """All ranks hold the same weights?  MIN / MAX all-reduce of the per-rank checksum (two 31-bit halves: exact in any backend)."""
+    c = weights_checksum(model)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return True, c
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    halves = torch.tensor([c >> 31, c & ((1 << 31) - 1)], dtype=torch.int64, device=device)
+    lo, hi = halves.clone(), halves.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi)), c
+
+
 def reduce_metrics(values: torch.Tensor) -> torch.Tensor:
     """SUM all-reduce of a small vector (float32 / float64, on the device the process group's backend reduces on), e.g.
     [intersection, union, count] -- the role of AverageMeter.all_reduce in the reference's eval scripts

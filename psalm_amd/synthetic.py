@@ -33,14 +33,19 @@ MASK_LOGIT_OFFSET = 24.0
 
 
 class _Gen:
-    def __init__(self, seed: int):
+    def __init__(self, seed: int, shapes_only: bool = False):
         self.g = torch.Generator(device="cpu")
         self.g.manual_seed(seed)
+        self.shapes_only = shapes_only          # placeholders of the right shapes (means / mid-range values), no random numbers drawn
 
     def normal(self, *shape, std=1.0, mean=0.0):
+        if self.shapes_only:
+            return torch.full(shape, float(mean), dtype=torch.float32)
         return torch.randn(*shape, generator=self.g, dtype=torch.float32) * std + mean
 
     def uniform(self, *shape, lo=0.0, hi=1.0):
+        if self.shapes_only:
+            return torch.full(shape, 0.5 * (lo + hi), dtype=torch.float32)
         return torch.rand(*shape, generator=self.g, dtype=torch.float32) * (hi - lo) + lo
 
     def linear(self, sd, name, out_f, in_f, gain=1.0, bias=True, bias_std=0.05):
@@ -74,9 +79,11 @@ def relative_position_index(ws: int) -> torch.Tensor:
 
 
 def make_state_dict(cfg: PsalmConfig, seed: int = 0, include_lm_head: bool = False,
-                    extra_vocab: int = 2) -> Dict[str, torch.Tensor]:
-    """fp32 CPU state dict in the reference checkpoint layout (SURVEY.md §5 'checkpoint / resume')."""
-    g = _Gen(seed)
+                    extra_vocab: int = 2, shapes_only: bool = False) -> Dict[str, torch.Tensor]:
+    """fp32 CPU state dict in the reference checkpoint layout (SURVEY.md §5 'checkpoint / resume').
+    shapes_only: constant placeholders of the same names / shapes (what the ranks > 0 of a multi-GPU job build their weight
+    arena from before rank 0's weights arrive by broadcast -- no 1.6 G random numbers drawn per rank)."""
+    g = _Gen(seed, shapes_only)
     sd: Dict[str, torch.Tensor] = {}
     H = cfg.hidden_size
     V = cfg.vocab_size + extra_vocab            # tokenizer adds [SEG] etc. (train.py); 51202 in practice

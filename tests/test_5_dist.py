@@ -140,3 +140,70 @@ def test_two_rank_real_model_broadcast_and_sharded_eval():
     want = {i: float(m.eval_seg(**make_inputs(cfg, "referring", size=96, batch=1, seed=40 + i))[0]["mask_pred"].double().sum()) for i in range(2)}
     got = dict(res[0]["digest"] + res[1]["digest"])
     assert got == want
+
+
+def _worker_four(rank, world, port, q):
+    """bench.py's start-up protocol on 4 ranks: rank 0 owns the checkpoint, the others build their arena from shape-only placeholders,
+    one broadcast, a checksum MIN / MAX all-reduce proves the arenas identical; then 6 images (not a multiple of 4) round-robin."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "emu")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ops_backend import make_ops
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.dist import broadcast_weights, check_weights_identical, shard_indices, weights_checksum
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    ops = make_ops("emu")
+    cfg = PsalmConfig.tiny("panoptic")
+    model = PSALM(cfg, make_state_dict(cfg, seed=7, shapes_only=rank != 0), ops=ops, precision="f16x3")
+    before = weights_checksum(model)
+    same_before, _ = check_weights_identical(model)
+    nbytes, _ = broadcast_weights(model, src=0, bucket_bytes=1 << 18)
+    same_after, csum = check_weights_identical(model)
+    mine = shard_indices(6, rank, world)
+    digest = []
+    for i in mine:
+        inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=60 + i, num_classes=9)
+        r = model.eval_seg(**inputs)[0]
+        digest.append((i, float(r["mask_pred"].double().sum()), int(r["panoptic_seg"][0].to(torch.int64).sum())))
+    q.put({"rank": rank, "before": before, "same_before": same_before, "same_after": same_after, "csum": csum, "nbytes": nbytes, "mine": mine,
+           "digest": digest})
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_four_ranks_placeholder_arenas_broadcast_checksum_and_ragged_shards():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from ops_backend import make_ops
+    ops = make_ops("emu")
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_four, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in ps), key=lambda d: d["rank"])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert not any(r["same_before"] for r in res)                         # placeholders != rank 0's weights: the check can fail
+    assert res[1]["before"] == res[2]["before"] == res[3]["before"] != res[0]["before"]
+    assert all(r["same_after"] for r in res) and len({r["csum"] for r in res}) == 1 and res[0]["csum"] == res[0]["before"]
+    assert [r["mine"] for r in res] == [[0, 4], [1, 5], [2], [3]]
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    cfg = PsalmConfig.tiny("panoptic")
+    m = PSALM(cfg, make_state_dict(cfg, seed=7), ops=ops, precision="f16x3")
+    want = {}
+    for i in range(6):
+        r = m.eval_seg(**make_inputs(cfg, "panoptic", size=96, batch=1, seed=60 + i, num_classes=9))[0]
+        want[i] = (float(r["mask_pred"].double().sum()), int(r["panoptic_seg"][0].to(torch.int64).sum()))
+    got = {i: (a, b) for r in res for i, a, b in r["digest"]}
+    assert got == want
