@@ -39,8 +39,8 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBPS = 8000.0         # HBM3E, same guide
 # HBM bytes per launch per kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload (tools/gpu_profile.sh ->
 # tools/make_traffic_json.py); the file of the current round if present, else the previous round's (bf16 kernels only)
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"))
-                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json"))
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"))
+                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json"))
 
 
 def main():
@@ -170,52 +170,31 @@ def main():
         torch.cuda.synchronize()
         ev_over = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2]
         agg, shapes, kern = {}, {}, {}
-        for name, a, e0, e1 in recs:
+        for name, a, e0, e1, kname in recs:
             ms = e0.elapsed_time(e1)              # raw event time: agrees with the rocprofv3 kernel-trace durations for long kernels
             d = agg.setdefault(name, [0, 0.0])
             d[0] += 1
             d[1] += ms
+            # (M, N, algorithmic K) of a matrix-core GEMM from its launch arguments; the KERNEL is named by the library itself
+            # (psalm_gemm_last_kernel: the exact template instantiation, as a rocprofv3 kernel trace spells it)
             geo = None
             if name in ("psalm_gemm", "psalm_gemm_ln") and a[4] == 1:            # w_dtype == bf16 -> MFMA bf16 arithmetic
-                geo = (a[12], a[13], a[14], a[1] == 1, a[10] == 1, "")
+                geo = (a[12], a[13], a[14])
             elif name == "psalm_conv2d_nhwc":                                     # implicit GEMM: M = B*Ho*Wo, N = Cout, K = k*k*Cin
                 B_, H_, W_, Cin, Cout, ks, st, pd_ = a[1], a[2], a[3], a[4], a[6], a[7], a[8], a[9]
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
-                geo = (B_ * Ho * Wo, Cout, ks * ks * Cin, True, a[14] == 1, ",conv")
-            x3 = name in ("psalm_gemm_x3", "psalm_gemm_x3_split", "psalm_gemm_x3_ln_split")
-            x8 = x3 and a[7] != 0                                                 # operand form argument (after Kp): e4m3 cross terms, K range 2*Kp
-            if name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):              # split-f16 GEMM: the kernel's K range is 3*Kp (x8: 2*Kp)
-                geo = (a[13], a[14], (2 if x8 else 3) * a[6], True, False, ",x8" if x8 else ",x3")
-            elif x3:                                                             # ... with the split-f16 output epilogue (same K loop)
-                geo = (a[11], a[12], (2 if x8 else 3) * a[6], True, False, ",x8" if x8 else ",x3")
-            if geo is not None:
-                M, N, K, a_bf16, c_bf16, tag = geo
-                path, BM, BN, splits = model.ops.gemm_describe(M, N, K, a_bf16, True, x3=x3 and not x8, x8=x8)
-                if x3:
-                    K = a[6]                                                      # ALGORITHMIC flops: 2 M N K of the fp32 product it stands for
-                if name == "psalm_gemm_x3_split":                                 # always the tiled kernel, never split-K
-                    path, splits = 1, 1
-                    if M <= 128 and not x8:
-                        BM, BN = 64, 128
-                if path == 2 and name in ("psalm_gemm", "psalm_gemm_x3"):
-                    kname = f"gemm_bf16_skinny_kernel<{'bf16' if c_bf16 else 'f32'}{tag}>"
-                elif path == 1 or path == 2:
-                    if path == 2:                             # psalm_gemm_ln has no skinny variant: it takes the tiled path
-                        BM, BN, splits = (64, 128, 1)
-                    kname = f"gemm_bf16_glds_kernel<{'bf16' if (c_bf16 and splits == 1) else 'f32'},{BM},{BN},2,{4 if BM == 256 else 2}{tag}>"
-                    if splits > 1:
-                        kname += " + splitk_reduce_ln_kernel" if name in ("psalm_gemm_ln", "psalm_gemm_x3_ln_split") else " + splitk_reduce_kernel"
-                    elif name == "psalm_gemm_ln":
-                        kname += " + layernorm_vec_kernel"
-                    elif name == "psalm_gemm_x3_ln_split":
-                        kname += " + layernorm_split_kernel"
-                else:
-                    kname = f"gemm_bf16_kernel<{'bf16' if a_bf16 else 'f32'},{'bf16' if c_bf16 else 'f32'},{BM}>"
+                geo = (B_ * Ho * Wo, Cout, ks * ks * Cin)
+            elif name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):            # split-f16 GEMM: ALGORITHMIC flops 2 M N Kp of the fp32 product it stands for
+                geo = (a[13], a[14], a[6])
+            elif name == "psalm_gemm_x3_split":
+                geo = (a[11], a[12], a[6])
+            if geo is not None and kname and "mfma" not in kname and ("glds" in kname or "skinny_kernel<float, true>" in kname or "gemm_bf16" in kname):
+                M, N, K = geo
                 kd = kern.setdefault(kname, [0, 0.0, 0.0])
                 kd[0] += 1
                 kd[1] += ms
                 kd[2] += 2.0 * M * N * K
-                sh = shapes.setdefault(f"M{M} N{N} K{K} a{'bf16' if a_bf16 else 'f32'} c{'bf16' if c_bf16 else 'f32'} -> {kname}", [0, 0.0, 2.0 * M * N * K])
+                sh = shapes.setdefault(f"M{M} N{N} K{K} -> {kname}", [0, 0.0, 2.0 * M * N * K])
                 sh[0] += 1
                 sh[1] += ms
         breakdown = {k: {"launches_per_step": v[0] / nprof, "ms_per_step": v[1] / nprof} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
@@ -228,9 +207,11 @@ def main():
         #   semantic_from_masks: read (Q, HW) f32 logits once + write (C, HW) f32                      
         #   msda_fused: per (b, q): value row in (D*M) + offsets/logits (M*L*P*3 f32) + out row         (compulsory bytes)
         hbm = {}
-        for name, a, e0, e1 in recs:
+        for name, a, e0, e1, _k in recs:
             if name == "psalm_semantic_from_masks":
                 nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_kernel"
+            elif name == "psalm_semantic_from_masks_x3":                          # (mask, probsT, out, mask_score, workspace, Q, C, HW, Kpad, stream)
+                nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_x3_kernel"
             elif name == "psalm_msda_fused":
                 esz_v, esz_o = (2 if a[1] == 1 else 4), (2 if a[6] == 1 else 4)
                 B_, S_, M_, D_, L_, P_ = a[7], a[8], a[9], a[10], a[11], a[12]
@@ -249,7 +230,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f).get("kernels", {})
             hbm_roof = [{"kernel": k, "bound": "hbm", "achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": tj.get(k, {}).get("hbm_bytes_per_launch"),
+                         "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": next((v_.get("hbm_bytes_per_launch") for kk_, v_ in tj.items() if kk_.startswith(k.replace("_kernel", ""))), None),
                          "algorithmic_bytes_per_launch": v[2] // v[0], "launches_per_step": v[0] / nprof,
                          "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])]
         if kern:
@@ -265,10 +246,11 @@ def main():
             if os.path.exists(tpath):                                            # (tools/gpu_final.sh + tools/make_traffic_json.py)
                 with open(tpath) as f:
                     tj = json.load(f).get("kernels", {})
-                if kname in tj:
-                    traffic = tj[kname].get("hbm_bytes_per_launch")
-            is_x3 = ",x3" in kname or ",x8" in kname
-            prods = 2 if ",x8" in kname else 3                                   # f16-product equivalents issued per algorithmic product
+                traffic = tj.get(kname.split(" + ")[0], {}).get("hbm_bytes_per_launch")
+            targs = [t.strip() for t in kname.split("<", 1)[1].split(">", 1)[0].split(",")] if "glds_kernel<" in kname else []
+            x3_form = int(targs[9]) if len(targs) >= 11 else 0                   # template argument X3: 1 / 2 split-f16 (3 products), 3 = x8 form
+            is_x3 = x3_form != 0
+            prods = 2 if x3_form == 3 else 3                                     # f16-product equivalents issued per algorithmic product
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues " +

@@ -188,6 +188,9 @@ int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k
                                      const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
                                      void* stream);
 
+/* Template instantiation (as a kernel trace names it, e.g. "gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3, true>") of the
+ * calling thread's most recent GEMM launch through psalm_gemm / psalm_gemm_x3* / psalm_conv2d_nhwc / psalm_gemm_ln. */
+const char* psalm_gemm_last_kernel(void);
 /* Which kernel psalm_gemm launches for a problem size: out4 = {path (0 register-staged, 1 direct-to-LDS), BM, BN, split-K slices}. */
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;

@@ -23,6 +23,7 @@
 // blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (sharing the A row-panel) are placed on the
 // same XCD (block b runs on XCD b % 8) so the panel is fetched into that XCD's L2 once.
 #include "common.h"
+#include <cstring>
 #include <type_traits>
 
 #define ACT_NONE 0
@@ -1471,6 +1472,8 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
 // (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
 static int g_tile_policy = 0;
+static thread_local char g_last_kernel[192] = "";    // template instantiation of the calling thread's last direct-to-LDS launch
+extern "C" const char* psalm_gemm_last_kernel() { return g_last_kernel; }
 static long g_skinny_nmax = 4096;    // skinny kernel for M <= 128 and N <= this
 static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
 // operand-ring depth of the 64x128 configuration: 0 = automatic (3 when the K range of a block is >= 1024: with <= 1 block per CU the
@@ -1620,84 +1623,68 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
                          (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
     const dim3 grid((unsigned)tiles, splits);
     const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
-#define LAUNCH_GLDS(BM_, BN_, WM_, WN_, NS_, CV_)                                                                            \
-    do {                                                                                                                     \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, CV_>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
+    // every launch goes through GO(): it records the exact template instantiation (psalm_gemm_last_kernel: the name a kernel trace shows,
+    // so that per-kernel attributions made from launch arguments -- bench.py -- agree with rocprofv3) and launches it
+#define GO(NT_, TCN_, TC_, ...)                                                                                                              \
+    do {                                                                                                                                     \
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_bf16_glds_kernel<" TCN_ ", " #__VA_ARGS__ ">");                                 \
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<TC_, __VA_ARGS__>), grid, dim3(NT_), 0, s, fa);                                           \
     } while (0)
-#define LAUNCH_GLDS128(BM_, BN_, WM_, WN_)                                                                                   \
-    do {                                                                                                                     \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, 2, false, 128>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, 2, false, 128>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
-    } while (0)
-#define LAUNCH_GLDS32(BM_, BN_, WM_, WN_, NS_)                                                                               \
-    do {                                                                                                                     \
-        if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);  \
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, BM_, BN_, WM_, WN_, NS_, false, 32>), grid, dim3(64 * WM_ * WN_), 0, s, fa);        \
-    } while (0)
+    // (BM, BN, WM, WN, NS, CONV, BK, PH8, X3, SO) in the output type the call needs (fp32 results / slabs, or bf16)
+#define GO_T(NT_, ...) do { if (f32out) GO(NT_, "float", float, __VA_ARGS__); else GO(NT_, "unsigned short", bf16_t, __VA_ARGS__); } while (0)
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
-#define LAUNCH_X3S(BM_, BN_, WM_, WN_, NS_, BK_) \
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, BK_, 0, 2>), grid, dim3(64 * WM_ * WN_), 0, s, fa)
-        if (BM == 128 && slice == 2) LAUNCH_X3S(128, 128, 2, 2, 4, 32);
-        else if (BM == 128) LAUNCH_X3S(128, 128, 2, 2, 2, 64);
-        else if (slice == 2) LAUNCH_X3S(64, 128, 2, 2, 4, 32);
-        else LAUNCH_X3S(64, 128, 2, 2, 2, 64);
-#undef LAUNCH_X3S
+        if (BM == 128 && slice == 2) GO(256, "float", float, 128, 128, 2, 2, 4, false, 32, 0, 2, false);
+        else if (BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 2, false);
+        else if (slice == 2) GO(256, "float", float, 64, 128, 2, 2, 4, false, 32, 0, 2, false);
+        else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);
     } else if (x8) {                                              // split-f16 operands with e4m3 cross-term halves (K range 2 Kp)
         if (fa.k_per_split < 128 || (K - (splits - 1) * fa.k_per_split) < 128) { psalm_set_error("psalm_gemm_x3 (x8): K range too short"); return -1; }
-        if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3, true>), grid, dim3(512), 0, s, fa);
-        else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3>), grid, dim3(512), 0, s, fa);
+        if (fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true);
+        else GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, false);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
-#define LAUNCH_X3(BM_, BN_, WM_, WN_, NS_, PH_)                                                                                                        \
-        do {                                                                                                                                           \
-            if (fa.so) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, PH_, 1, true>), grid,               \
-                                          dim3(64 * WM_ * WN_), 0, s, fa);                                                                             \
-            else hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, BM_, BN_, WM_, WN_, NS_, false, 64, PH_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, fa); \
-        } while (0)
-        if (BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128) LAUNCH_X3(256, 256, 2, 4, 2, 3);
-        else if (BM == 256) LAUNCH_X3(256, 256, 2, 4, 2, 0);
-        else if (BM == 128 && g_ring_depth == 3) LAUNCH_X3(128, 128, 2, 2, 3, 0);
-        else if (BM == 128) LAUNCH_X3(128, 128, 2, 2, 2, 0);
-        else if ((g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2)) >= 3) LAUNCH_X3(64, 128, 2, 2, 3, 0);
-        else LAUNCH_X3(64, 128, 2, 2, 2, 0);
-#undef LAUNCH_X3
+        const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
+        const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
+#define GO_X3(NT_, ...) do { if (fa.so) GO(NT_, "float", float, __VA_ARGS__, true); else GO(NT_, "float", float, __VA_ARGS__, false); } while (0)
+        if (ph) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 3, 1);
+        else if (BM == 256) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 0, 1);
+        else if (BM == 128 && g_ring_depth == 3) GO_X3(256, 128, 128, 2, 2, 3, false, 64, 0, 1);
+        else if (BM == 128) GO_X3(256, 128, 128, 2, 2, 2, false, 64, 0, 1);
+        else if (ring64 >= 3) GO_X3(256, 64, 128, 2, 2, 3, false, 64, 0, 1);
+        else GO_X3(256, 64, 128, 2, 2, 2, false, 64, 0, 1);
+#undef GO_X3
     } else if (conv) {
-        if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, true);
-        else if (BM == 128) LAUNCH_GLDS(128, 128, 2, 2, 2, true);
-        else LAUNCH_GLDS(64, 128, 2, 2, 2, true);
+        if (BM == 256) GO_T(512, 256, 256, 2, 4, 2, true, 64, 0, 0, false);
+        else if (BM == 128) GO_T(256, 128, 128, 2, 2, 2, true, 64, 0, 0, false);
+        else GO_T(256, 64, 128, 2, 2, 2, true, 64, 0, 0, false);
     } else {
         if (BM == 256 && g_ph8 && fa.k_per_split % 64 == 0 && K % 64 == 0 && fa.k_per_split >= 128 &&
             (K - (splits - 1) * fa.k_per_split) >= 128) {
-            if (g_ph8 == 1) {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 1>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 1>), grid, dim3(512), 0, s, fa);
-            } else if (g_ph8 == 2) {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 2>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 2>), grid, dim3(512), 0, s, fa);
-            } else {
-                if (f32out) hipLaunchKernelGGL((gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3>), grid, dim3(512), 0, s, fa);
-                else hipLaunchKernelGGL((gemm_bf16_glds_kernel<bf16_t, 256, 256, 2, 4, 2, false, 64, 3>), grid, dim3(512), 0, s, fa);
-            }
+            if (g_ph8 == 1) GO_T(512, 256, 256, 2, 4, 2, false, 64, 1, 0, false);
+            else if (g_ph8 == 2) GO_T(512, 256, 256, 2, 4, 2, false, 64, 2, 0, false);
+            else GO_T(512, 256, 256, 2, 4, 2, false, 64, 3, 0, false);
         }
-        else if (BM == 256) LAUNCH_GLDS(256, 256, 2, 4, 2, false);
-        else if (BM == 128 && BN == 64) LAUNCH_GLDS(128, 64, 2, 2, 2, false);
+        else if (BM == 256) GO_T(512, 256, 256, 2, 4, 2, false, 64, 0, 0, false);
+        else if (BM == 128 && BN == 64) GO_T(256, 128, 64, 2, 2, 2, false, 64, 0, 0, false);
         else if (BM == 128) {
-            if (g_ring_depth == 3) LAUNCH_GLDS(128, 128, 2, 2, 3, false);
-            else if (g_ring_depth == 128 && K % 128 == 0 && fa.k_per_split % 128 == 0) LAUNCH_GLDS128(128, 128, 2, 2);
-            else if (g_ring_depth == 324) LAUNCH_GLDS32(128, 128, 2, 2, 4);
-            else if (g_ring_depth == 323) LAUNCH_GLDS32(128, 128, 2, 2, 3);
-            else LAUNCH_GLDS(128, 128, 2, 2, 2, false);
+            if (g_ring_depth == 3) GO_T(256, 128, 128, 2, 2, 3, false, 64, 0, 0, false);
+            else if (g_ring_depth == 128 && K % 128 == 0 && fa.k_per_split % 128 == 0) GO_T(256, 128, 128, 2, 2, 2, false, 128, 0, 0, false);
+            else if (g_ring_depth == 324) GO_T(256, 128, 128, 2, 2, 4, false, 32, 0, 0, false);
+            else if (g_ring_depth == 323) GO_T(256, 128, 128, 2, 2, 3, false, 32, 0, 0, false);
+            else GO_T(256, 128, 128, 2, 2, 2, false, 64, 0, 0, false);
         }
         else {
             const int ring = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
-            if (ring == 4) LAUNCH_GLDS(64, 128, 2, 2, 4, false);
-            else if (ring == 3) LAUNCH_GLDS(64, 128, 2, 2, 3, false);
-            else LAUNCH_GLDS(64, 128, 2, 2, 2, false);
+            if (ring == 4) GO_T(256, 64, 128, 2, 2, 4, false, 64, 0, 0, false);
+            else if (ring == 3) GO_T(256, 64, 128, 2, 2, 3, false, 64, 0, 0, false);
+            else GO_T(256, 64, 128, 2, 2, 2, false, 64, 0, 0, false);
         }
     }
-#undef LAUNCH_GLDS
-#undef LAUNCH_GLDS32
-#undef LAUNCH_GLDS128
+#undef GO_T
+#undef GO
+    auto also = [&](const char* k2) { strncat(g_last_kernel, " + ", sizeof(g_last_kernel) - strlen(g_last_kernel) - 1);
+                                      strncat(g_last_kernel, k2, sizeof(g_last_kernel) - strlen(g_last_kernel) - 1); };
+    if (splits > 1) also(ln ? "splitk_reduce_ln_kernel" : "splitk_reduce_kernel");
+    else if (ln) also(ln->split_out ? "layernorm_split_kernel" : "layernorm_vec_kernel");
     if (splits > 1) {
         if (ln && ln->split_out) {                                // ... + the normalised rows in split-f16 form (psalm_gemm_x3_ln_split)
 #define RLNS_LAUNCH(NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<float, NV_, true>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
@@ -1786,6 +1773,7 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         // ---- skinny path: latency-bound GEMMs of the predictor (measured r1x: ~3 us vs ~10 us per launch)
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_bf16_skinny_kernel<%s, false>", c_dtype == PSALM_F32 ? "float" : "unsigned short");
         if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float>), grid, dim3(256), 0, s, g, SkinnyX3{nullptr, nullptr, 0});
         else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<bf16_t>), grid, dim3(256), 0, s, g, SkinnyX3{nullptr, nullptr, 0});
         PSALM_LAUNCH_END("psalm_gemm");
@@ -1803,6 +1791,7 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     if (a_dtype == PSALM_F32 && w_dtype == PSALM_F32 && M <= 192 && N <= 8192 && K % 8 == 0 && !g_tile_policy) {
         // ---- exact-fp32 skinny path (mask-decoder GEMMs with M = 100 query rows in the fp32 / f16x3 modes)
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_skinny_kernel<%s, %d>", c_dtype == PSALM_F32 ? "float" : "unsigned short", K >= 256 ? 16 : 4);
         if (K >= 256) {                                           // 16 wavefronts split K
             if (c_dtype == PSALM_F32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<float, 16>), grid, dim3(1024), 0, s, g);
             else hipLaunchKernelGGL((gemm_f32_skinny_kernel<bf16_t, 16>), grid, dim3(1024), 0, s, g);
@@ -1819,6 +1808,8 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     const int BM = small ? 64 : 128;
     g.tiles_m = cdiv(M, BM);
     const dim3 grid(g.tiles_m * g.tiles_n), block(256);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s%s, %d>", w_dtype == PSALM_BF16 ? "gemm_bf16_kernel" : "gemm_f32_kernel",
+             w_dtype == PSALM_BF16 ? (a_dtype == PSALM_F32 ? "float, " : "unsigned short, ") : "", c_dtype == PSALM_F32 ? "float" : "unsigned short", BM);
 #define LAUNCH_BF16(TA, TC)                                                                             \
     do {                                                                                                \
         if (BM == 128) hipLaunchKernelGGL((gemm_bf16_kernel<TA, TC, 128>), grid, block, 0, s, g);     \
@@ -2024,6 +2015,7 @@ static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const vo
     hipStream_t s = (hipStream_t)stream;
     if (!x8 && !so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_bf16_skinny_kernel<float, true>");
         hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
         PSALM_LAUNCH_END(name);
     }

@@ -51,7 +51,7 @@ class _ProfiledLib:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version",
+        if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version", "psalm_gemm_last_kernel",
                                                          "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
             return fn
 
@@ -72,7 +72,10 @@ class _ProfiledLib:
             e0.record()
             rc = fn(*args)
             e1.record()
-            rec.append((name, tuple(a.value if hasattr(a, "value") else a for a in args), e0, e1))
+            kern = None
+            if name.startswith(("psalm_gemm", "psalm_conv2d")):   # exact template instantiation the library launched (as a kernel trace names it)
+                kern = self._cdll.psalm_gemm_last_kernel().decode()
+            rec.append((name, tuple(a.value if hasattr(a, "value") else a for a in args), e0, e1, kern))
             return rc
         return call
 
@@ -112,6 +115,7 @@ class Ops:
         cdll = ctypes.CDLL(lib_path)
         cdll.psalm_last_error.restype = c_char_p
         cdll.psalm_backend.restype = c_char_p
+        cdll.psalm_gemm_last_kernel.restype = c_char_p
         self._cdll_raw = cdll
         self.lib = _ProfiledLib(cdll)
         self.backend = self.lib.psalm_backend().decode()

@@ -1,7 +1,7 @@
 # Round profile pass on the GPU box: default bench line (+ CPU baseline, bf16 side line), rocprofv3 kernel trace of the same workload,
 # the two HBM-traffic PMC passes (separate runs, no trace domains), per-kernel summaries under gpurun_out/ (copied to profiles/ by hand).
 #   bash tools/gpu_profile.sh <tag>            e.g. r02e
-TAG=${1:-r02}
+TAG=${1:-r03}
 set -x
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
