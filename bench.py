@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"])
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 side-line measurement (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-seeds", type=int, default=5, help="inputs the parity leg compares with the CPU oracle (rank 0, N=1; ~12 s of CPU each)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
@@ -143,6 +144,24 @@ def main():
         dist.all_gather(every, mine)                            # each rank's own wall time for its K steps
         per_rank = [args.steps / float(t_.item()) for t_ in every]
         dt = max(float(t_.item()) for t_ in every)              # the job is done when its slowest rank is
+
+    # ---- is the host on the critical path?  GPU time of one step = the captured hipGraph replayed back to back with NO host work in
+    # between (events on the replay stream); `ms_per_step` - `gpu_ms_per_step` is what prompt handling, the blob upload, the replay call
+    # and the one result read-back per image add
+    gpu_ms = None
+    if not args.eager and rank == 0:
+        ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
+        if len(ents) == 1:
+            g_ = ents[0]["graph"]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g_.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.steps):
+                g_.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            gpu_ms = e0.elapsed_time(e1) / args.steps
 
     # ---- instrumented steps (not part of `value`): HIP events (torch's current stream = the launch stream) around every
     # C-ABI launch, attributed to kernel instantiations through psalm_gemm_describe (the library's own selection function)
@@ -295,6 +314,7 @@ def main():
             union = (gm | wm).flatten(1).sum(1).float()
             iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
             return {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
+                    "mask_iou_pooled": round(float(inter.sum() / union.sum().clamp(min=1)), 6), "flipped_mask_pixels": int((gm != wm).sum()),
                     "mask_logit_rel_err": float(f"{((g['mask_pred'].cpu() - w_['mask_pred']).abs().max() / w_['mask_pred'].abs().max()).item():.3e}"),
                     "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
                     "semantic_argmax_agreement": round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6),
@@ -302,6 +322,25 @@ def main():
                     "panoptic_segments": [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]}
         parity = parity_of(out[0], want[0])
         parity["meets_north_star_bar"] = bool(parity["mask_iou_mean"] >= 0.999 and parity["semantic_argmax_agreement"] >= 0.999)
+        # ... and over more inputs (same weights, other seeded images / prompts): one image is a noisy gate -- 0.3 % positive pixels, ~10
+        # empty reference masks, masks of a few pixels whose IoU moves in steps of 1/area.  min / max over the seeds.
+        if args.parity_seeds > 1 and not args.eager:
+            per_seed = [dict(parity, inputs_seed=rank)]
+            for s_ in range(1, args.parity_seeds):
+                pin = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank + s_)
+                w_s = O.eval_seg(sd, cfg, **pin)[0]
+                pin["images"] = pin["images"].cuda()
+                g_s = model.eval_seg(**pin)[0]
+                torch.cuda.synchronize()
+                per_seed.append(dict(parity_of(g_s, w_s), inputs_seed=rank + s_))
+            parity["seeds"] = {"n": len(per_seed), "inputs_seeds": [p_["inputs_seed"] for p_ in per_seed],
+                               "mask_iou_mean_min": min(p_["mask_iou_mean"] for p_ in per_seed),
+                               "mask_iou_pooled_min": min(p_["mask_iou_pooled"] for p_ in per_seed),
+                               "mask_logit_rel_err_max": max(p_["mask_logit_rel_err"] for p_ in per_seed),
+                               "semantic_argmax_agreement_min": min(p_["semantic_argmax_agreement"] for p_ in per_seed),
+                               "panoptic_id_agreement_min": min(p_["panoptic_id_agreement"] for p_ in per_seed),
+                               "flipped_mask_pixels_max": max(p_["flipped_mask_pixels"] for p_ in per_seed), "per_seed": per_seed}
+            parity["meets_north_star_bar"] = bool(parity["seeds"]["mask_iou_mean_min"] >= 0.999 and parity["seeds"]["semantic_argmax_agreement_min"] >= 0.999)
         if not args.no_side_modes and args.precision != "bf16":
             # side line: the bf16 fast mode on the same image (NOT `value`: it does not meet the parity bar on this network)
             del model, out
@@ -326,6 +365,8 @@ def main():
         line = {
             "metric": "images/sec at 1024x1024 COCO-panoptic inference", "value": round(world * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "gpu_ms_per_step": round(gpu_ms, 3) if gpu_ms is not None else None,
+            "host_ms_per_step": round(dt / args.steps * 1e3 - gpu_ms, 3) if gpu_ms is not None else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",

@@ -7,9 +7,12 @@
                            installed here; call site psalm/eval/region_segmentation.py:282 `mask.encode(np.asfortranarray(pred_))`)
   * `intersection_and_union`  psalm/eval/referring_segmentation.py:101-113 (intersectionAndUnionGPU with torch.histc)
   * `compute_metric_update`   psalm/eval/referring_segmentation.py:139-171
-PINNING: the reference holds no golden vectors for these; pycocotools / panopticapi are absent from this image.  The RLE codec is pinned
-by hand-computed run lists, the string round trip and the structural identities in tests/test_8_evalout.py ("parity unpinned" for the
-byte-exact COCO string against a real pycocotools build; the run LENGTHS are unambiguous).  Only tests/ may import this module."""
+PINNING: `intersection_and_union`, `compute_metric_update`, the cIoU / gIoU formulas and `semantic_confusion` are pinned against the
+reference's OWN functions run in the authoring container (tests/golden/make_evalout_golden.py executes their source text from
+/root/reference on seeded inputs -> tests/golden/evalout.npz; tests/test_8_evalout.py checks this module and the device path against it,
+exactly).  "parity unpinned" remains for two third-party formats only -- the byte-exact COCO RLE string (pycocotools) and id2rgb
+(panopticapi), both absent from the image: the RLE codec is held by hand-computed run lists, the string round trip and the structural
+identities in tests/test_8_evalout.py (the run LENGTHS are unambiguous).  Only tests/ may import this module."""
 import numpy as np
 
 

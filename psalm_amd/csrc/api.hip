@@ -19,3 +19,20 @@ extern "C" const char* psalm_backend() {
     return "hip-gfx950";
 #endif
 }
+
+// Buffer clears / device-to-device copies of the per-image path as plain stream operations (captured into the hipGraph as memset / memcpy
+// nodes), so that the path launches no framework kernel for them (north star: PyTorch for tensor containers and launch glue only).
+extern "C" int psalm_memset_zero(void* p, long bytes, void* stream) {
+    if (bytes <= 0) return 0;
+    PSALM_CHECK_ARG(p != nullptr, "psalm_memset_zero: null pointer");
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { psalm_set_error("psalm_memset_zero: hipMemsetAsync failed"); return (int)e; }
+    return 0;
+}
+extern "C" int psalm_copy_d2d(void* dst, const void* src, long bytes, void* stream) {
+    if (bytes <= 0) return 0;
+    PSALM_CHECK_ARG(dst != nullptr && src != nullptr, "psalm_copy_d2d: null pointer");
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { psalm_set_error("psalm_copy_d2d: hipMemcpyAsync failed"); return (int)e; }
+    return 0;
+}

@@ -10,6 +10,7 @@ sources compiled for the host -- explicitly via `Ops(path)`; `get_ops()` never d
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import sys
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
@@ -28,6 +29,12 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
 _DEBUG_SYNC = os.environ.get("PSALM_DEBUG_SYNC", "0") not in ("", "0")
+# PSALM_DEBUG_BOUNDS=1: after every split-output GEMM, compare the magnitude BOUND behind its row scales with what the rows actually hold
+# (one device round trip per call -- a debugging aid, off in production): the emitted operand keeps its 22 bits while bound / actual row
+# maximum <= 2^14 (tests/test_2_gemm.py::test_gemm_x3_split_output_loose_bound); trained weights with outlier channels can be far looser
+# than the seeded Gaussian ones of the tests, and this is how to find out.
+_DEBUG_BOUNDS = os.environ.get("PSALM_DEBUG_BOUNDS", "0") not in ("", "0")
+BOUND_LOOSENESS_LIMIT = 2.0 ** 14
 
 
 class PsalmHipError(RuntimeError):
@@ -124,6 +131,8 @@ class Ops:
         self.lib_path = lib_path
         self._ws = {}                      # cached kernel workspaces (device buffers owned by this binding)
         self._msda_tables = set()          # device-side MSDA level tables already validated (msda_forward_dev)
+        self.debug_bounds = False          # True (or PSALM_DEBUG_BOUNDS=1): verify the scale bound of every split-output GEMM (host round trip)
+        self.bound_looseness_max = 1.0
         self.x3 = False                    # True: float32 x float32 GEMMs run in split-f16 arithmetic (precision="f16x3")
 
     # ------------------------------------------------------------------ plumbing
@@ -171,7 +180,17 @@ class Ops:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
     def zeros(self, *shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=self.device)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self._check(self.lib.psalm_memset_zero(self._p(t), c_long(t.numel() * t.element_size()), self._stream()), "psalm_memset_zero")
+        return t
+
+    def copy_(self, dst, src):
+        """dst <- src for two contiguous device tensors of equal dtype / numel, as a stream copy (no framework kernel)."""
+        if dst.dtype != src.dtype or dst.numel() != src.numel() or not (dst.is_contiguous() and src.is_contiguous()) or src.device != dst.device:
+            dst.copy_(src)
+            return dst
+        self._check(self.lib.psalm_copy_d2d(self._p(dst), self._p(src), c_long(dst.numel() * dst.element_size()), self._stream()), "psalm_copy_d2d")
+        return dst
 
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, w, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=None):
@@ -290,7 +309,25 @@ class Ops:
                                           split_col_start, split_form, self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
                                           self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_split")
+        if _DEBUG_BOUNDS or self.debug_bounds:
+            self.check_split_bound(split_out, split_col_off, N - split_col_start, "gemm_x3_split")
         return split_out
+
+    def check_split_bound(self, split_out, col_off, ncols, what=""):
+        """Looseness of the scale bound of an emitted split-f16 operand: the scale puts the BOUND in [2^12, 2^13), so 2^13 / max |hi| over a
+        row's emitted columns is (within 2x) bound / actual row maximum.  Records the worst row in `bound_looseness_max`; raises beyond
+        BOUND_LOOSENESS_LIMIT (lo would be reaching the f16 subnormal floor: the operand no longer carries 22 bits)."""
+        hi = split_out[:, col_off:col_off + ncols].float().abs().amax(1)
+        live = hi > 0
+        if not bool(live.any()):
+            return 1.0
+        loose = float((2.0 ** 13 / hi[live]).max())
+        self.bound_looseness_max = max(self.bound_looseness_max, loose)
+        if loose > BOUND_LOOSENESS_LIMIT:
+            raise PsalmHipError(f"{what}: the magnitude bound behind the split-f16 output scale is 2^{math.log2(loose):.1f} above the "
+                                f"actual row maximum (limit 2^14): lo is reaching the f16 subnormal floor -- run this GEMM without the "
+                                "fused split output (PSALM.fuse_split = False) or tighten its bound")
+        return loose
 
     def gemm_ln(self, a, w, bias, residual, gamma, beta, eps=1e-5, ln_dtype=torch.bfloat16, act=ACT_NONE):
         """(C fp32, LayerNorm(C) ln_dtype) with C = act(a @ w^T + bias) + residual; bf16 a / w, K % 64 == 0."""
@@ -772,14 +809,14 @@ class Ops:
         self._check(rc, "psalm_mask_scores")
         return score
 
-    def topk_select(self, vals, C, k, is_thing=None, mask_score=None, apply_sigmoid=False):
+    def topk_select(self, vals, C, k, is_thing=None, mask_score=None, apply_sigmoid=False, count_out=None):
         """vals (Q,stride) f32, first C columns are candidates.  Returns (score (k), class (k) i32, query (k) i32, count (1) i32),
-        entries [0,count) valid, in descending candidate order."""
+        entries [0,count) valid, in descending candidate order.  count_out: a zeroed (1,) int32 view to write the count into."""
         Q, stride = vals.shape
         sc = self.zeros(k)
         cl = self.zeros(k, dtype=torch.int32)
         qq = self.zeros(k, dtype=torch.int32)
-        cnt = self.zeros(1, dtype=torch.int32)
+        cnt = count_out if count_out is not None else self.zeros(1, dtype=torch.int32)
         rc = self.lib.psalm_topk_select(self._p(vals), Q, C, stride, k, self._p(is_thing), self._p(mask_score), self._p(sc), self._p(cl),
                                         self._p(qq), self._p(cnt), int(apply_sigmoid), self._stream())
         self._check(rc, "psalm_topk_select")
@@ -793,16 +830,17 @@ class Ops:
         self._check(rc, "psalm_binarize_gather")
         return out
 
-    def panoptic(self, mask, score, label, is_thing, num_classes, obj_thr, overlap_thr):
-        """mask (Q,H,W) f32 logits; returns (pan (H,W) i32, info (Q,3) i32, ninfo (1) i32)."""
+    def panoptic(self, mask, score, label, is_thing, num_classes, obj_thr, overlap_thr, info_out=None, ninfo_out=None):
+        """mask (Q,H,W) f32 logits; returns (pan (H,W) i32, info (Q,3) i32, ninfo (1) i32).  info_out / ninfo_out: zeroed int32 views
+        ((Q,3) / (1,)) to write into -- the caller fetches its data-dependent counts in ONE device-to-host copy."""
         Q, Hh, Ww = mask.shape
         HW = Hh * Ww
         argq = self.empty(HW, dtype=torch.int32)
         counts = self.empty(Q * 3, dtype=torch.int32)
         final_id = self.empty(Q + num_classes + 1, dtype=torch.int32)
         pan = self.empty(Hh, Ww, dtype=torch.int32)
-        info = self.zeros(Q, 3, dtype=torch.int32)
-        ninfo = self.zeros(1, dtype=torch.int32)
+        info = info_out if info_out is not None else self.zeros(Q, 3, dtype=torch.int32)
+        ninfo = ninfo_out if ninfo_out is not None else self.zeros(1, dtype=torch.int32)
         rc = self.lib.psalm_panoptic(self._p(mask), self._p(score), self._p(label), self._p(is_thing), self._p(argq), self._p(counts),
                                      self._p(final_id), self._p(pan), self._p(info), self._p(ninfo), Q, c_long(HW), num_classes,
                                      c_float(obj_thr), c_float(overlap_thr), self._stream())

@@ -695,3 +695,33 @@ def test_gemm_x8_split_output_and_ln_split(ops):
     assert torch.equal(by[..., 0], _e4m3(hi * 2.0 ** -6))
     lo = y1 / inv[:, None] - hi
     assert ((by[..., 1] * 2.0 ** -6 - lo).abs() <= 2.0 ** -4 * lo.abs() + 2.0 ** -15).all()
+
+
+def test_split_output_bound_debug_check_heavy_tailed_weights(ops):
+    """the L1 bound behind the split-output scale was validated on Gaussian weights only.  With heavy-tailed weights
+    (a few outlier channels carry most of every row's L1 norm while typical activations never excite them) the bound is much looser; the
+    debug check (Ops.debug_bounds / PSALM_DEBUG_BOUNDS=1) measures it per call and refuses an operand past the documented 2^14."""
+    M, N, K = 200, 256, 256
+    g = torch.Generator().manual_seed(77)
+    d = ops.device
+    w = torch.randn(N, K, generator=g) * 0.02
+    w[:, :4] = torch.randn(N, 4, generator=g) * 40.0              # outlier input channels: ~90 % of each row's L1 norm
+    a = torch.randn(M, K, generator=g)
+    a[:, :4] *= 1e-3                                               # ... which this layer's inputs barely excite
+    bias = torch.randn(N, generator=g) * 0.01
+    par = split_bound_par(w, bias)
+    asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+    so = torch.zeros(M, 2 * N, dtype=torch.float16, device=d)
+    inv = torch.zeros(M, device=d)
+    ops.debug_bounds, ops.bound_looseness_max = True, 1.0
+    try:
+        ops.gemm_x3_split(asp, wsp, bias.to(d), H.ACT_NONE, so, inv, par.to(d))
+        loose = ops.bound_looseness_max
+        assert 2.0 ** 6 < loose <= H.BOUND_LOOSENESS_LIMIT, loose    # far looser than the Gaussian case (2^4..2^7), still inside the limit
+        want = ops.gemm_x3(asp, wsp, bias.to(d)).cpu().double()
+        rec = (so.cpu()[:, :N].double() + so.cpu()[:, N:].double()) * inv.cpu().double()[:, None]
+        assert ((rec - want).abs() <= 2.0 ** -20 * want.abs().amax(1, keepdim=True)).all()
+        with pytest.raises(H.PsalmHipError, match="2\\^14"):
+            ops.gemm_x3_split(asp, wsp, bias.to(d), H.ACT_NONE, so, inv, (par * torch.tensor([2.0 ** 12, 2.0 ** 12, 1.0, 1.0])).to(d))
+    finally:
+        ops.debug_bounds = False

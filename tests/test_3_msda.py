@@ -158,3 +158,62 @@ def test_plugin_module_by_name_device_side_level_table(ops, monkeypatch):
         MSDA.ms_deform_attn_backward(None)
     with pytest.raises(RuntimeError):                                                                    # contiguity contract, ms_deform_attn_cuda.cu:33-43
         MSDA.ms_deform_attn_forward(value.to(d).transpose(1, 2), ss, lsi, loc.to(d), w.to(d), 128)
+
+
+@pytest.mark.gpu
+def test_real_shape_1024_vs_f64_oracle():
+    """The op at the shape the 1024 x 1024 pixel decoder runs it at -- value (1, 21504, 8, 32), 3 levels (128^2, 64^2, 32^2), 4 points, one
+    query per pixel -- against the fp64 C restatement of the CUDA op: both the plugin entry
+    (explicit locations / weights) and the fused kernel the model launches (softmax + location arithmetic in-kernel)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ops_backend import make_ops
+    ops = make_ops("hip")
+    shapes = [(128, 128), (64, 64), (32, 32)]
+    B, M, D, P, L = 1, 8, 32, 4, 3
+    S = sum(h * w for h, w in shapes)
+    assert S == 21504
+    st = _starts(shapes)
+    g = torch.Generator().manual_seed(11)
+    value = torch.randn(B, S, M * D, generator=g)
+    ow = torch.randn(B, S, M * L * P * 3, generator=g) * 2.0
+    off = ow[..., : M * L * P * 2].reshape(B, S, M, L, P, 2)
+    aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, S, M, L * P), -1).view(B, S, M, L, P)
+    refs = []
+    for (H_, W_) in shapes:
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing="ij")
+        refs.append(torch.stack((rx.reshape(-1) / W_, ry.reshape(-1) / H_), -1))
+    ref_pts = torch.cat(refs, 0)[None, :, None, None, None, :]
+    norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)[None, None, None, :, None, :]
+    loc = (ref_pts + off / norm).contiguous()
+    ref64 = _c_ref(value.view(B, S, M, D), shapes, st, loc, aw, f64=True)
+    tol = 1e-5 * float(value.abs().max())
+    got = ops.msda_forward(value.view(B, S, M, D).cuda(), shapes, st, loc.cuda(), aw.cuda()).cpu()
+    assert float((got - ref64).abs().max()) <= tol
+    fused = ops.msda_fused(value.cuda(), shapes, st, ow.cuda(), M).cpu()
+    assert float((fused - ref64).abs().max()) <= 4 * tol          # in-kernel softmax (__expf) and location arithmetic in fp32
+    dev = ops.msda_forward_dev(value.view(B, S, M, D).cuda(), torch.tensor(shapes, dtype=torch.int64).cuda(),
+                               torch.tensor(st, dtype=torch.int64).cuda(), loc.cuda(), aw.cuda()).cpu()
+    assert torch.equal(dev, got)
+
+
+def test_device_level_table_is_validated_once_and_guarded(ops):
+    """a level table that does not describe `value` must not become out-of-bounds gathers.  The binding checks each distinct
+    device-side table once (then stays asynchronous); the kernel itself skips a level whose rows do not lie inside the S rows."""
+    from psalm_amd import hip_ops as H
+    d = ops.device
+    shapes = [(4, 4), (2, 2)]
+    value, loc, w = _rand_case(3, 1, 2, 8, 6, shapes, 2)
+    sh = torch.tensor(shapes, dtype=torch.int64, device=d)
+    st = torch.tensor(_starts(shapes), dtype=torch.int64, device=d)
+    good = ops.msda_forward_dev(value.to(d), sh, st, loc.to(d), w.to(d)).cpu()
+    assert torch.allclose(good, O.msda_core(value, shapes, _starts(shapes), loc, w), atol=1e-5)
+    bad = torch.tensor([(4, 4), (3, 3)], dtype=torch.int64, device=d)          # 16 + 9 rows != 20
+    with pytest.raises(H.PsalmHipError):
+        ops.msda_forward_dev(value.to(d), bad, st, loc.to(d), w.to(d))
+    # the kernel's own guard (what protects a captured graph, where the host check cannot run): level 1 does not fit -> contributes nothing
+    key = (bad.data_ptr(), bad._version, st.data_ptr(), st._version, value.shape[1], 2)
+    ops._msda_tables.add(key)
+    out = ops.msda_forward_dev(value.to(d), bad, st, loc.to(d), w.to(d)).cpu()
+    lvl0 = O.msda_core(value[:, :16], shapes[:1], [0], loc[:, :, :, :1], w[:, :, :, :1])
+    assert torch.allclose(out, lvl0, atol=1e-5)

@@ -126,3 +126,50 @@ def test_compact_results_equal_host_evaluator_formulas_on_model_outputs():
     assert (pred_o == pred_ref).mean() >= 0.99
     assert np.array_equal(R.id2rgb(w["panoptic_seg"][0].numpy()), c["panoptic_rgb"].cpu().numpy())
     assert w["panoptic_seg"][1] == c["segments_info"]
+
+
+# ---- the REFERENCE's evaluator arithmetic run on seeded outputs (tests/golden/make_evalout_golden.py -> evalout.npz) --------------------
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "evalout.npz"))
+
+
+def test_oracle_matches_reference_evaluator_golden():
+    """oracle/evalout_ref.py vs what the reference's own intersectionAndUnionGPU / compute_metric / my_SemSegEvaluator.process produced."""
+    G = _golden()
+    ref = {"I": np.zeros(2), "U": np.zeros(2), "acc": np.zeros(2), "n": 0}
+    for i in range(4):
+        pred, gt, sc = G[f"s{i}/pred"], G[f"s{i}/gt"], G[f"s{i}/scores"]
+        top = int(np.argmax(sc))
+        assert np.array_equal(G[f"s{i}/kept_pred"], pred[top])
+        ai, au, at = R.intersection_and_union(pred[top], gt)
+        assert np.array_equal(ai, G[f"s{i}/intersection"].astype(np.int64)) and np.array_equal(au, G[f"s{i}/union"].astype(np.int64))
+        assert np.array_equal(at, G[f"s{i}/target"].astype(np.int64))
+        R.compute_metric_update(ref, pred[top], gt)
+    assert np.array_equal(ref["I"], G["meters/intersection_sum"]) and np.array_equal(ref["U"], G["meters/union_sum"])
+    assert np.allclose(ref["acc"], G["meters/acc_iou_sum"], rtol=0, atol=1e-12) and ref["n"] == int(G["meters/count"])
+    assert abs(ref["I"][1] / (ref["U"][1] + 1e-10) - float(G["meters/ciou"])) < 1e-15
+    C = int(G["sem/num_classes"])
+    _, conf = R.semantic_confusion(G["sem/logits"], G["sem/gt"], C, 255)
+    assert np.array_equal(conf, G["sem/conf_matrix"])
+
+
+def test_device_evalout_matches_reference_evaluator_golden(ops):
+    """psalm_amd.evalout (kernels: emulator here, the GPU under -m gpu) vs the same golden: counts exact, cIoU / gIoU to float64 round-off."""
+    G = _golden()
+    meters = E.IoUMeters()
+    for i in range(4):
+        pred, gt, sc = torch.from_numpy(G[f"s{i}/pred"]), torch.from_numpy(G[f"s{i}/gt"]), G[f"s{i}/scores"]
+        top = int(np.argmax(sc))
+        inter, union, tgt = E.iou_counts(pred.to(ops.device), gt[None], [(top, 0)], ops=ops)
+        assert np.array_equal(inter[0].cpu().numpy(), G[f"s{i}/intersection"].astype(np.int64))
+        assert np.array_equal(union[0].cpu().numpy(), G[f"s{i}/union"].astype(np.int64))
+        assert np.array_equal(tgt[0].cpu().numpy(), G[f"s{i}/target"].astype(np.int64))
+        meters.update(inter, union)
+    res = meters.results()
+    assert res["n"] == int(G["meters/count"])
+    assert abs(res["ciou"] - float(G["meters/ciou"])) < 1e-12 and abs(res["giou"] - float(G["meters/giou"])) < 1e-12
+    C = int(G["sem/num_classes"])
+    cm = E.ConfusionMatrix(C, 255, ops=ops)
+    cm.update(E.semantic_labels(torch.from_numpy(G["sem/logits"]).to(ops.device), ops=ops), torch.from_numpy(G["sem/gt"]))
+    assert np.array_equal(cm.conf.cpu().numpy(), G["sem/conf_matrix"])

@@ -62,6 +62,11 @@ def _stage_checks(z, case, cfg, stages, outs, rtol, tag):
         errs[k] = check_signature(z, k, _nchw(tok, B, h, w).contiguous(), rtol, what=tag)
     if not case.get("video"):          # (eval_video: the golden's projector signature belongs to the previous frame, LP:1665)
         errs["image_tokens"] = check_signature(z, "image_tokens", stages["image_tokens"], rtol, what=tag)
+    # the LLM's own output (a Phi regression must not surface only as a downstream mask error).  Un-padded batches
+    # only: behind a ragged batch's padding the reference's hidden states are whatever its masked attention leaves there.
+    hs = stages["hidden_states"]
+    if all(int(n) == hs.shape[1] for n in stages["lengths"]):
+        errs["hidden_states"] = check_signature(z, "hidden_states", hs, rtol, what=tag)
     pm = torch.stack([o["pred_masks"] for o in outs])
     # mask logits sit behind the 24-layer LLM and the 9 discontinuous mask -> attention-mask feedback steps: in bf16 on random
     # weights they move 2-3x more than the feed-forward stages (measured 1.4e-2 .. 7e-2 of absmax over the five golden cases)
