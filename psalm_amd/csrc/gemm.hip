@@ -1498,7 +1498,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
-    if (bm >= 3300 && bm <= 3302) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
+    if (bm >= 3300 && bm <= 3304) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
@@ -1633,7 +1633,12 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     // (BM, BN, WM, WN, NS, CONV, BK, PH8, X3, SO) in the output type the call needs (fp32 results / slabs, or bf16)
 #define GO_T(NT_, ...) do { if (f32out) GO(NT_, "float", float, __VA_ARGS__); else GO(NT_, "unsigned short", bf16_t, __VA_ARGS__); } while (0)
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
-        if (BM == 128 && slice == 2) GO(256, "float", float, 128, 128, 2, 2, 4, false, 32, 0, 2, false);
+        // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
+        // with 1.5x the matrix work per copy round trip
+        if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);
+        else if (slice == 3) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, false);
+        else if (slice == 4) GO(256, "float", float, 64, 128, 2, 2, 3, false, 32, 0, 2, false);
+        else if (BM == 128 && slice == 2) GO(256, "float", float, 128, 128, 2, 2, 4, false, 32, 0, 2, false);
         else if (BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 2, false);
         else if (slice == 2) GO(256, "float", float, 64, 128, 2, 2, 4, false, 32, 0, 2, false);
         else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);

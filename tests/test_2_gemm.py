@@ -281,7 +281,7 @@ X3_CASES = [
 
 
 # K loop forms: 3300 K-panel (default) on every case; 3301 slice form / 3302 32-deep slices in a 4-deep ring on the tiled (policy != 0) cases
-X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302)]
+X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302, 3303, 3304)]
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy,kloop", X3_PARAMS)

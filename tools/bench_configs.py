@@ -1,62 +1,119 @@
-"""BASELINE.json configs as side-lines (bench.py stays on the headline config): throughput of the HIP path and parity
-against the CPU oracle on the same seeded inputs, full-size architecture.
+"""BASELINE.json configs other than the headline one, as side-lines (bench.py stays on configs[1]): throughput of the HIP path in the
+QUALIFYING mode (f16x3: split-f16 GEMMs, Phi cross terms in e4m3 -- the default product mode) and, for contrast, the bf16 fast mode; parity
+against the CPU oracle over several seeded inputs ("the configs' lines in the mode that meets the bar"), and which kernel
+instantiation dominates each.
 
-    python tools/bench_configs.py [--json out.json] [--skip-oracle] [--fp32]
-  config 2  COCO-panoptic 1024x1024 batch=1            (bf16; --fp32 adds the exact-fp32 mode)
+    python tools/bench_configs.py [--json out.json] [--seeds 5] [--skip-oracle] [--only 3]
+  config 2  COCO-panoptic 1024x1024 batch=1
   config 3  RefCOCO referring 640x640 batch=4 (ragged sentences)
-  config 5  interactive (region prompts) 1024x1024 batch=2 -- bf16 LLM and fp8 (OCP e4m3) LLM projections
-"""
+  config 5  interactive (region prompts) 1024x1024 batch=2
+Per line: images/s (hipGraph replay, results consumed per step), the graph's own GPU time, parity min-over-seeds (mean / pooled IoU, IoU over
+reference masks of >= 64 pixels, mask-logit error, and for panoptic the semantic / panoptic agreement), the three launches that take most of
+a step with their share.  fp8 (e4m3) for WHOLE operands is not a mode any more: profiles/r03a_cross_term_precision.jsonl -- only the cross
+terms of the Phi GEMMs tolerate it, which is what f16x3 does."""
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from parity_seeds import compare  # noqa: E402
 from psalm_amd.config import PsalmConfig  # noqa: E402
 from psalm_amd.model import PSALM  # noqa: E402
 from psalm_amd.synthetic import make_inputs, make_state_dict  # noqa: E402
 
-
-def iou_stats(got, want):
-    gm, wm = got["mask_pred"].cpu() > 0, want["mask_pred"] > 0
-    inter = (gm & wm).flatten(1).sum(1).float()
-    union = (gm | wm).flatten(1).sum(1).float()
-    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
-    return {"mask_iou_mean": round(float(iou.mean()), 5), "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6)}
+CONFIGS = {2: ("2: panoptic 1024 b1", "panoptic", 1024, 1), 3: ("3: referring 640 b4", "referring", 640, 4),
+           5: ("5: region 1024 b2", "region", 1024, 2)}
 
 
-def run(name, task, size, batch, precision, oracle=True, steps=8):
+def dominant(model, inputs, nprof=2):
+    """share of the summed per-launch time (HIP events around every C-ABI launch, one stream, eager) by kernel instantiation"""
+    recs = []
+    g, ov = model.use_graphs, model.overlap_streams
+    model.use_graphs, model.overlap_streams = False, False
+    try:
+        model.eval_seg(**inputs)
+        model.ops.lib.records = recs
+        for _ in range(nprof):
+            model.eval_seg(**inputs)
+        torch.cuda.synchronize()
+    finally:
+        model.ops.lib.records = None
+        model.use_graphs, model.overlap_streams = g, ov
+    agg = {}
+    for name, _a, e0, e1, kname in recs:
+        d = agg.setdefault(kname or name, [0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+    tot = sum(v[1] for v in agg.values())
+    top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:3]
+    return {"launches_per_step": sum(v[0] for v in agg.values()) / nprof, "sum_launch_ms_per_step": round(tot / nprof, 3),
+            "top": [{"kernel": k, "launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 3), "share": round(v[1] / tot, 4)} for k, v in top]}
+
+
+def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
+    name, task, size, batch = CONFIGS[key]
     cfg = PsalmConfig(seg_task=task)
-    sd = make_state_dict(cfg, seed=0)
+    if task not in sd_cache:
+        sd_cache.clear()
+        sd_cache[task] = make_state_dict(cfg, seed=0)
+    sd = sd_cache[task]
     model = PSALM(cfg, sd, precision=precision, use_graphs=True)
+    model.graph_outputs = "alias"
     inputs = make_inputs(cfg, task, size=size, batch=batch, seed=3)
     inputs["images"] = inputs["images"].cuda()
-    torch.manual_seed(7)
-    for _ in range(3):
-        torch.manual_seed(7)
-        out = model.eval_seg(**inputs)
+    for _ in range(4):
+        model.eval_seg(**inputs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        torch.manual_seed(7)
-        out = model.eval_seg(**inputs)
+        model.eval_seg(**inputs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision, "ms_per_batch": round(dt * 1e3, 2),
-           "images_per_s": round(batch / dt, 2)}
-    if oracle:
+    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision, "llm_x8": bool(model.llm_x8),
+           "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 2)}
+    ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
+    if len(ents) == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            ents[0]["graph"].replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res["gpu_ms_per_batch"] = round(e0.elapsed_time(e1) / steps, 3)
+    res["kernels"] = dominant(model, inputs)
+    if seeds:
         from oracle import psalm_oracle as O
-        torch.set_num_threads(64)
-        cin = make_inputs(cfg, task, size=size, batch=batch, seed=3)
-        torch.manual_seed(7)
-        t1 = time.perf_counter()
-        want = O.eval_seg(sd, cfg, **cin)
-        res["oracle_s"] = round(time.perf_counter() - t1, 1)
-        res["parity"] = [iou_stats(out[b], want[b]) for b in range(batch)]
-        if task == "panoptic":
-            res["parity"][0]["semantic_argmax_agreement"] = round(float((out[0]["sem_seg"].argmax(0).cpu() == want[0]["sem_seg"].argmax(0)).float().mean()), 6)
-            res["parity"][0]["panoptic_id_agreement"] = round(float((out[0]["panoptic_seg"][0].cpu() == want[0]["panoptic_seg"][0]).float().mean()), 6)
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        model.graph_outputs = "copy"
+        rows = []
+        for s in range(seeds):
+            pin = make_inputs(cfg, task, size=size, batch=batch, seed=3 + s)
+            ck = (task, size, batch, 3 + s)
+            if ck not in oracle_cache:
+                t1 = time.perf_counter()
+                torch.manual_seed(1234)
+                oracle_cache[ck] = (O.eval_seg(sd, cfg, **pin), round(time.perf_counter() - t1, 1))
+            want, secs = oracle_cache[ck]
+            torch.manual_seed(1234)
+            got = model.eval_seg(**pin)
+            torch.cuda.synchronize()
+            rows += [dict(compare(got[b], want[b]), inputs_seed=3 + s, image=b, oracle_seconds=secs) for b in range(batch)]
+
+        def mn(k):
+            v = [r[k] for r in rows if r.get(k) is not None]
+            return min(v) if v else None
+        res["parity"] = {"images": len(rows), "inputs_seeds": [3 + s for s in range(seeds)], "mask_iou_mean_min": mn("mask_iou_mean"),
+                         "mask_iou_pooled_min": mn("mask_iou_pooled"), "mask_iou_mean_area_ge_64_min": mn("mask_iou_mean_area_ge_64"),
+                         "mask_pixel_agreement_min": mn("mask_pixel_agreement"), "mask_logit_rel_err_max": max(r["mask_logit_rel_err"] for r in rows),
+                         "semantic_argmax_agreement_min": mn("semantic_argmax_agreement"), "panoptic_id_agreement_min": mn("panoptic_id_agreement"),
+                         "flipped_pixels_max": max(r["flipped_pixels"] for r in rows), "per_image": rows}
+        res["parity"]["meets_north_star_bar"] = bool(res["parity"]["mask_iou_mean_min"] >= 0.999 and
+                                                     (res["parity"]["semantic_argmax_agreement_min"] or 1.0) >= 0.999)
     print(json.dumps(res), flush=True)
     del model
     torch.cuda.empty_cache()
@@ -64,16 +121,15 @@ def run(name, task, size, batch, precision, oracle=True, steps=8):
 
 
 def main():
-    oracle = "--skip-oracle" not in sys.argv
-    out = [run("2: panoptic 1024 b1", "panoptic", 1024, 1, "bf16", oracle),
-           run("3: referring 640 b4", "referring", 640, 4, "bf16", oracle),
-           run("5*: region 1024 b2 (bf16 LLM)", "region", 1024, 2, "bf16", oracle),
-           run("5: region 1024 b2 (fp8 e4m3 LLM projections)", "region", 1024, 2, "fp8", oracle),
-           run("2': panoptic 1024 b1 (fp8 e4m3 LLM projections)", "panoptic", 1024, 1, "fp8", oracle)]
-    if "--fp32" in sys.argv:
-        out.append(run("2: panoptic 1024 b1 (exact fp32 mode)", "panoptic", 1024, 1, "fp32", oracle, steps=3))
-    if "--json" in sys.argv:
-        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+    av = sys.argv[1:]
+    seeds = 0 if "--skip-oracle" in av else int(av[av.index("--seeds") + 1]) if "--seeds" in av else 5
+    only = [int(x) for x in av[av.index("--only") + 1].split(",")] if "--only" in av else [3, 5]
+    out, sd_cache, oc = [], {}, {}
+    for key in only:
+        out.append(run(key, "f16x3", sd_cache, seeds, oc))
+        out.append(run(key, "bf16", sd_cache, min(seeds, 1), oc))       # contrast line: does not meet the bar on this network
+    if "--json" in av:
+        with open(av[av.index("--json") + 1], "w") as f:
             json.dump(out, f, indent=1)
 
 

@@ -8,9 +8,11 @@ from psalm_amd.hip_ops import get_ops
 
 SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512, 2048), (5184, 1536, 512), (5184, 512, 512),
           (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256), (65536, 512, 128), (65536, 128, 512), (16384, 1024, 256),
-          (1024, 4096, 1024), (100, 65536, 256), (133, 1048576, 128), (65536, 256, 2304)]
-POLICIES = [("auto", [0]), ("auto_slice", [3301]), ("auto_slice32", [3302]), ("t128", [128]), ("t128_slice", [128, 3301]),
-            ("t64", [64]), ("t64_slice", [64, 3301]), ("t256", [256])]
+          (1024, 4096, 1024), (100, 65536, 256), (65536, 256, 2304),
+          (21504, 288, 256), (1296, 3072, 1024), (17424, 768, 256), (69696, 384, 128), (256, 2048, 18432), (1024, 1024, 4096)]
+# 3301 / 3302: slice forms with one block per CU (r02l: lose); 3303 / 3304: 32-deep slices in a 2- / 3-deep ring (the K-panel form's LDS footprint)
+POLICIES = [("auto", [0]), ("auto_s3", [3303]), ("t128", [128]), ("t128_s3", [128, 3303]), ("t64", [64]), ("t64_s3", [64, 3303]), ("t64_s4", [64, 3304]),
+            ("t64_slice", [64, 3301]), ("t256", [256])]
 
 
 def main():
