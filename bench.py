@@ -313,7 +313,9 @@ def main():
             inter = (gm & wm).flatten(1).sum(1).float()
             union = (gm | wm).flatten(1).sum(1).float()
             iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
+            big = wm.flatten(1).sum(1) >= 64                     # a smaller mask's IoU moves in steps of >= 1/64 per flipped pixel
             return {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
+                    "mask_iou_mean_area_ge_64": round(float(iou[big].mean()), 6) if bool(big.any()) else None, "ref_masks_lt_64px": int((~big).sum()),
                     "mask_iou_pooled": round(float(inter.sum() / union.sum().clamp(min=1)), 6), "flipped_mask_pixels": int((gm != wm).sum()),
                     "mask_logit_rel_err": float(f"{((g['mask_pred'].cpu() - w_['mask_pred']).abs().max() / w_['mask_pred'].abs().max()).item():.3e}"),
                     "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
@@ -336,6 +338,7 @@ def main():
             parity["seeds"] = {"n": len(per_seed), "inputs_seeds": [p_["inputs_seed"] for p_ in per_seed],
                                "mask_iou_mean_min": min(p_["mask_iou_mean"] for p_ in per_seed),
                                "mask_iou_pooled_min": min(p_["mask_iou_pooled"] for p_ in per_seed),
+                               "mask_iou_mean_area_ge_64_min": min((p_["mask_iou_mean_area_ge_64"] for p_ in per_seed if p_["mask_iou_mean_area_ge_64"] is not None), default=None),
                                "mask_logit_rel_err_max": max(p_["mask_logit_rel_err"] for p_ in per_seed),
                                "semantic_argmax_agreement_min": min(p_["semantic_argmax_agreement"] for p_ in per_seed),
                                "panoptic_id_agreement_min": min(p_["panoptic_id_agreement"] for p_ in per_seed),

@@ -166,6 +166,8 @@ __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned by
 __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<float*>(r.base + off) = v; }
 __device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<unsigned*>(r.base + off) = v; }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) { return (off < r.bytes && r.bytes - off >= 4u) ? *reinterpret_cast<const float*>(r.base + off) : 0.f; }
+__device__ __forceinline__ void psalm_buf_store_f32_s(float v, psalm_rsrc r, unsigned voff, unsigned soff) { if (voff < PSALM_BUF_OOB) psalm_buf_store_f32(v, r, voff + soff); }
+__device__ __forceinline__ float psalm_buf_load_f32_s(psalm_rsrc r, unsigned voff, unsigned soff) { return voff < PSALM_BUF_OOB ? psalm_buf_load_f32(r, voff + soff) : 0.f; }
 #else
 __device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) {                              // DPP quad_perm [1,0,3,2]: no LDS crossbar
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
@@ -180,6 +182,14 @@ __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsig
 __device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+// ... with a wave-uniform part of the offset in an SGPR (soff; buffers < 2^31 bytes, a per-lane voff >= PSALM_BUF_OOB still drops the access):
+// one VGPR of address per access instead of a 64-bit pointer
+__device__ __forceinline__ void psalm_buf_store_f32_s(float v, psalm_rsrc r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float psalm_buf_load_f32_s(psalm_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 #endif
 

@@ -361,7 +361,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8 = 0, int X3 = 0,
           bool SO = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
-    static_assert(!SO || X3 == 1 || X3 == 3, "split-f16 output: K-panel / x8 form of the split-f16 GEMM");
+    static_assert(!SO || X3 == 1 || X3 == 3 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel / x8 form, or 32-deep slices in two stages");
     static_assert(X3 != 3 || (PH8 == 3 && BK == 64), "x8 form: the phased 256 x 256 K loop");
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV), "PH8 configuration");
     static_assert(!X3 || !CONV, "split-f16 variants: plain GEMM");
@@ -1484,11 +1484,15 @@ static int g_ring64 = 0;
 // 74.9 -> 69.4 us, 4096^3 1007 -> 1091 TF/s, 8192^3 1053 -> 1191; bitwise equal to the 2-buffer loop on 360 / 360 repetitions);
 // 0 = the plain 2-buffer loop, 1 / 2 = the other copy placements (psalm_gemm_set_tile_policy 2560 / 2568..2570)
 static int g_ph8 = 3;
-// split-f16 GEMMs on the 128x128 / 64x128 tiles: 0 = the K-panel form (3 Kp-long loop; default), 1 = "slice" K loop (4 operand images per
-// 64-deep slice, 3 products per barrier), 2 = the same with 32-deep slices in a 4-deep ring.  psalm_gemm_set_tile_policy 3300 / 3301 / 3302.
-// r02 sweep (profiles/r02l_gemm_x3_slice_ab.json): the slice form's 128 KB / 96 KB stages leave ONE block per CU and lose to the K-panel
-// form at 2-3 blocks per CU on every short-K problem (M4096 N2048 K512: 74 vs 50 us); it wins only where a long K meets a grid that
+// split-f16 GEMMs on the 128x128 / 64x128 tiles, K loop form (psalm_gemm_set_tile_policy 3300 + v):
+//   v = 0  automatic (below)                    1  "slice" K loop: 4 operand images per 64-deep slice, 3 products per barrier
+//   2  32-deep slices in a 4-deep ring          3 / 4  32-deep slices in a 2- / 3-deep ring       5  the K-panel form (3 Kp-long loop)
+// r02 sweep (profiles/r02l_gemm_x3_slice_ab.json): forms 1 / 2 need 128 KB / 96 KB stages, leave ONE block per CU and lose to the K-panel
+// form at 2-3 blocks per CU on every short-K problem (M4096 N2048 K512: 74 vs 50 us); 1 wins only where a long K meets a grid that
 // 64 x 128 tiles can fill without split-K (M4096 N512 K2048, Swin stage-2 fc2: 39 vs 53 us) -- select_fast_config picks it there.
+// r03 sweep (profiles/r03h_gemm_x3_sweep_slice32.json): form 3 keeps the K-panel form's LDS footprint (64 KB on 128^2: two blocks per CU)
+// with 1.5x the matrix work per copy round trip and 2/3 of the copies: 3-17 % faster on 17 of 21 shapes of the image (M5184 N512 K512
+// 22.0 -> 18.3 us, M21504 N256 K1024 60.3 -> 52.6, M65536 N128 K512 43.4 -> 38.1), equal within noise on the rest: the automatic choice.
 static int g_x3_slice = 0;
 static bool g_x3_auto_slice = false;    // set by select_fast_config: this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
@@ -1498,7 +1502,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
-    if (bm >= 3300 && bm <= 3304) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
+    if (bm >= 3300 && bm <= 3305) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
@@ -1604,7 +1608,8 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (x8) { BM = BN = 256; splits = x8_splits(M, N, K, workspace != nullptr, workspace_bytes); }   // x8 form: the phased 256 x 256 kernel only
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-    const int slice = !x3 || BM == 256 || fa.so ? 0 : (g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 ? 1 : 0));
+    int slice = !x3 || x8 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
+    if (fa.so && slice != 3) slice = 0;                           // split-f16 output: K-panel form or form 3
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
         kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
@@ -1635,7 +1640,9 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
         // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
         // with 1.5x the matrix work per copy round trip
-        if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);
+        if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);
+        else if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);
+        else if (slice == 3 && fa.so) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true);
         else if (slice == 3) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, false);
         else if (slice == 4) GO(256, "float", float, 64, 128, 2, 2, 3, false, 32, 0, 2, false);
         else if (BM == 128 && slice == 2) GO(256, "float", float, 128, 128, 2, 2, 4, false, 32, 0, 2, false);

@@ -374,6 +374,173 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
     }
 }
 
+// ---- the same pass as TWO wave groups per CU that run half a tile apart (r03: the one-group kernel above serialises load latency, the
+// sigmoid / split VALU work, the matrix phase and the stores of a tile -- 15 us per 128-pixel tile, 2.0 TB/s).  One persistent block of 8
+// waves per CU; group g = wave >> 2 owns every other 64-pixel tile of the block and walks   X | C | M1 | M2   with a block barrier after each
+// slot, group 1 two slots behind group 0 -- so one group's VALU slots (X: wait for the logits, sigmoids, pixel maxima; C: per-pixel scale,
+// split into f16 hi / lo, 8-byte LDS writes) run beside the other group's matrix slots (M1 / M2: 3 products per class tile and k-step; M2
+// ends with the stores), on the same SIMDs.  The logits of a group's NEXT tile are requested at the end of X and consumed three slots
+// later; the wait there is a counted vmcnt (the stores issued in between are unconditional buffer stores -- out-of-range ones carry an
+// offset the descriptor drops -- so the count is static).  K is padded to KP = 112 when Q allows (7 instead of 8 k-steps; LDS 136 KB).
+template <int KP>
+__global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(const float* __restrict__ mask, const float* __restrict__ probsT,
+                                                                             float* __restrict__ out, float* __restrict__ partial, int Q,
+                                                                             int C, long HW, int ntiles) {
+    constexpr int PITCH = KP + 4, CT = 5, NI = KP / 4, KS = KP / 16, KS1 = (KS + 1) / 2;
+    constexpr float SC = 8192.0f;
+    __shared__ __attribute__((aligned(16))) unsigned short Ph[CT * 32 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Pl[CT * 32 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Sh[2][64 * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Sl[2][64 * PITCH];
+    __shared__ float pmax[2][4][64];                          // per-wave maximum logit of each pixel of the group's tile
+    __shared__ float oinv_s[2][64];                           // 1 / (2^13 * pixel scale) for the stores
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, w = wave & 3;
+    for (int e = tid; e < CT * 32 * KP; e += 512) {           // probsT (C, 128) f32 -> hi / lo in LDS (probabilities <= 1: scale 2^13), zero rows beyond C
+        const int c = e / KP, k = e % KP;
+        unsigned short h = 0, l = 0;
+        if (c < C) {
+            const float a = probsT[(long)c * 128 + k] * SC;
+            const _Float16 hh = (_Float16)a;
+            h = __builtin_bit_cast(unsigned short, hh);
+            l = __builtin_bit_cast(unsigned short, (_Float16)(a - (float)hh));
+        }
+        Ph[c * PITCH + k] = h;
+        Pl[c * PITCH + k] = l;
+    }
+    const psalm_rsrc orsrc = psalm_make_rsrc(out, (unsigned)((unsigned long)C * (unsigned long)HW * 4ul));
+    const psalm_rsrc mrsrc = psalm_make_rsrc(mask, (unsigned)((unsigned long)Q * (unsigned long)HW * 4ul));
+    const unsigned row_bytes = (unsigned)HW * 4u;
+    const int qb = w * NI;                                    // this wave's queries in the VALU slots: [qb, qb + NI)
+    const int ps = w & 1, u0 = (w >> 1) ? 3 : 0, nu = (w >> 1) ? 2 : 3;   // matrix slots: pixel half ps, class tiles u0 .. u0 + nu - 1
+    const int iters = (ntiles + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x);
+    float num[NI], den[NI], m[NI], sg[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
+    auto tile_of = [&](int it) { return (long)blockIdx.x + (long)gridDim.x * (2 * it + grp); };
+    auto request = [&](int it) {                              // unconditional clamped loads: NI in flight per lane
+        const long t = min(tile_of(it), (long)ntiles - 1);
+        const unsigned voff = (unsigned)min(t * 64 + lane, HW - 1) * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) m[i] = psalm_buf_load_f32_s(mrsrc, voff, (unsigned)min(qb + i, Q - 1) * row_bytes);   // row offset: SGPR
+    };
+    request(0);
+    // 48 dropped stores behind the first request: the loop's wait for a tile's logits then sees the SAME instruction stream behind them on
+    // the entry path as on the back edge (48 stores of the previous tile) and the compiler's counted vmcnt stays exact
+#pragma unroll
+    for (int r = 0; r < 48; ++r) psalm_buf_store_f32(0.f, orsrc, PSALM_BUF_OOB + 4u * r);      // (distinct addresses: not merged)
+    __syncthreads();                                          // P staged
+    if (grp == 1) { PSALM_RAW_BARRIER(); PSALM_RAW_BARRIER(); }
+    for (int it = 0; it < iters; ++it) {
+        const long t = tile_of(it);
+        const bool live = t < ntiles;
+        const long p0 = min(t, (long)ntiles - 1) * 64;
+        const bool v = live && p0 + lane < HW;
+        // ---- X: sigmoids, mask-score sums, this wave's maximum logit per pixel; then the next tile's logits are requested
+        float xm = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float x = v ? m[i] : 0.f;
+            const bool vq = qb + i < Q;
+            const float sv = sigmoidf_(x);
+            sg[i] = vq ? sv : 0.f;
+            if (vq) xm = fmaxf(xm, m[i]);
+            const bool pos = vq && x > 0.f;
+            num[i] += pos ? sv : 0.f;
+            den[i] += pos ? 1.f : 0.f;
+        }
+        pmax[grp][w][lane] = xm;
+        if (it + 1 < iters) request(it + 1);
+        PSALM_RAW_BARRIER();
+        // ---- C: power of two placing the pixel's largest sigmoid in [2^12, 2^14) (see the one-group kernel); split; LDS
+        {
+            const float mxl = fmaxf(fmaxf(pmax[grp][0][lane], pmax[grp][1][lane]), fmaxf(pmax[grp][2][lane], pmax[grp][3][lane]));
+            const float smax = sigmoidf_(mxl);
+            const int e = (int)((__builtin_bit_cast(unsigned, smax) >> 23) & 0xffu) - 127;
+            int se = 13 - e;
+            se = se > 100 ? 100 : se;
+            const bool zero = !(smax > 0.f);
+            const float sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+            const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+            if (w == 0) oinv_s[grp][lane] = inv * (1.0f / SC);
+            unsigned short* sh = &Sh[grp][lane * PITCH + qb];
+            unsigned short* sl = &Sl[grp][lane * PITCH + qb];
+#pragma unroll
+            for (int i = 0; i < NI; i += 4) {
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = sg[i + k] * sc;
+                    const _Float16 hh = (_Float16)a;
+                    hw[k] = __builtin_bit_cast(unsigned short, hh);
+                    lw[k] = __builtin_bit_cast(unsigned short, (_Float16)(a - (float)hh));
+                }
+                *reinterpret_cast<psalm_u32x2*>(sh + i) = psalm_u32x2{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16)};
+                *reinterpret_cast<psalm_u32x2*>(sl + i) = psalm_u32x2{lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16)};
+            }
+        }
+        PSALM_RAW_BARRIER();
+        // ---- M1 / M2: (class tile, k-step) = hi.hi + lo.hi + hi.lo, fp32 accumulate
+        pp_f32x16 acc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        auto frag = [&](const unsigned short* base) -> pp_f16x8 {
+            const unsigned long long* p = reinterpret_cast<const unsigned long long*>(base);
+            const unsigned long long a0 = p[0], a1 = p[1];
+            return __builtin_bit_cast(pp_f16x8, psalm_u32x4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)});
+        };
+        auto ksteps = [&](int k0, int k1) {
+#pragma unroll
+            for (int kk = k0; kk < k1; ++kk) {
+                const int ko = 16 * kk + 8 * hi;
+                const pp_f16x8 bh = frag(&Sh[grp][(32 * ps + n) * PITCH + ko]), bl = frag(&Sl[grp][(32 * ps + n) * PITCH + ko]);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (u < nu) {
+                        const pp_f16x8 ah = frag(&Ph[(32 * (u0 + u) + n) * PITCH + ko]), al = frag(&Pl[(32 * (u0 + u) + n) * PITCH + ko]);
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        ksteps(0, KS1);
+        PSALM_RAW_BARRIER();
+        ksteps(KS1, KS);
+        {
+            const float oinv = oinv_s[grp][32 * ps + n];
+            const bool pv = live && p0 + 32 * ps + n < HW;
+            // lane part of the address: the pixel inside a class row + this half-wave's 4 rows; the class row of (u, r) is wave-uniform
+            const unsigned pix = pv ? (unsigned)(p0 + 32 * ps + n) * 4u + (unsigned)(4 * hi) * row_bytes : PSALM_BUF_OOB;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cb = 32 * (u0 + u) + (r & 3) + 8 * (r >> 2);
+                    const bool ok = u < nu && cb + 4 * hi < C;
+                    psalm_buf_store_f32_s(acc[u][r] * oinv, orsrc, ok ? pix : PSALM_BUF_OOB, (unsigned)min(cb, C - 1) * row_bytes);
+                }
+        }
+        PSALM_RAW_BARRIER();
+    }
+    if (grp == 0) { PSALM_RAW_BARRIER(); PSALM_RAW_BARRIER(); }
+    if (partial) {                                            // (q, 2 * block + group, 2) partial sums -> mask_score_final_kernel (fixed order)
+        const long nb = 2 * (long)gridDim.x, b = 2 * (long)blockIdx.x + grp;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = qb + i;
+            const float a = wave_sum(num[i]), bsum = wave_sum(den[i]);
+            if (lane == 0 && q < Q) {
+                partial[(q * nb + b) * 2 + 0] = a;
+                partial[(q * nb + b) * 2 + 1] = bsum;
+            }
+        }
+    }
+}
+
 // fp32-class form: probsT (C, 128) FLOAT32 (psalm_class_softmax with an fp32 transposed copy); otherwise as psalm_semantic_from_masks.
 extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* probsT_f32, float* out, float* mask_score, float* workspace,
                                             int Q, int C, long HW, int Kpad, void* stream) {
@@ -381,6 +548,19 @@ extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* prob
     PSALM_CHECK_ARG(mask_score == nullptr || workspace != nullptr, "psalm_semantic_from_masks_x3: mask_score needs the workspace");
     PSALM_CHECK_ARG(HW <= (1L << 27), "psalm_semantic_from_masks_x3: HW <= 2^27 (32-bit lane offsets)");
     if (HW == 0) return 0;
+    if ((unsigned long)C * (unsigned long)HW * 4ul < (1ul << 31) && (unsigned long)Q * (unsigned long)HW * 4ul < (1ul << 31)) {          // the buffer descriptor of the stores spans `out` (offsets >= 2^31: dropped)
+        const int nt64 = (int)((HW + 63) / 64);
+        const int grid2 = nt64 < 512 ? (nt64 + 1) / 2 : 256;                  // 1 persistent block (two wave groups) per CU
+        if (Q <= 112)
+            hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<112>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
+                               mask_score ? workspace : nullptr, Q, C, HW, nt64);
+        else
+            hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<128>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
+                               mask_score ? workspace : nullptr, Q, C, HW, nt64);
+        if (mask_score)
+            hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, 2 * grid2);
+        PSALM_LAUNCH_END("psalm_semantic_from_masks_x3");
+    }
     const int ntiles = (int)((HW + 127) / 128);
     const int grid = ntiles < 256 ? ntiles : 256;            // 1 persistent block per CU (LDS 152 KB)
     if (Q <= 100)

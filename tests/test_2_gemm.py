@@ -280,8 +280,9 @@ X3_CASES = [
 ]
 
 
-# K loop forms: 3300 K-panel (default) on every case; 3301 slice form / 3302 32-deep slices in a 4-deep ring on the tiled (policy != 0) cases
-X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302, 3303, 3304)]
+# K loop forms: 3300 automatic (32-deep slices, 2 stages = 3303) on every case; the others (3301 64-deep slices, 3302 / 3304 deeper rings, 3305 K panel)
+# on the tiled (policy != 0) cases
+X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302, 3304, 3305)]
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy,kloop", X3_PARAMS)
@@ -326,7 +327,7 @@ def split_bound_par(w, bias, g1=0.0, g0=0.0):
     (300, 520, 128, H.ACT_GELU, 256, 256, 0, True),        # 256 x 256 tiles, two LDS passes (m-tiles of both wave rows per pass), ragged last tiles
     (300, 264, 192, H.ACT_RELU, 128, 64, 0, False),        # col_start inside a tile: its fp32 columns leave through the same LDS image
 ])
-def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glob):
+def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glob, kloop=3300):
     """psalm_gemm_x3_split: the columns >= col_start of act(a.w^T + b) leave the GEMM as split-f16 rows [hi | lo] under a per-row power-of-two
     scale derived from a magnitude bound.  Checked: the bound holds (|hi| < 2^13), the scales are powers of two, hi + lo reproduces the fp32
     result of psalm_gemm_x3 to 2^-21 (22-bit operand), the columns below col_start equal psalm_gemm_x3's bit for bit, and the NEXT GEMM on the
@@ -341,6 +342,7 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     g1, g0 = (2.0 ** 14 * 3.0, 0.5) if glob else (0.0, 0.0)
     par = split_bound_par(w[col_start:], bias[col_start:], g1, g0).to(d)
     ops.gemm_tile_policy(policy)
+    ops.gemm_tile_policy(kloop)
     try:
         asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
         want = ops.gemm_x3(asp, wsp, bias.to(d), None, act, col_start)
@@ -350,6 +352,7 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
         ops.gemm_x3_split(asp, wsp, bias.to(d), act, so, inv, par, split_col_off=col_off, split_col_start=col_start, act_col_start=col_start,
                           out=out, global_rows=glob)
     finally:
+        ops.gemm_tile_policy(3300)
         ops.gemm_tile_policy(0)
     so, inv, want = so.cpu(), inv.cpu(), want.cpu()
     if col_start:
@@ -385,6 +388,12 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     y2 = ops.gemm_x3(x.to(d), w2.to(d)).cpu().double()
     mag = x.abs().double() @ w2.abs().double().t()
     assert ((y1 - y2).abs() <= 8 * 2.0 ** -22 * mag + 1e-9).all()
+
+
+def test_gemm_x3_split_output_k_panel_form(ops):
+    """the automatic K loop of the 128 / 64-row tiles is the 32-deep slice form (policy 3303); the K-panel form (3305) stays selectable"""
+    test_gemm_x3_split_output(ops, 300, 264, 192, H.ACT_RELU, 128, 0, 64, False, kloop=3305)
+    test_gemm_x3_split_output(ops, 131, 384, 64, H.ACT_GELU_NEW, 64, 256, 8, True, kloop=3305)
 
 
 @pytest.mark.parametrize("loose_bits", [0, 10, 13])
@@ -610,7 +619,7 @@ X8_CASES = [
     # M, N, K, bias, res, act
     (300, 520, 256, True, True, H.ACT_RELU),                # 4 f16 + 4 e4m3 K tiles, ragged tiles, fp32 direct epilogue
     (257, 256, 128, False, False, H.ACT_NONE),              # 2 + 2 tiles: prologue / drain only, the kind switch inside the drain
-    (300, 300, 1920, True, True, H.ACT_NONE),               # split-K: slices on either side of the hi / e4m3 boundary and one across it
+    (140, 100, 1920, True, True, H.ACT_NONE),               # split-K: slices on either side of the hi / e4m3 boundary and one across it
     (100, 72, 384, True, False, H.ACT_GELU),                # M <= 128 (no skinny kernel in this form), erf epilogue through the LDS
 ]
 
