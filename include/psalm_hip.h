@@ -123,7 +123,12 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
  * g1, g0};  bound_r = max(a_scale[r] * par[0] + par[1], (global_rows ? max_r a_scale[r] : 0) * g1 + g0)  (the second term: the caller's
  * bound for values ANOTHER kernel writes into the same rows, see psalm_causal_attention_f32_split);  bound_r * scale in [2^12, 2^13);
  * 1/scale -> split_inv[r].  Columns < split_col_start go to C (fp32) as in psalm_gemm_x3.  No residual, no split-K; N and the column
- * arguments are multiples of 8.  Columns of split_out this call does not write (K padding) are the caller's to zero. */
+ * arguments are multiples of 8.  Columns of split_out this call does not write (K padding) are the caller's to zero.
+ * split_form: 0 f16 lo / 1 e4m3 pairs (x8 A operand), + 4 = PAIRED stores: the caller has permuted the W rows (with their w_scale and
+ * bias entries) >= split_col_start inside every group of 64 -- physical row 64 g + 32 b + n holds logical row 64 g + 2 n + b -- so that a
+ * lane of the accumulator layout owns two ADJACENT output columns and the operand leaves in 4-byte stores of whole 128-byte row segments
+ * straight from the registers (no LDS transpose).  Output identical bit for bit.  Needs split_col_start % 256 == 0,
+ * (N - split_col_start) % 64 == 0, split_out < 2 GiB. */
 /* x = A.W^T + bias + residual (fp32 -> C) followed by LayerNorm(x) leaving as the split-f16 operand of the next GEMM (and optionally as
  * fp32 rows ln_out): the residual GEMM + the following block's input LayerNorm of a pre-norm layer (Phi [dense | fc2] + residual, then the
  * next input_layernorm, modeling_phi.py:263-300).  With split-K the partial-sum reduce, epilogue, LayerNorm and split are ONE row pass.

@@ -312,6 +312,11 @@ struct GemmFastArgs {
     long ldso = 0;
     int so_kp = 0, so_col_off = 0, so_col_start = 0, so_global = 0;
     int so_form = 0;    // second half-word of the emitted operand: 0 f16 lo, 1 e4m3 pair of an A operand (psalm_split_words)
+    // so_paired: the W rows (and bias / w_scale entries) >= so_col_start were PERMUTED by the caller inside every group of 64 -- physical row
+    // 64 g + 32 b + n holds logical row 64 g + 2 n + b (psalm_gemm_x3_split, split_form bit 2) -- so that the two 32-column MFMA tiles of a
+    // wave hold ADJACENT logical columns in the same lane: the 2-byte outputs leave as 4-byte stores of 128-byte row segments straight from
+    // the accumulators (the fp32 tiles' store pattern, r03b: 5.6 TB/s) instead of through the LDS transpose.
+    int so_paired = 0;
     float* so_inv = nullptr;
     const float* so_par = nullptr;
 };
@@ -359,8 +364,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // SO = true (X3 == 1 only): the epilogue can emit split-f16 output (GemmFastArgs::so; psalm_gemm_x3_split).  A separate instantiation so that
 // the plain kernels' epilogue -- at the register limit on the 256 x 256 tile -- is untouched.
 template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8 = 0, int X3 = 0,
-          bool SO = false>
+          bool SO = false, bool PAIR = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+    static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || X3 == 3 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel / x8 form, or 32-deep slices in two stages");
     static_assert(X3 != 3 || (PH8 == 3 && BK == 64), "x8 form: the phased 256 x 256 K loop");
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV), "PH8 configuration");
@@ -840,6 +846,46 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 actc[j] = act != ACT_NONE && col >= g.act_col_start;
                 soc[j] = col >= fa.so_col_start;
             }
+            if constexpr (PAIR) {                                     // (host: so_col_start % BN == 0 -- no tile straddles it)
+                static_assert(TN == 2, "paired split-f16 output: two 32-column tiles per wave");
+                const psalm_rsrc srs = psalm_make_rsrc(fa.so, (unsigned)((long)g.M * fa.ldso * 2));
+                const int lc = bn + wn * (BN / WN) + 2 * n32;                 // logical column of this lane's j = 0 element; j = 1: lc + 1
+                const unsigned cbyte = lc + 1 < g.N ? (unsigned)(fa.so_col_off + (lc - fa.so_col_start)) * 2u : PSALM_BUF_OOB;
+                const unsigned second = (unsigned)fa.so_kp * 2u;
+                const bool writes_inv = bn == fa.so_col_start && wn == 0 && n32 == 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row0 = bm + wm * (BM / WM) + i * 32 + 4 * hi;
+                    float asc[16], sc[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        asc[r] = fa.a_scale[min(row, g.M - 1)];
+                        float inv_;
+                        split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
+                        if (writes_inv && row < g.M) fa.so_inv[row] = inv_;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        float x0 = acc[i][0][r] * (asc[r] * wsc[0]) + bias_c[0];
+                        float x1 = acc[i][1][r] * (asc[r] * wsc[1]) + bias_c[1];
+                        if (actc[0]) x0 = apply_act(x0, act);
+                        if (actc[1]) x1 = apply_act(x1, act);
+                        unsigned h0, s0, h1, s1;
+                        psalm_split_words(x0 * sc[r], fa.so_form, h0, s0);
+                        psalm_split_words(x1 * sc[r], fa.so_form, h1, s1);
+                        const unsigned off = row < g.M && cbyte != PSALM_BUF_OOB ? (unsigned)row * (unsigned)(fa.ldso * 2) + cbyte : PSALM_BUF_OOB;
+                        psalm_buf_store_u32(h0 | (h1 << 16), srs, off);
+                        psalm_buf_store_u32(s0 | (s1 << 16), srs, off == PSALM_BUF_OOB ? off : off + second);
+                    }
+                }
+                PSALM_TL(4);
+                PSALM_TL_DRAIN();
+                PSALM_TL(5);
+                return;
+            }
+            if constexpr (!PAIR) {
             const int c8 = (tid % TPR) * 8, col0 = bn + c8;
             float* C = (float*)g.C;
 #pragma unroll                                                     // (unrolled: acc[e * TMP + ii] must be a compile-time register choice)
@@ -911,6 +957,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             PSALM_TL_DRAIN();
             PSALM_TL(5);
             return;
+            }
         }
     }
     // ---- epilogue through LDS (bf16 outputs, erf / tanh activations on fp32 outputs): the accumulator layout (lane = one column, 16 scattered rows)
@@ -1627,6 +1674,13 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     else fa.vec_store = (N % 8 == 0 && (uintptr_t)g.C % 16 == 0 && (g.ldc * csz) % 16 == 0 &&
                          (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
     const dim3 grid((unsigned)tiles, splits);
+    if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
+        const bool ph_ = x3 && !x8 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
+        if (!(x8 || slice == 3 || ph_) || fa.so_col_start % BN != 0) {
+            psalm_set_error("psalm_gemm_x3_split: paired output is not available under this tile policy / for this column start");
+            return -1;
+        }
+    }
     const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
     // every launch goes through GO(): it records the exact template instantiation (psalm_gemm_last_kernel: the name a kernel trace shows,
     // so that per-kernel attributions made from launch arguments -- bench.py -- agree with rocprofv3) and launches it
@@ -1640,7 +1694,9 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
         // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
         // with 1.5x the matrix work per copy round trip
-        if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);
+        if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
+        else if (slice == 3 && fa.so && fa.so_paired) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true, true);
+        else if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);
         else if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);
         else if (slice == 3 && fa.so) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true);
         else if (slice == 3) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, false);
@@ -1651,13 +1707,15 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);
     } else if (x8) {                                              // split-f16 operands with e4m3 cross-term halves (K range 2 Kp)
         if (fa.k_per_split < 128 || (K - (splits - 1) * fa.k_per_split) < 128) { psalm_set_error("psalm_gemm_x3 (x8): K range too short"); return -1; }
-        if (fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true);
+        if (fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true, true);
+        else if (fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true);
         else GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, false);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
         const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
         const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
 #define GO_X3(NT_, ...) do { if (fa.so) GO(NT_, "float", float, __VA_ARGS__, true); else GO(NT_, "float", float, __VA_ARGS__, false); } while (0)
-        if (ph) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 3, 1);
+        if (ph && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 1, true, true);
+        else if (ph) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 3, 1);
         else if (BM == 256) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 0, 1);
         else if (BM == 128 && g_ring_depth == 3) GO_X3(256, 128, 128, 2, 2, 3, false, 64, 0, 1);
         else if (BM == 128) GO_X3(256, 128, 128, 2, 2, 2, false, 64, 0, 1);
@@ -2008,7 +2066,7 @@ extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, fl
 // C = act((A . W^T) + bias) + residual from split-f16 operands:  A2 (M, 2 Kp) / W2 (N, 2 Kp) f16 [hi | lo] with row strides lda / ldw
 // (elements) and per-row scales a_scale (M) / w_scale (N) as written by psalm_split_f16;  Kp % 64 == 0.  C / residual fp32.
 // Same tile selection, split-K and epilogue as psalm_gemm (on a K range of 3 Kp); M <= 128 problems take the skinny kernel.
-struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; int so_form; };
+struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; int so_form; int so_paired; };
 static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
                         const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
                         int act_col_start, void* workspace, long workspace_bytes, void* stream, const SplitOut* so, const char* name,
@@ -2039,7 +2097,7 @@ static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const vo
     if (so) {
         fa.so = (unsigned short*)so->so; fa.ldso = so->ldso; fa.so_kp = so->so_kp; fa.so_col_off = so->so_col_off;
         fa.so_col_start = so->so_col_start; fa.so_global = so->so_global; fa.so_inv = so->so_inv; fa.so_par = so->so_par;
-        fa.so_form = so->so_form;
+        fa.so_form = so->so_form; fa.so_paired = so->so_paired;
     }
     return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, true, x8 != 0);
 }
@@ -2061,14 +2119,18 @@ extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scal
                                    const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out,
                                    long ld_split, int split_kp, int split_col_off, int split_col_start, int split_form, float* split_inv,
                                    const float* bound_par, int global_rows, void* workspace, long workspace_bytes, void* stream) {
-    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_gemm_x3_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand)");
+    const int paired = (split_form >> 2) & 1;                    // bit 2: W rows >= split_col_start permuted for paired stores (GemmFastArgs::so_paired)
+    split_form &= 3;
+    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_gemm_x3_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand), + 4: paired");
+    PSALM_CHECK_ARG(!paired || (split_col_start % 256 == 0 && (N - split_col_start) % 64 == 0 && (long)M * ld_split * 2 < (1L << 31)),
+                    "psalm_gemm_x3_split: paired output needs split_col_start % 256 == 0, (N - split_col_start) % 64 == 0, split_out < 2 GiB");
     PSALM_CHECK_ARG(split_out && split_inv && bound_par, "psalm_gemm_x3_split: split output, scale array and bound parameters required");
     PSALM_CHECK_ARG(N % 8 == 0 && split_col_start % 8 == 0 && split_col_start >= 0 && split_col_start < N && split_col_off % 8 == 0 &&
                         split_col_off >= 0 && split_kp % 8 == 0 && (uintptr_t)split_out % 16 == 0 && (ld_split * 2) % 16 == 0 &&
                         split_col_off + (N - split_col_start) <= split_kp && ld_split >= 2L * split_kp,
                     "psalm_gemm_x3_split: N / column offsets multiples of 8, 16-byte aligned split rows of >= 2*split_kp f16");
     PSALM_CHECK_ARG(C || split_col_start == 0, "psalm_gemm_x3_split: C required for the columns below split_col_start");
-    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par, split_form};
+    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par, split_form, paired};
     return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
                         stream, &so, "psalm_gemm_x3_split");
 }

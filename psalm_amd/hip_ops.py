@@ -288,10 +288,11 @@ class Ops:
         return x, SplitF16(so, inv, N, split_form), y
 
     def gemm_x3_split(self, a, w, bias, act, split_out, split_inv, bound_par, split_col_off=0, split_col_start=0, act_col_start=0,
-                      out=None, global_rows=False, split_form=0):
+                      out=None, global_rows=False, split_form=0, paired=False):
         """gemm_x3 whose columns >= split_col_start are written as the split-f16 A operand of the next GEMM: into `split_out` (a SplitF16's
         .t buffer (M, 2*Kp_out) f16) at columns split_col_off.. (hi) / Kp_out + split_col_off.. (lo), row scales (inverse) into split_inv;
-        bound_par: 4 device floats, see psalm_gemm_x3_split.  Columns below split_col_start go to `out` (M, >= split_col_start...) fp32."""
+        bound_par: 4 device floats, see psalm_gemm_x3_split.  Columns below split_col_start go to `out` (M, >= split_col_start...) fp32.
+        paired: the rows of `w` (and bias) >= split_col_start were permuted with `so_pair_perm` (stores straight from the accumulators)."""
         a, w, x8 = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if split_out.dtype != torch.float16 or split_out.dim() != 2 or split_out.shape[0] != M or split_out.stride(1) != 1:
@@ -306,12 +307,21 @@ class Ops:
                                           self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(out),
                                           c_long(out.stride(0) if out is not None else 0), M, N, act, act_col_start,
                                           self._p(split_out), c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
-                                          split_col_start, split_form, self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
+                                          split_col_start, split_form | (4 if paired else 0), self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
                                           self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_split")
         if _DEBUG_BOUNDS or self.debug_bounds:
             self.check_split_bound(split_out, split_col_off, N - split_col_start, "gemm_x3_split")
         return split_out
+
+    @staticmethod
+    def so_pair_perm(n: int) -> torch.Tensor:
+        """Row permutation of a weight (and its bias) whose GEMM emits split-f16 output with paired stores (psalm_gemm_x3_split, split_form
+        bit 2): index tensor `c` with W_physical = W_logical[c]; physical row 64 g + 32 b + j holds logical row 64 g + 2 j + b.  n % 64 == 0."""
+        if n % 64:
+            raise PsalmHipError("so_pair_perm: n % 64 == 0")
+        p = torch.arange(n)
+        return (p // 64) * 64 + 2 * (p % 32) + (p % 64) // 32
 
     def check_split_bound(self, split_out, col_off, ncols, what=""):
         """Looseness of the scale bound of an emitted split-f16 operand: the scale puts the BOUND in [2^12, 2^13), so 2^13 / max |hi| over a

@@ -97,7 +97,8 @@ class PSALM:
     DEFAULT_PRECISION = "f16x3"
 
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
-                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8: Optional[bool] = None):
+                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8: Optional[bool] = None,
+                 paired_split_stores: Optional[bool] = None):
         precision = precision or self.DEFAULT_PRECISION
         if precision not in ("bf16", "fp32", "f16x3"):
             raise ValueError("precision must be 'f16x3', 'fp32' or 'bf16'")
@@ -128,6 +129,11 @@ class PSALM:
         # f16x3: GEMM / attention outputs that feed another GEMM leave their kernel already in split-f16 operand form (psalm_gemm_x3_split,
         # psalm_*_attention*_split, psalm_gemm_x3_ln_split) instead of fp32 + a psalm_split_f16 pass.  False: the r02k data flow (tools/exp_modes.py A/B)
         self.fuse_split = precision == "f16x3"
+        # ... and where the emitting kernel is a GEMM (Swin fc1, encoder linear1, Phi fc1) the weight rows are stored PERMUTED inside groups
+        # of 64 (H.Ops.so_pair_perm) so that the 2-byte operand leaves in 4-byte stores of whole 128-byte row segments straight from the
+        # accumulators (psalm_gemm_x3_split, split_form bit 2) -- results bit for bit those of the un-permuted layout.  A construction-time
+        # choice (the weights are laid out for it): such a model cannot be switched to fuse_split = False afterwards.
+        self.so_paired = self.fuse_split if paired_split_stores is None else (bool(paired_split_stores) and self.fuse_split)
         # f16x3: the Phi decoder's GEMMs form their two cross terms (lo.hi + hi.lo, 2^-11 of the result) as ONE e4m3 dot product on the
         # block-scaled fp8 matrix instruction (operand form "x8", csrc/common.h psalm_split_words): 2 instead of 3 f16-product equivalents
         # for 2/3 of the path's GEMM flops.  Decided on numerics first (tools/exp_fp8cross.py, profiles/r03d_*: over 10 weight / input
@@ -139,6 +145,7 @@ class PSALM:
         self.llm_x8 = can_x8 if llm_cross_fp8 is None else (bool(llm_cross_fp8) and can_x8)
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
+        self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
         self.config = None                            # LlavaConfig when built by from_pretrained (llava_phi.py:34)
         self.image_processor = None                   # dict of pre-processors, set by from_pretrained / load_pretrained_model
         self.training = False
@@ -229,6 +236,14 @@ class PSALM:
     def _wop(self, t):                    # an ACTIVATION used as the W operand of a GEMM (mask features, class embeddings, ...)
         return self.ops.split_f16(t) if self.x3 and t is not None and t.shape[0] > 4096 else t
 
+    def _pair_rows(self, wt, bias, start=0):
+        """(weight, bias, paired?) with the rows >= start permuted for paired split-f16 stores, when the shape allows it"""
+        n = wt.shape[0] - start
+        if not (self.so_paired and self.x3) or n <= 0 or n % 64 or start % 256:
+            return wt, bias, False
+        idx = torch.cat([torch.arange(start), start + H.Ops.so_pair_perm(n)]).to(wt.device)
+        return wt.detach()[idx], (bias.detach()[idx.to(bias.device)] if bias is not None else None), True
+
     def _gemm_act_split(self, a, name, act):
         """f16x3: act(a . W^T + b) of linear `name` straight into the split-f16 operand form of the GEMM that consumes it (no fp32 round
         trip, no psalm_split_f16 pass); None when the shape does not allow it (caller falls back to gemm + implicit split)."""
@@ -236,13 +251,17 @@ class PSALM:
         wt = w[name + ".w"]
         bnd = w.get(name + ".bnd")
         N = wt.shape[0]
+        paired = self.paired.get(name, False)
         if not self.fuse_split or bnd is None or N % 8 != 0 or not isinstance(wt, H.SplitF16):
+            if paired:
+                raise H.PsalmHipError(f"{name}: weight rows are laid out for paired split-f16 stores (PSALM(paired_split_stores=True)); "
+                                      "build the model with paired_split_stores=False to run it with fuse_split off")
             return None
         rows = a.shape[0]
         Kp = (N + 63) // 64 * 64                                      # the consumer's K padding columns must read as zeros
         so = (o.empty if Kp == N else o.zeros)(rows, 2 * Kp, dtype=torch.float16)
         inv = o.empty(rows, dtype=torch.float32)
-        o.gemm_x3_split(a, wt, w.get(name + ".b"), act, so, inv, bnd)
+        o.gemm_x3_split(a, wt, w.get(name + ".b"), act, so, inv, bnd, paired=paired)
         return H.SplitF16(so, inv, N)
 
     def _F(self, t):                      # fp32 parameter (bias, norm scale, tables)
@@ -252,10 +271,13 @@ class PSALM:
         cfg, w = self.cfg, self.w
         W, Fp = self._W, self._F
 
-        def lin(dst, src, bias=True, small=False):
-            w[dst + ".w"] = (self._Ws if small else W)(sd[src + ".weight"])
-            if bias and (src + ".bias") in sd:
-                w[dst + ".b"] = Fp(sd[src + ".bias"])
+        def lin(dst, src, bias=True, small=False, pair=False):
+            wt, bs = sd[src + ".weight"], (sd[src + ".bias"] if bias and (src + ".bias") in sd else None)
+            if pair:                                      # this linear's GEMM emits split-f16 output: rows permuted for paired stores
+                wt, bs, self.paired[dst] = self._pair_rows(wt, bs)
+            w[dst + ".w"] = (self._Ws if small else W)(wt)
+            if bs is not None:
+                w[dst + ".b"] = Fp(bs)
 
         def norm(dst, src):
             w[dst + ".g"] = Fp(sd[src + ".weight"])
@@ -286,14 +308,15 @@ class PSALM:
             a = p + "self_attn."
             w1 = torch.cat([sd[a + "k_proj.weight"], sd[a + "v_proj.weight"], sd[a + "q_proj.weight"], sd[p + "mlp.fc1.weight"]], 0)
             w2 = torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1)
+            b1 = torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"], sd[p + "mlp.fc1.bias"]], 0)
+            w1, b1, self.paired[f"llm{i}"] = self._pair_rows(w1, b1, 3 * cfg.hidden_size)      # the fc1 rows: gelu(fc1) leaves as fc2's operand
             if self.llm_x8:                        # split-f16 with e4m3 cross-term halves (W operand form)
                 for nm, mat in (("w1", w1), ("w2", w2)):
                     w[f"llm{i}.{nm}"] = self.ops.split_f16(self._aligned(mat.detach().to(torch.float32).contiguous().to(self.device)), 2)
             else:
                 w[f"llm{i}.w1"] = W(w1)
                 w[f"llm{i}.w2"] = W(w2)
-            w[f"llm{i}.b1"] = Fp(torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"],
-                                            sd[p + "mlp.fc1.bias"]], 0))
+            w[f"llm{i}.b1"] = Fp(b1)
             w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"].float() + sd[p + "mlp.fc2.bias"].float())
             norm(f"llm{i}.ln", p + "input_layernorm")
             bound(f"llm{i}.bnd", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[a + "v_proj.weight"], sd[a + "v_proj.bias"])
@@ -315,7 +338,7 @@ class PSALM:
                 norm(q + "n2", p + "norm2")
                 lin(q + "qkv", p + "attn.qkv")
                 lin(q + "proj", p + "attn.proj")
-                lin(q + "fc1", p + "mlp.fc1")
+                lin(q + "fc1", p + "mlp.fc1", pair=True)
                 bound(q + "fc1.bnd", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
                 Cq = sd[p + "attn.qkv.weight"].shape[0] // 3                       # bound of the v rows: the window attention's output scale
                 bound(q + "qkv.bnd", sd[p + "attn.qkv.weight"][2 * Cq:], sd[p + "attn.qkv.bias"][2 * Cq:])
@@ -363,7 +386,7 @@ class PSALM:
             lin(q + "value", p + "self_attn.value_proj")
             lin(q + "out", p + "self_attn.output_proj")
             norm(q + "n1", p + "norm1")
-            lin(q + "l1", p + "linear1")
+            lin(q + "l1", p + "linear1", pair=True)
             bound(q + "l1.bnd", sd[p + "linear1.weight"], sd[p + "linear1.bias"])
             lin(q + "l2", p + "linear2")
             norm(q + "n2", p + "norm2")
@@ -733,6 +756,9 @@ class PSALM:
         x8 = 1 if (self.llm_x8 and fuse_split) else 0   # operand form of this decoder's GEMMs (weights were prepared to match)
         if self.llm_x8 and not fuse_split:
             raise H.PsalmHipError("llm_cross_fp8: the Phi weights are in the x8 form but the fused operand hand-over is off")
+        if self.paired.get("llm0", False) and not fuse_split:
+            raise H.PsalmHipError("the Phi fc1 rows are laid out for paired split-f16 stores but the fused operand hand-over is off "
+                                  "(build the model with paired_split_stores=False)")
         if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
             h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, form=x8)[1]
         else:
@@ -742,7 +768,8 @@ class PSALM:
             ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
             if fuse_split:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
-                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=x8)
+                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=x8,
+                                paired=self.paired.get(f"llm{i}", False))
                 o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
                                          cfg.rotary_dim, split_form=x8)
                 if last or Hd % 64 != 0 or Hd > 2048:

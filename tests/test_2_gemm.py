@@ -390,6 +390,49 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     assert ((y1 - y2).abs() <= 8 * 2.0 ** -22 * mag + 1e-9).all()
 
 
+@pytest.mark.parametrize("M,N,K,act,policy,col_start,col_off,glob,x8", [
+    (300, 256, 128, H.ACT_GELU, 64, 0, 0, False, False),
+    (300, 512, 192, H.ACT_RELU, 128, 0, 64, False, False),
+    (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, False),     # Phi layout on the 256 x 256 tile: [.. | fc1], fc1 columns paired
+    (140, 768, 256, H.ACT_GELU_NEW, 256, 256, 128, True, True),      # ... in the x8 operand form (e4m3 second words)
+])
+def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start, col_off, glob, x8):
+    """split_form bit 2: with the W rows / bias >= col_start permuted by so_pair_perm the emitted operand, its scales and the fp32 columns are
+    bit for bit those of the un-permuted call (same dot products; only the store path differs: registers -> 4-byte stores, no LDS pass)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    d = ops.device
+    Ns = N - col_start
+    Kp_out = (col_off + Ns + 127) // 128 * 128
+    par = split_bound_par(w[col_start:], bias[col_start:], 2.0 ** 14 * 3.0 if glob else 0.0, 0.5 if glob else 0.0).to(d)
+    perm = torch.cat([torch.arange(col_start), col_start + H.Ops.so_pair_perm(Ns)])
+    res = []
+    ops.gemm_tile_policy(policy)
+    try:
+        for paired in (False, True):
+            wq, bq = (w[perm], bias[perm]) if paired else (w, bias)
+            asp = ops.split_f16(a.to(d), 1 if x8 else 0)
+            wsp = ops.split_f16(wq.to(d), 2 if x8 else 0)
+            so = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
+            inv = torch.full((M,), -1.0, device=d)
+            out = torch.full((M, N), 7.0, device=d) if col_start else None
+            ops.gemm_x3_split(asp, wsp, bq.to(d), act, so, inv, par, split_col_off=col_off, split_col_start=col_start, act_col_start=col_start,
+                              out=out, global_rows=glob, split_form=1 if x8 else 0, paired=paired)
+            res.append((so.cpu(), inv.cpu(), out.cpu() if out is not None else None))
+    finally:
+        ops.gemm_tile_policy(0)
+    (so0, inv0, out0), (so1, inv1, out1) = res
+    assert (so0[:, col_off:col_off + Ns] != 0).any()
+    assert torch.equal(so0.view(torch.int16), so1.view(torch.int16)) and torch.equal(inv0, inv1)
+    if col_start:
+        assert torch.equal(out0, out1)
+    with pytest.raises(H.PsalmHipError):                       # a column count the permutation is not defined for
+        ops.gemm_x3_split(asp, ops.split_f16(w[:N - 8].to(d), 2 if x8 else 0), bias[:N - 8].to(d), act, so, inv, par, split_col_off=col_off,
+                          split_col_start=col_start, act_col_start=col_start, out=out, split_form=1 if x8 else 0, paired=True)
+
+
 def test_gemm_x3_split_output_k_panel_form(ops):
     """the automatic K loop of the 128 / 64-row tiles is the 32-deep slice form (policy 3303); the K-panel form (3305) stays selectable"""
     test_gemm_x3_split_output(ops, 300, 264, 192, H.ACT_RELU, 128, 0, 64, False, kloop=3305)

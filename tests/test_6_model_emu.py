@@ -176,10 +176,15 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
     sd = make_state_dict(cfg, seed=21)
     inputs = make_inputs(cfg, task, size=96, batch=batch, seed=6, num_classes=7)            # batch 2: ragged prompts, padded key mask
     model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8=False)    # (the x8 weight form exists only with the hand-over)
-    assert model.fuse_split and not model.llm_x8
+    assert model.fuse_split and not model.llm_x8 and model.so_paired and any(model.paired.values())
     kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
     torch.manual_seed(5)
     model_out_a = model.forward_logits(**kw)
+    model.fuse_split = False                              # its fc1 / linear1 rows are permuted for the paired stores of the hand-over: refused
+    with pytest.raises(Exception, match="paired"):
+        model.forward_logits(**kw)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8=False, paired_split_stores=False)
+    assert not any(model.paired.values())
     model.fuse_split = False
     torch.manual_seed(5)
     model_out_b = model.forward_logits(**kw)
