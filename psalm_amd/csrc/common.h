@@ -119,11 +119,15 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #define PSALM_WAIT_VMCNT(N) do { } while (0)          /* the stand-in's copies are synchronous */
 #define PSALM_RAW_BARRIER() __syncthreads()
 #define PSALM_OPAQUE_VGPR(x) do { } while (0)
+__device__ __forceinline__ float psalm_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float psalm_exp2(float x) { return exp2f(x); }
 #else
 // makes an int look freshly defined to the optimiser (keeps loop-invariant LDS fragment reads from being hoisted into registers)
 #define PSALM_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #define PSALM_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+__device__ __forceinline__ float psalm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     /* v_rcp_f32: 1 ulp */
+__device__ __forceinline__ float psalm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  /* v_exp_f32 (no denormal range fix-up: callers add 1) */
 #endif
 
 // ---- split-f16 operand rows, second half-word of an element.  An operand row is [hi (Kp) | second (Kp)] 16-bit words with x s = hi + lo

@@ -87,11 +87,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         // 0.5 v (1 + tanh u) = v / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of the library tanhf (~4x the instructions; the
         // activation runs once per output element in the epilogue's critical path -- 65536 per 256 x 256 tile).  exp(-2u) = inf for
         // u << 0 gives v * 0 = -0, the limit; a few ulp from the tanh form, both a few ulp from the exact value.
-        const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-        return __fdividef(v, 1.f + __expf(-2.f * u));
+        // exp(-2u) = 2^(v (c1 + c2 v^2)),  c1 = -2 sqrt(2/pi) log2(e),  c2 = 0.044715 c1: the constants folded by hand (no fast-math
+        // reassociation), v_exp_f32 is base 2, v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division __fdividef expands to here
+        const float p = fmaf(v * v, -0.10294324f, -2.3022082f);
+        return v * psalm_rcp(1.f + psalm_exp2(v * p));
     }
     return v;
 }
+
+// compile-time activation (A >= 0) for the straight-line epilogues; A < 0: the launch's run-time code
+template <int A> __device__ __forceinline__ float apply_act_t(float v, int act_rt) { return apply_act(v, A < 0 ? act_rt : A); }
+template <int V> struct psalm_ic { static constexpr int value = V; };
 
 __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 
@@ -853,32 +859,51 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const unsigned cbyte = lc + 1 < g.N ? (unsigned)(fa.so_col_off + (lc - fa.so_col_start)) * 2u : PSALM_BUF_OOB;
                 const unsigned second = (unsigned)fa.so_kp * 2u;
                 const bool writes_inv = bn == fa.so_col_start && wn == 0 && n32 == 0;
+                // The element code is instantiated for the launch's (activation, operand form) as compile-time constants and selected ONCE,
+                // outside the loops: with run-time codes every element carried the activation switch, the per-lane act_col_start branch
+                // and the form branch (r03k: 33 us of epilogue on the Phi fc1 tiles whichever way the words were stored -- 4 scalar
+                // branches and an exec-mask region per element, no overlap between the 128 dependent chains of a lane).
+                auto body = [&](auto AC, auto FC) {
+                    constexpr int A = decltype(AC)::value, F = decltype(FC)::value;
+                    const int form = F < 0 ? fa.so_form : F;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row0 = bm + wm * (BM / WM) + i * 32 + 4 * hi;
-                    float asc[16], sc[16];
+                    for (int i = 0; i < TM; ++i) {
+                        const int row0 = bm + wm * (BM / WM) + i * 32 + 4 * hi;
+                        float asc[16], sc[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2);
-                        asc[r] = fa.a_scale[min(row, g.M - 1)];
-                        float inv_;
-                        split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
-                        if (writes_inv && row < g.M) fa.so_inv[row] = inv_;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            asc[r] = fa.a_scale[min(row, g.M - 1)];
+                            float inv_;
+                            split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
+                            if (writes_inv && row < g.M) fa.so_inv[row] = inv_;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            float x0 = acc[i][0][r] * (asc[r] * wsc[0]) + bias_c[0];
+                            float x1 = acc[i][1][r] * (asc[r] * wsc[1]) + bias_c[1];
+                            const float y0 = apply_act_t<A>(x0, act), y1 = apply_act_t<A>(x1, act);
+                            x0 = actc[0] ? y0 : x0;
+                            x1 = actc[1] ? y1 : x1;
+                            unsigned h0, s0, h1, s1;
+                            psalm_split_words(x0 * sc[r], form, h0, s0);
+                            psalm_split_words(x1 * sc[r], form, h1, s1);
+                            const unsigned off = row < g.M && cbyte != PSALM_BUF_OOB ? (unsigned)row * (unsigned)(fa.ldso * 2) + cbyte : PSALM_BUF_OOB;
+                            psalm_buf_store_u32(h0 | (h1 << 16), srs, off);
+                            psalm_buf_store_u32(s0 | (s1 << 16), srs, off == PSALM_BUF_OOB ? off : off + second);
+                        }
                     }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2);
-                        float x0 = acc[i][0][r] * (asc[r] * wsc[0]) + bias_c[0];
-                        float x1 = acc[i][1][r] * (asc[r] * wsc[1]) + bias_c[1];
-                        if (actc[0]) x0 = apply_act(x0, act);
-                        if (actc[1]) x1 = apply_act(x1, act);
-                        unsigned h0, s0, h1, s1;
-                        psalm_split_words(x0 * sc[r], fa.so_form, h0, s0);
-                        psalm_split_words(x1 * sc[r], fa.so_form, h1, s1);
-                        const unsigned off = row < g.M && cbyte != PSALM_BUF_OOB ? (unsigned)row * (unsigned)(fa.ldso * 2) + cbyte : PSALM_BUF_OOB;
-                        psalm_buf_store_u32(h0 | (h1 << 16), srs, off);
-                        psalm_buf_store_u32(s0 | (s1 << 16), srs, off == PSALM_BUF_OOB ? off : off + second);
-                    }
+                };
+                if constexpr (X3 == 3) {
+                    if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
+                    else body(psalm_ic<-1>{}, psalm_ic<-1>{});
+                } else {
+                    if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});
+                    else if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{}, psalm_ic<0>{});
+                    else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{}, psalm_ic<0>{});
+                    else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
+                    else body(psalm_ic<-1>{}, psalm_ic<0>{});
                 }
                 PSALM_TL(4);
                 PSALM_TL_DRAIN();
@@ -888,38 +913,51 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             if constexpr (!PAIR) {
             const int c8 = (tid % TPR) * 8, col0 = bn + c8;
             float* C = (float*)g.C;
-#pragma unroll                                                     // (unrolled: acc[e * TMP + ii] must be a compile-time register choice)
-            for (int e = 0; e < EPS; ++e) {
+            auto pass = [&](auto EC) {                                // (the pass index is a compile-time constant: acc[e * TMP + ii] is a register choice)
+                constexpr int e = decltype(EC)::value;
                 if (e > 0) __syncthreads();                           // previous pass read out
+                // (element code instantiated for compile-time (activation, operand form) and selected once per pass: see the paired form above)
+                auto body = [&](auto AC, auto FC) {
+                    constexpr int A = decltype(AC)::value, F = decltype(FC)::value;
+                    const int form = F < 0 ? fa.so_form : F;
 #pragma unroll
-                for (int ii = 0; ii < TMP; ++ii) {
-                    const int i = e * TMP + ii;
-                    const int lrow0 = wm * (BM / WM) + i * 32 + 4 * hi;          // tile-local row of accumulator element r = 0
-                    const int prow0 = wm * BAND + ii * 32 + 4 * hi;              // its row in this pass's LDS image
-                    float asc[16], sc[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        asc[r] = fa.a_scale[min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1)];
-                        float inv_;
-                        split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int ii = 0; ii < TMP; ++ii) {
+                        const int i = e * TMP + ii;
+                        const int lrow0 = wm * (BM / WM) + i * 32 + 4 * hi;          // tile-local row of accumulator element r = 0
+                        const int prow0 = wm * BAND + ii * 32 + 4 * hi;              // its row in this pass's LDS image
+                        float asc[16], sc[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float x = acc[i][j][r] * (asc[r] * wsc[j]) + bias_c[j];
-                            if (actc[j]) x = apply_act(x, act);
-                            unsigned word = __builtin_bit_cast(unsigned, x);
-                            if (soc[j]) {
-                                unsigned hw_, sw_;
-                                psalm_split_words(x * sc[r], fa.so_form, hw_, sw_);
-                                word = hw_ | (sw_ << 16);
-                            }
-                            Cw[(prow0 + (r & 3) + 8 * (r >> 2)) * BN + wn * (BN / WN) + j * 32 + n32] = word;
+                            asc[r] = fa.a_scale[min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1)];
+                            float inv_;
+                            split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
                         }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float x = acc[i][j][r] * (asc[r] * wsc[j]) + bias_c[j];
+                                const float y = apply_act_t<A>(x, act);
+                                x = actc[j] ? y : x;
+                                unsigned hw_, sw_;
+                                psalm_split_words(x * sc[r], form, hw_, sw_);
+                                const unsigned word = soc[j] ? (hw_ | (sw_ << 16)) : __builtin_bit_cast(unsigned, x);
+                                Cw[(prow0 + (r & 3) + 8 * (r >> 2)) * BN + wn * (BN / WN) + j * 32 + n32] = word;
+                            }
+                    }
+                };
+                if constexpr (X3 == 3) {
+                    if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
+                    else body(psalm_ic<-1>{}, psalm_ic<-1>{});
+                } else {
+                    if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});
+                    else if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{}, psalm_ic<0>{});
+                    else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{}, psalm_ic<0>{});
+                    else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
+                    else body(psalm_ic<-1>{}, psalm_ic<0>{});
                 }
                 __syncthreads();
-                if (col0 >= g.N) continue;
+                if (col0 >= g.N) return;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int rl = it * RPI + tid / TPR;                          // row of the LDS image -> row of the tile
@@ -952,7 +990,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                         }
                     }
                 }
-            }
+            };
+            pass(psalm_ic<0>{});
+            if constexpr (EPS > 1) pass(psalm_ic<1>{});
+            static_assert(EPS <= 2, "split-output epilogue: at most two passes");
             PSALM_TL(4);
             PSALM_TL_DRAIN();
             PSALM_TL(5);

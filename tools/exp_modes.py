@@ -46,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         m.ops.lib.records = None
         agg = {}
-        for name, a, e0, e1 in recs:
+        for name, a, e0, e1, *_ in recs:
             d = agg.setdefault(name, [0, 0.0]); d[0] += 1; d[1] += e0.elapsed_time(e1)
         while mode in out:
             mode += "'"                             # repeated modes (interleaved A/B runs) keep separate entries

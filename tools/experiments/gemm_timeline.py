@@ -44,6 +44,10 @@ POLICIES = [("auto", [0]), ("t128", [128]), ("t64", [64]), ("t256", [256])]
 
 
 def main():
+    global SHAPES
+    if os.environ.get("TL_SHAPES") == "paired":          # the split-f16-output epilogues, LDS transpose vs paired stores
+        SHAPES = [(899, 14336, 2048, 6144, 3, 1), (899, 14336, 2048, 6144, 3, 1, 1), (899, 14336, 2048, None, 0, 1), (4096, 2048, 512, 0, 2), (4096, 2048, 512, 0, 2, 0, 1),
+                  (4096, 2048, 512, None, 0), (21504, 1024, 256, 0, 1), (21504, 1024, 256, 0, 1, 0, 1)]
     import ctypes
     import torch
     from psalm_amd import hip_ops as H
@@ -55,6 +59,7 @@ def main():
     for shape in SHAPES:
         M, N, K, so_from, act = shape[:5]
         x8 = len(shape) > 5 and shape[5]                     # operands (and the emitted operand) in the x8 form: e4m3 cross terms
+        paired = len(shape) > 6 and shape[6]                 # paired split-f16 stores (timing only: the W rows are NOT permuted here)
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
         asp, wsp = (ops.split_f16(a, 1), ops.split_f16(w, 2)) if x8 else (ops.split_f16(a), ops.split_f16(w))
@@ -68,13 +73,13 @@ def main():
 
             def launch():
                 ops.gemm_x3_split(asp, wsp, bias, act, so, so_inv, bnd, split_col_off=2048, split_col_start=so_from, act_col_start=so_from, out=c,
-                                  split_form=1 if x8 else 0)
+                                  split_form=1 if x8 else 0, paired=bool(paired))
         else:
             def launch():
                 ops.gemm_x3(asp, wsp, out=c)
         big = torch.empty(64 << 20, device="cuda")        # 256 MB: evicts the operands from the Infinity Cache between cold launches
         row = {}
-        for name, pol in (POLICIES[:1] if x8 else POLICIES):
+        for name, pol in (POLICIES[:1] if x8 or os.environ.get("TL_SHAPES") else POLICIES):
             for p in pol:
                 ops.gemm_tile_policy(p)
             try:
@@ -115,7 +120,7 @@ def main():
             finally:
                 for p in (1282, 640, 3300, 0):
                     ops.gemm_tile_policy(p)
-        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "") + (" x8" if x8 else "")
+        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "") + (" x8" if x8 else "") + (" paired" if paired else "")
         out[key] = row
         print(key, json.dumps(row), flush=True)
         del a, w, asp, wsp, c, big
