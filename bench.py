@@ -163,6 +163,51 @@ def main():
             torch.cuda.synchronize()
             gpu_ms = e0.elapsed_time(e1) / args.steps
 
+    # ---- side metric, NOT `value`: two images in flight on one GPU.  `value` above is the reference's own usage (one synchronous eval_seg
+    # at a time); a serving loop can drive a second `PSALM.replica()` (shared weights, own buffers / graphs) from a second host thread on a
+    # second stream, and the hardware fills one image's partial waves and latency-bound launches with the other's (r03a: +11 %).
+    inflight = None
+    if rank == 0 and world == 1 and not args.eager and not args.no_side_modes and args.precision == "f16x3":
+        import threading
+        rep = model.replica()
+        rep.graph_outputs = "alias"
+        st = [torch.cuda.Stream(), torch.cuda.Stream()]
+        inputs_b = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank + 1)
+        inputs_b["images"] = inputs_b["images"].cuda()
+        with torch.cuda.stream(st[1]):
+            for _ in range(3):                                     # eager, capture, one replay
+                out_b = rep.eval_seg(**inputs_b)
+        torch.cuda.synchronize()
+        ref_b = model.eval_seg(**inputs_b)                          # same image through the first instance: bit-identical results expected
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref_b[0]["mask_pred"], out_b[0]["mask_pred"]) and torch.equal(ref_b[0]["sem_seg"], out_b[0]["sem_seg"]) and
+                    torch.equal(ref_b[0]["panoptic_seg"][0], out_b[0]["panoptic_seg"][0]))
+
+        def worker(m, inp, stream, k, bar):
+            with torch.cuda.stream(stream):
+                bar.wait()
+                for _ in range(k):
+                    m.eval_seg(**inp)
+                stream.synchronize()
+        rates = []
+        for _ in range(3):
+            bar = threading.Barrier(3)
+            th = [threading.Thread(target=worker, args=(m_, i_, s_, args.steps, bar)) for m_, i_, s_ in ((model, inputs, st[0]), (rep, inputs_b, st[1]))]
+            for t_ in th:
+                t_.start()
+            torch.cuda.synchronize()
+            bar.wait()
+            t1 = time.perf_counter()
+            for t_ in th:
+                t_.join()
+            torch.cuda.synchronize()
+            rates.append(2 * args.steps / (time.perf_counter() - t1))
+        inflight = {"images_in_flight": 2, "images_per_s": round(sorted(rates)[1], 3), "runs": [round(r_, 2) for r_ in rates],
+                    "replica_results_identical": same,
+                    "note": "two PSALM instances (shared weights, own graphs) driven by two host threads on two HIP streams; not `value`"}
+        del rep, out_b, ref_b
+        torch.cuda.empty_cache()
+
     # ---- instrumented steps (not part of `value`): HIP events (torch's current stream = the launch stream) around every
     # C-ABI launch, attributed to kernel instantiations through psalm_gemm_describe (the library's own selection function)
     roof = None
@@ -378,7 +423,8 @@ def main():
                                       "; fp32 norms / softmax / attention") if args.precision == "f16x3" else args.precision,
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},
-            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": side, "weight_broadcast": bcast,
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": side, "two_in_flight": inflight,
+            "weight_broadcast": bcast,
             "per_rank_images_per_s": ({"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)} if per_rank else None),
         }
         print(json.dumps(line))

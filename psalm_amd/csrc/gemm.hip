@@ -1582,7 +1582,7 @@ static int g_ph8 = 3;
 // with 1.5x the matrix work per copy round trip and 2/3 of the copies: 3-17 % faster on 17 of 21 shapes of the image (M5184 N512 K512
 // 22.0 -> 18.3 us, M21504 N256 K1024 60.3 -> 52.6, M65536 N128 K512 43.4 -> 38.1), equal within noise on the rest: the automatic choice.
 static int g_x3_slice = 0;
-static bool g_x3_auto_slice = false;    // set by select_fast_config: this problem takes the slice form on 64 x 128 tiles
+static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
     if (bm == 1282 || bm == 1283) { g_ring_depth = bm - 1280; return 0; }      // 128x128, BK 64, ring depth 2 / 3 (tuning)

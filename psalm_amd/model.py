@@ -151,6 +151,19 @@ class PSALM:
         self.training = False
         self._prepare_weights(state_dict)
 
+    def replica(self) -> "PSALM":
+        """A second instance of this model for ANOTHER HIP stream / host thread (two images in flight on one GPU: the hardware interleaves the
+        launches of independent images -- profiles/r03a_inflight2.json, +11 % images/s): shares the weights, owns everything a call
+        writes -- its binding's workspaces, constant caches, splice plans, captured graphs and side stream.  `eval_seg` itself stays the
+        reference's synchronous call; the caller drives each replica from its own thread under `torch.cuda.stream(...)`."""
+        import copy
+        r = copy.copy(self)
+        r.ops = H.Ops(self.ops.lib_path)
+        r.ops.x3, r.ops.debug_bounds = self.ops.x3, self.ops.debug_bounds
+        r._cache, r._graphs, r._plan_cache, r._prep_cache = {}, {}, {}, {}
+        r._side = None
+        return r
+
     # ======================================================================================= nn.Module / HF surface the eval scripts touch
     def to(self, *args, **kwargs):
         """`model.to(dtype=torch.float32, device=device)` (psalm/eval/panoptic_segmentation.py:127 and siblings).  The weights already

@@ -78,15 +78,12 @@ def _worker_real_model(rank, world, port, q):
     ops = make_ops("emu")
     cfg = PsalmConfig.tiny("referring")
     out = {"rank": rank}
+    from psalm_amd.dist import weights_checksum
     for precision in ("fp32", "f16x3"):
         model = PSALM(cfg, make_state_dict(cfg, seed=100 + rank), ops=ops, precision=precision)        # different weights per rank
+        before = weights_checksum(model)
         nbytes, _ = broadcast_weights(model, src=0, bucket_bytes=1 << 16)
-        ref = PSALM(cfg, make_state_dict(cfg, seed=100), ops=ops, precision=precision)                 # what rank 0 holds
-        same = True
-        for k, v in ref.w.items():
-            a = model.w[k]
-            same &= (torch.equal(a.t, v.t) and torch.equal(a.inv_scale, v.inv_scale)) if hasattr(v, "inv_scale") else torch.equal(a, v)
-        out[precision] = (bool(same), int(nbytes))
+        out[precision] = (before, weights_checksum(model), int(nbytes))        # (the parent holds rank 0's checksum from its own build)
     # images sharded round-robin: 2 images -> rank 0 gets {0}, rank 1 gets {1}; same pixels whoever computes them
     meters = E.IoUMeters()
     mine = shard_indices(2, rank, world)
@@ -118,28 +115,29 @@ def test_two_rank_real_model_broadcast_and_sharded_eval():
     ps = [ctx.Process(target=_worker_real_model, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
+    # while the ranks run: what a single process holds / computes with rank 0's weights (seed 100)
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.dist import weights_checksum
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    cfg = PsalmConfig.tiny("referring")
+    ops = make_ops("emu")
+    csum = {pr: weights_checksum(PSALM(cfg, make_state_dict(cfg, seed=100), ops=ops, precision=pr)) for pr in ("fp32",)}
+    m = PSALM(cfg, make_state_dict(cfg, seed=100), ops=ops, precision="f16x3")
+    csum["f16x3"] = weights_checksum(m)
+    want = {i: float(m.eval_seg(**make_inputs(cfg, "referring", size=96, batch=1, seed=40 + i))[0]["mask_pred"].double().sum()) for i in range(2)}
     res = sorted((q.get(timeout=600) for _ in ps), key=lambda d: d["rank"])
     for p in ps:
         p.join(120)
         assert p.exitcode == 0
-    for r in res:
-        assert r["fp32"][0] and r["f16x3"][0], "weights differ from rank 0's after the broadcast"
-        assert r["fp32"][1] > 0 and r["f16x3"][1] > 0
-    assert res[0]["fp32"][1] == res[1]["fp32"][1] and res[0]["f16x3"][1] == res[1]["f16x3"][1]
+    for pr in ("fp32", "f16x3"):                       # both weight layouts: plain fp32 tensors and split-f16 pairs + scales
+        assert res[0][pr][0] == csum[pr] and res[1][pr][0] != csum[pr]          # rank 1 started from other weights ...
+        assert res[0][pr][1] == csum[pr] and res[1][pr][1] == csum[pr]          # ... and holds rank 0's after the broadcast
+        assert res[0][pr][2] == res[1][pr][2] > 0
     assert res[0]["mine"] == [0] and res[1]["mine"] == [1]
     assert res[0]["meters"] == res[1]["meters"] and res[0]["meters"]["n"] == 2          # all-reduced: every rank holds the global meters
-    # the shards are what a single process computes for the same images with rank 0's weights
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
-    from ops_backend import make_ops
-    from psalm_amd.config import PsalmConfig
-    from psalm_amd.model import PSALM
-    from psalm_amd.synthetic import make_inputs, make_state_dict
-    cfg = PsalmConfig.tiny("referring")
-    m = PSALM(cfg, make_state_dict(cfg, seed=100), ops=make_ops("emu"), precision="f16x3")
-    want = {i: float(m.eval_seg(**make_inputs(cfg, "referring", size=96, batch=1, seed=40 + i))[0]["mask_pred"].double().sum()) for i in range(2)}
     got = dict(res[0]["digest"] + res[1]["digest"])
-    assert got == want
+    assert got == want                                 # the shards are what a single process computes for the same images
 
 
 def _worker_four(rank, world, port, q):

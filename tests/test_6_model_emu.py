@@ -212,3 +212,19 @@ def test_tiny_f16x3_llm_cross_terms_in_e4m3_match_three_products():
     b = m3.forward_logits(stages=st3, **kw)[0]
     assert _rel(st8["hidden_states"], st3["hidden_states"]) < 2e-4
     assert 0 < _rel(a["pred_masks"], b["pred_masks"]) < 5e-4
+
+
+def test_replica_shares_weights_owns_state_and_agrees():
+    """PSALM.replica(): the second instance for another stream / host thread (bench.py `two_in_flight`) holds the SAME weight tensors, its
+    own binding (workspaces), caches and graphs, and returns the first instance's results bit for bit."""
+    cfg = PsalmConfig.tiny("panoptic")
+    sd = make_state_dict(cfg, seed=12)
+    inputs = make_inputs(cfg, "panoptic", size=64, batch=1, seed=4, num_classes=9)
+    m = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
+    a = m.eval_seg(**inputs)[0]
+    r = m.replica()
+    assert r.w is m.w and r.paired is m.paired and r.ops is not m.ops and r.ops._ws is not m.ops._ws
+    assert r._cache == {} and r._graphs == {} and r._prep_cache == {} and m._cache
+    b = r.eval_seg(**inputs)[0]
+    assert torch.equal(a["mask_pred"], b["mask_pred"]) and torch.equal(a["sem_seg"], b["sem_seg"])
+    assert torch.equal(a["panoptic_seg"][0], b["panoptic_seg"][0]) and a["panoptic_seg"][1] == b["panoptic_seg"][1]
