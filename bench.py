@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"])
+    ap.add_argument("--llm-cross-fp8", default=None, choices=["w1", "w2", "both", "off"],
+                    help="f16x3: which Phi GEMMs form their cross terms as e4m3 dot products (default: the model's default, w2)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 side-line measurement (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-seeds", type=int, default=5, help="inputs the parity leg compares with the CPU oracle (rank 0, N=1; ~12 s of CPU each)")
@@ -100,8 +102,10 @@ def main():
     # rank 0 owns the (seeded) checkpoint; the other ranks build their weight arena from placeholders of the same shapes and receive
     # rank 0's prepared weights through the broadcast -- which is thereby real, not a copy of identical data onto itself
     sd = make_state_dict(cfg, seed=0, shapes_only=rank != 0)
-    model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
-    model_info = type("I", (), {"llm_x8": bool(getattr(model, "llm_x8", False))})      # (the model object itself is released before the JSON line)
+    model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager,
+                  llm_cross_fp8={None: None, "off": False}.get(args.llm_cross_fp8, args.llm_cross_fp8))
+    model_info = type("I", (), {"llm_x8": bool(getattr(model, "llm_x8", False)),
+                                "x8_gemms": [n for n, f in (("[k|v|q|fc1]", getattr(model, "llm_x8_w1", False)), ("[dense|fc2]", getattr(model, "llm_x8_w2", False))) if f]})      # (the model object itself is released before the JSON line)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"
@@ -275,7 +279,7 @@ def main():
             if name == "psalm_semantic_from_masks":
                 nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_kernel"
             elif name == "psalm_semantic_from_masks_x3":                          # (mask, probsT, out, mask_score, workspace, Q, C, HW, Kpad, stream)
-                nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_x3_kernel"
+                nbytes, kn = (a[5] + a[6]) * a[7] * 4, "semantic_from_masks_x3_pair_kernel"
             elif name == "psalm_msda_fused":
                 esz_v, esz_o = (2 if a[1] == 1 else 4), (2 if a[6] == 1 else 4)
                 B_, S_, M_, D_, L_, P_ = a[7], a[8], a[9], a[10], a[11], a[12]
@@ -419,7 +423,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
                        "arithmetic": ("GEMMs in split-f16 (22-bit operands as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulate)" +
-                                      ("; Phi decoder GEMMs: hi.hi in f16 + both cross terms as one e4m3 dot product" if getattr(model_info, "llm_x8", False) else "") +
+                                      (("; Phi " + " and ".join(model_info.x8_gemms) + " GEMM: hi.hi in f16 + both cross terms as one e4m3 dot product") if getattr(model_info, "llm_x8", False) else "") +
                                       "; fp32 norms / softmax / attention") if args.precision == "f16x3" else args.precision,
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},

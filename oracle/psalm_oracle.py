@@ -272,15 +272,7 @@ def gelu_new(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def fp8_fake_quant_rows(x):
-    """Per-row dynamic quantisation to OCP e4m3fn and back (what psalm_quantize_rows_fp8 + the MFMA's exact e4m3 products
-    compute): scale = amax/448 (1 for a zero row), RNE with saturation."""
-    amax = x.abs().amax(-1, keepdim=True)
-    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    return (x * (1.0 / sc)).to(torch.float8_e4m3fn).float() * sc
-
-
-def phi_forward(sd, cfg, inputs_embeds, attention_mask, prefix="model.", fp8=False):
+def phi_forward(sd, cfg, inputs_embeds, attention_mask, prefix="model."):
     """PHI:343-396 (model), :263-300 (parallel-residual layer), :189-245 (attention, partial RoPE),
     :137-160 (eager attention, fp32 softmax), :53-90 (rotary cos/sin), :248-260 (MLP gelu_new).
     attention_mask (B,L) bool: True = attend.  Causal + key-padding additive mask (finfo.min)."""
@@ -297,31 +289,10 @@ def phi_forward(sd, cfg, inputs_embeds, attention_mask, prefix="model.", fp8=Fal
     def rot_half(x):
         return torch.cat((-x[..., rd // 2:], x[..., : rd // 2]), -1)
 
-    # fp8=True is NOT reference behaviour: it restates the fp8 (e4m3) Phi-projection extension of the HIP path (BASELINE.json
-    # configs[4]) so that path can be checked against the same arithmetic: GEMM inputs rounded to bf16 then fake-quantised per
-    # row; weights per output row of the fused [k|v|q|fc1] and [dense|fc2] matrices; everything else as the reference.
-    def lin_q(name, xq):
-        return F.linear(xq, fp8_fake_quant_rows(sd[name + ".weight"].bfloat16().float()), sd[name + ".bias"])
-
     h = inputs_embeds
     for i in range(cfg.num_layers):
         p = f"{prefix}layers.{i}."
         x = _ln(sd, p + "input_layernorm", h, cfg.layer_norm_eps)
-        if fp8:
-            xq = fp8_fake_quant_rows(x.bfloat16().float())
-            q = lin_q(p + "self_attn.q_proj", xq).bfloat16().float().view(B, L, nh, hd).transpose(1, 2)
-            k = lin_q(p + "self_attn.k_proj", xq).bfloat16().float().view(B, L, nh, hd).transpose(1, 2)
-            v = lin_q(p + "self_attn.v_proj", xq).bfloat16().float().view(B, L, nh, hd).transpose(1, 2)
-            qr, kr = q[..., :rd], k[..., :rd]
-            q = torch.cat((qr * cos + rot_half(qr) * sin, q[..., rd:]), -1)
-            k = torch.cat((kr * cos + rot_half(kr) * sin, k[..., rd:]), -1)
-            w = torch.matmul(q, k.transpose(2, 3)) * hd ** -0.5 + bias
-            a = torch.matmul(F.softmax(w, dim=-1, dtype=torch.float32), v).transpose(1, 2).reshape(B, L, H)
-            mlp = gelu_new(lin_q(p + "mlp.fc1", xq))
-            cat = fp8_fake_quant_rows(torch.cat((a, mlp), -1).bfloat16().float())              # one row scale over [attn | mlp]
-            w2 = fp8_fake_quant_rows(torch.cat((sd[p + "self_attn.dense.weight"], sd[p + "mlp.fc2.weight"]), 1).bfloat16().float())
-            h = F.linear(cat, w2, sd[p + "self_attn.dense.bias"] + sd[p + "mlp.fc2.bias"]) + h
-            continue
         q = _lin(sd, p + "self_attn.q_proj", x).view(B, L, nh, hd).transpose(1, 2)
         k = _lin(sd, p + "self_attn.k_proj", x).view(B, L, nh, hd).transpose(1, 2)
         v = _lin(sd, p + "self_attn.v_proj", x).view(B, L, nh, hd).transpose(1, 2)
@@ -654,10 +625,9 @@ def region_inference(region_cls, mask_pred):                         # LP:387-40
 def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images, seg_info, class_name_ids=None,
              class_name_embedding_indices=None, cls_indices=None, token_refer_id=None, refer_embedding_indices=None,
              labels=None, is_thing_list=None, region_point_sampler: Callable = default_region_point_sampler,
-             return_stages: bool = False, postprocess: bool = True, msda_fn=msda_core, llm_fp8: bool = False, vp_images=None):
+             return_stages: bool = False, postprocess: bool = True, msda_fn=msda_core, vp_images=None):
     """LP:1317-1472 (and, with vp_images, PSALMForDAVISEval.eval_video LP:1845-1998).  Returns list[dict] for ALL images
-    (and the stage tensors if asked).
-    llm_fp8: evaluate the Phi projections with e4m3 fake-quantised operands (see phi_forward) -- checker for precision="fp8"."""
+    (and the stage tensors if asked)."""
     task = cfg.seg_task
     st = {}
     feats = swin_forward(sd, cfg, images)                            # LP:787 / LP:1369 (evaluated once)
@@ -678,7 +648,7 @@ def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images
         st["region_features"] = region_features
     sp = splice_inputs(sd, cfg, input_ids, attention_mask, image_tokens, class_name_ids, cls_indices, token_refer_id,
                        region_features, class_name_embedding_indices is not None, refer_embedding_indices is not None)
-    hidden = phi_forward(sd, cfg, sp["inputs_embeds"], sp["attention_mask"], fp8=llm_fp8)       # LP:1354-1365
+    hidden = phi_forward(sd, cfg, sp["inputs_embeds"], sp["attention_mask"])       # LP:1354-1365
     st.update(inputs_embeds=sp["inputs_embeds"], hidden_states=hidden, lengths=sp["lengths"])
     emb = gather_llm_embeddings(sd, hidden, sp)
     st.update({k: v for k, v in emb.items()})

@@ -897,6 +897,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 };
                 if constexpr (X3 == 3) {
                     if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
+                    else if (act == ACT_GELU_NEW && fa.so_form == 0) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
                     else body(psalm_ic<-1>{}, psalm_ic<-1>{});
                 } else {
                     if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});
@@ -948,6 +949,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 };
                 if constexpr (X3 == 3) {
                     if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
+                    else if (act == ACT_GELU_NEW && fa.so_form == 0) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
                     else body(psalm_ic<-1>{}, psalm_ic<-1>{});
                 } else {
                     if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});

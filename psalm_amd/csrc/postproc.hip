@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) semantic_from_masks_x3_kernel(const fl
 template <int KP>
 __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(const float* __restrict__ mask, const float* __restrict__ probsT,
                                                                              float* __restrict__ out, float* __restrict__ partial, int Q,
-                                                                             int C, long HW, int ntiles) {
+                                                                             int C, long HW, int ntiles, int contig) {
     constexpr int PITCH = KP + 4, CT = 5, NI = KP / 4, KS = KP / 16, KS1 = (KS + 1) / 2;
     constexpr float SC = 8192.0f;
     __shared__ __attribute__((aligned(16))) unsigned short Ph[CT * 32 * PITCH];
@@ -417,7 +417,9 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
     float num[NI], den[NI], m[NI], sg[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
-    auto tile_of = [&](int it) { return (long)blockIdx.x + (long)gridDim.x * (2 * it + grp); };
+    // tile order: strided (all CUs walk neighbouring 256-byte pieces of every row at the same time) or, contig != 0, one contiguous
+    // pixel range per block (experiment: PSALM_SEM_ORDER=1)
+    auto tile_of = [&](int it) { return contig ? (long)blockIdx.x * (2 * iters) + 2 * it + grp : (long)blockIdx.x + (long)gridDim.x * (2 * it + grp); };
     auto request = [&](int it) {                              // unconditional clamped loads: NI in flight per lane
         const long t = min(tile_of(it), (long)ntiles - 1);
         const unsigned voff = (unsigned)min(t * 64 + lane, HW - 1) * 4u;
@@ -551,12 +553,14 @@ extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* prob
     if ((unsigned long)C * (unsigned long)HW * 4ul < (1ul << 31) && (unsigned long)Q * (unsigned long)HW * 4ul < (1ul << 31)) {          // the buffer descriptor of the stores spans `out` (offsets >= 2^31: dropped)
         const int nt64 = (int)((HW + 63) / 64);
         const int grid2 = nt64 < 512 ? (nt64 + 1) / 2 : 256;                  // 1 persistent block (two wave groups) per CU
+        static int order_env = -1;                                            // PSALM_SEM_ORDER=1: contiguous pixel range per block (A/B)
+        if (order_env < 0) { const char* e = getenv("PSALM_SEM_ORDER"); order_env = e ? atoi(e) : 0; }
         if (Q <= 112)
             hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<112>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
-                               mask_score ? workspace : nullptr, Q, C, HW, nt64);
+                               mask_score ? workspace : nullptr, Q, C, HW, nt64, order_env);
         else
             hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<128>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
-                               mask_score ? workspace : nullptr, Q, C, HW, nt64);
+                               mask_score ? workspace : nullptr, Q, C, HW, nt64, order_env);
         if (mask_score)
             hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, 2 * grid2);
         PSALM_LAUNCH_END("psalm_semantic_from_masks_x3");

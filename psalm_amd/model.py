@@ -142,7 +142,14 @@ class PSALM:
         # products).  Needs hidden and hidden + intermediate to be multiples of 128 and the fused operand hand-over (fuse_split).
         Hd_, I_ = cfg.hidden_size, cfg.intermediate_size
         can_x8 = self.fuse_split and Hd_ % 128 == 0 and (Hd_ + I_) % 128 == 0 and Hd_ <= 2048 and cfg.head_dim == 64 and cfg.rotary_dim == 32
-        self.llm_x8 = can_x8 if llm_cross_fp8 is None else (bool(llm_cross_fp8) and can_x8)
+        # llm_cross_fp8: None / True = the default below, False = three f16 products everywhere, "w1" / "w2" / "both" = per GEMM.
+        # DEFAULT "w2": only the [dense|fc2] GEMM.  With [k|v|q|fc1] in this form ONE of 43 validated inputs left the bar (r03 final pass,
+        # referring 640^2, `profiles/r03n_*` / `r03o_*`: mask logits off by 4e-3, mean IoU 0.9986 -- 1.6e-6 with three products, 3e-6 with
+        # only [dense|fc2] in the x8 form): q / k errors are amplified by the attention softmax and a mask-decoder threshold flipped; the
+        # [dense|fc2] product enters the residual stream linearly.
+        sel = {None: "w2", True: "w2", False: "", "w1": "w1", "w2": "w2", "both": "w1w2"}[llm_cross_fp8] if can_x8 else ""
+        self.llm_x8_w1, self.llm_x8_w2 = "w1" in sel, "w2" in sel
+        self.llm_x8 = self.llm_x8_w1 or self.llm_x8_w2
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
@@ -323,12 +330,11 @@ class PSALM:
             w2 = torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1)
             b1 = torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"], sd[p + "mlp.fc1.bias"]], 0)
             w1, b1, self.paired[f"llm{i}"] = self._pair_rows(w1, b1, 3 * cfg.hidden_size)      # the fc1 rows: gelu(fc1) leaves as fc2's operand
-            if self.llm_x8:                        # split-f16 with e4m3 cross-term halves (W operand form)
-                for nm, mat in (("w1", w1), ("w2", w2)):
+            for nm, mat, x8_ in (("w1", w1, self.llm_x8_w1), ("w2", w2, self.llm_x8_w2)):
+                if x8_:                            # split-f16 with e4m3 cross-term halves (W operand form)
                     w[f"llm{i}.{nm}"] = self.ops.split_f16(self._aligned(mat.detach().to(torch.float32).contiguous().to(self.device)), 2)
-            else:
-                w[f"llm{i}.w1"] = W(w1)
-                w[f"llm{i}.w2"] = W(w2)
+                else:
+                    w[f"llm{i}.{nm}"] = W(mat)
             w[f"llm{i}.b1"] = Fp(b1)
             w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"].float() + sd[p + "mlp.fc2.bias"].float())
             norm(f"llm{i}.ln", p + "input_layernorm")
@@ -766,14 +772,16 @@ class PSALM:
             a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)
             inv2 = o.empty(B * L, dtype=torch.float32)
         fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
-        x8 = 1 if (self.llm_x8 and fuse_split) else 0   # operand form of this decoder's GEMMs (weights were prepared to match)
+        # operand forms of this decoder's two GEMMs (weights were prepared to match): f1 = the LayerNorm output feeding [k|v|q|fc1],
+        # f2 = [attn | gelu(fc1)] feeding [dense|fc2]
+        f1, f2 = (1 if self.llm_x8_w1 and fuse_split else 0), (1 if self.llm_x8_w2 and fuse_split else 0)
         if self.llm_x8 and not fuse_split:
             raise H.PsalmHipError("llm_cross_fp8: the Phi weights are in the x8 form but the fused operand hand-over is off")
         if self.paired.get("llm0", False) and not fuse_split:
             raise H.PsalmHipError("the Phi fc1 rows are laid out for paired split-f16 stores but the fused operand hand-over is off "
                                   "(build the model with paired_split_stores=False)")
         if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
-            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, form=x8)[1]
+            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, form=f1)[1]
         else:
             h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
@@ -781,17 +789,17 @@ class PSALM:
             ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
             if fuse_split:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
-                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=x8,
+                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=f2,
                                 paired=self.paired.get(f"llm{i}", False))
                 o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                         cfg.rotary_dim, split_form=x8)
+                                         cfg.rotary_dim, split_form=f2)
                 if last or Hd % 64 != 0 or Hd > 2048:
-                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I, x8), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I, f2), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                     h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \
-                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps, form=x8)[1]
+                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps, form=f1)[1]
                 else:                                 # residual GEMM + the next layer's LayerNorm + its split: one pass after the K slices
-                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I, x8), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb,
-                                                 cfg.layer_norm_eps, split_form=x8)
+                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I, f2), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb,
+                                                 cfg.layer_norm_eps, split_form=f1)
                 continue
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place

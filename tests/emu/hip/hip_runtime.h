@@ -392,20 +392,12 @@ inline emu::f32x4_t emu_mfma_16x16x4f32(float a, float b, emu::f32x4_t c, int, i
     return emu::mfma<16, 1, emu::AB1, emu::f32x4_t, 4>(m, c, emu::ga1, emu::gb1);
 }
 namespace emu {
-struct AB8F { long a, b; };
 inline float e4m3(unsigned char v) {
     const unsigned e = (v >> 3) & 15u, m = v & 7u;
     float a = e == 0 ? (float)m * 0.001953125f : (e == 15 && m == 7 ? NAN : ldexpf(1.0f + m / 8.0f, (int)e - 7));
     return (v & 0x80u) ? -a : a;
 }
-inline float ga8f(const AB8F& x, int j) { return e4m3((unsigned char)((unsigned long)x.a >> (8 * j))); }
-inline float gb8f(const AB8F& x, int j) { return e4m3((unsigned char)((unsigned long)x.b >> (8 * j))); }
 }  // namespace emu
-// v_mfma_f32_32x32x16_fp8_fp8: A/B = 8 e4m3 bytes per lane (one 64-bit register pair), same fragment layout as the bf16 form
-inline emu::f32x16_t emu_mfma_32x32x16_fp8_fp8(long a, long b, emu::f32x16_t c, int, int, int) {
-    emu::AB8F m{a, b};
-    return emu::mfma<32, 8, emu::AB8F, emu::f32x16_t, 16>(m, c, emu::ga8f, emu::gb8f);
-}
 namespace emu {
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 struct AB8H { f16x8_t a, b; };
@@ -432,7 +424,6 @@ inline emu::f32x16_t emu_mfma_scale_32x32x64_f8f6f4(emu::v8i_t a, emu::v8i_t b, 
 }
 #define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 emu_mfma_scale_32x32x64_f8f6f4
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_mfma_32x32x16_f16
-#define __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8 emu_mfma_32x32x16_fp8_fp8
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2f32

@@ -75,6 +75,7 @@ def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision, "llm_x8": bool(model.llm_x8),
+           "x8_gemms": [n for n, f in (("w1", getattr(model, "llm_x8_w1", False)), ("w2", getattr(model, "llm_x8_w2", False))) if f],
            "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 2)}
     ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
     if len(ents) == 1:
@@ -127,7 +128,8 @@ def main():
     out, sd_cache, oc = [], {}, {}
     for key in only:
         out.append(run(key, "f16x3", sd_cache, seeds, oc))
-        out.append(run(key, "bf16", sd_cache, min(seeds, 1), oc))       # contrast line: does not meet the bar on this network
+        if "--no-bf16" not in av:
+            out.append(run(key, "bf16", sd_cache, min(seeds, 1), oc))   # contrast line: does not meet the bar on this network
     if "--json" in av:
         with open(av[av.index("--json") + 1], "w") as f:
             json.dump(out, f, indent=1)

@@ -4,7 +4,9 @@ reordering).  Per pair and mode: mean / min / pooled mask IoU, pixel, semantic-a
 number of reference masks below 64 pixels (whose IoU is quantised in steps of 1/area).
 
     python tools/parity_seeds.py [task=panoptic] [size=1024] [pairs=0:0,0:1,0:2,1:1,2:2]  -> one JSON line per (pair, mode) + a summary line
-Modes: "f16x3" (default product mode: Phi GEMM cross terms in e4m3) and "f16x3-3p" (three f16 products everywhere)."""
+Modes: "f16x3" (default product mode: Phi GEMM cross terms in e4m3) and "f16x3-3p" (three f16 products everywhere); PARITY_FP32=1 adds the
+exact-fp32 GPU mode (the oracle's arithmetic in another summation order: how far does an input move under re-ordering ALONE?).
+PARITY_BATCH: images per call."""
 import json
 import os
 import sys
@@ -57,6 +59,10 @@ def main():
             sd = make_state_dict(cfg, seed=wseed)
             sd_seed = wseed
             models = {"f16x3": PSALM(cfg, sd, precision="f16x3"), "f16x3-3p": PSALM(cfg, sd, precision="f16x3", llm_cross_fp8=False)}
+            for sel in [x for x in os.environ.get("PARITY_X8", "").split(",") if x]:      # e.g. PARITY_X8=w1,w2,both: which Phi GEMMs take e4m3 cross terms
+                models["f16x3-x8" + sel] = PSALM(cfg, sd, precision="f16x3", llm_cross_fp8=sel)
+            if os.environ.get("PARITY_FP32") == "1":          # the exact-fp32 GPU mode: same arithmetic as the oracle, another summation order
+                models["fp32"] = PSALM(cfg, sd, precision="fp32")
         inputs = make_inputs(cfg, task, size=size, batch=batch, seed=iseed)
         t0 = time.perf_counter()
         torch.manual_seed(1234)
@@ -72,8 +78,10 @@ def main():
                 rows.append(r)
                 print(json.dumps(r), flush=True)
     summ = {}
-    for mode in ("f16x3", "f16x3-3p"):
+    for mode in sorted({r["mode"] for r in rows}):
         rs = [r for r in rows if r["mode"] == mode]
+        if not rs:
+            continue
         summ[mode] = {"pairs": len(rs), "mask_iou_mean_min_over_seeds": min(r["mask_iou_mean"] for r in rs),
                       "mask_iou_pooled_min_over_seeds": min(r["mask_iou_pooled"] for r in rs),
                       "mask_iou_mean_area_ge_64_min_over_seeds": min((r["mask_iou_mean_area_ge_64"] for r in rs if r["mask_iou_mean_area_ge_64"] is not None), default=None),
