@@ -18,9 +18,10 @@ Precision modes
             bar on this network (the mask decoder's thresholded attention-mask feedback amplifies operand rounding into label flips;
             measured threshold between 15 and 17 operand bits, tools/exp_bits.py); this mode does, at 3 f16 MFMA passes instead of
             the fp32 MFMA's 16x lower rate.  Activations, norms, softmax and the attention kernels are those of "fp32".
-            With `llm_cross_fp8` (default where the shapes allow): the Phi decoder's GEMMs carry their two cross terms lo.hi + hi.lo as
-            ONE OCP e4m3 dot product on the block-scaled fp8 matrix instruction (2 instead of 3 f16-product equivalents; BASELINE.json
-            configs[4] names an "fp8 MFMA LLM path" -- this is the one that keeps parity, see PSALM.__init__).
+            With `llm_cross_fp8` (default "w2" where the shapes allow): Phi's [dense | fc2] GEMM -- or, "both", its [k|v|q|fc1] GEMM too --
+            carries its two cross terms lo.hi + hi.lo as ONE OCP e4m3 dot product on the block-scaled fp8 matrix instruction (2 instead
+            of 3 f16-product equivalents; BASELINE.json configs[4] names an "fp8 MFMA LLM path" -- this is the form that keeps parity,
+            and why only one of the two GEMMs takes it by default is written at PSALM.__init__).
 
 Layout: activations are token-major (rows = pixels/tokens, cols = channels; NHWC for feature maps), so 1x1
 convolutions are GEMMs, 3x3 / strided convolutions are im2col + GEMM, and LayerNorm/softmax rows are contiguous.
@@ -97,7 +98,7 @@ class PSALM:
     DEFAULT_PRECISION = "f16x3"
 
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
-                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8: Optional[bool] = None,
+                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8=None,
                  paired_split_stores: Optional[bool] = None):
         precision = precision or self.DEFAULT_PRECISION
         if precision not in ("bf16", "fp32", "f16x3"):
@@ -134,9 +135,9 @@ class PSALM:
         # accumulators (psalm_gemm_x3_split, split_form bit 2) -- results bit for bit those of the un-permuted layout.  A construction-time
         # choice (the weights are laid out for it): such a model cannot be switched to fuse_split = False afterwards.
         self.so_paired = self.fuse_split if paired_split_stores is None else (bool(paired_split_stores) and self.fuse_split)
-        # f16x3: the Phi decoder's GEMMs form their two cross terms (lo.hi + hi.lo, 2^-11 of the result) as ONE e4m3 dot product on the
+        # f16x3: a Phi GEMM can form its two cross terms (lo.hi + hi.lo, 2^-11 of the result) as ONE e4m3 dot product on the
         # block-scaled fp8 matrix instruction (operand form "x8", csrc/common.h psalm_split_words): 2 instead of 3 f16-product equivalents
-        # for 2/3 of the path's GEMM flops.  Decided on numerics first (tools/exp_fp8cross.py, profiles/r03d_*: over 10 weight / input
+        # (the two Phi GEMMs are 2/3 of the path's GEMM flops).  Decided on numerics first (tools/exp_fp8cross.py, profiles/r03d_*: over 10 weight / input
         # seeds the Phi stage in this arithmetic is indistinguishable from the three-product form -- mask logits move by 5e-6 of their
         # range, mean mask IoU vs exact fp32 >= 0.99999 -- while the Swin and pixel-decoder GEMMs are NOT tolerant and keep three
         # products).  Needs hidden and hidden + intermediate to be multiples of 128 and the fused operand hand-over (fuse_split).
