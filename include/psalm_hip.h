@@ -196,6 +196,8 @@ int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k
 /* zero `bytes` bytes / copy `bytes` bytes device-to-device, as stream operations (hipMemsetAsync / hipMemcpyAsync; graph-capturable) */
 int psalm_memset_zero(void* p, long bytes, void* stream);
 int psalm_copy_d2d(void* dst, const void* src, long bytes, void* stream);
+/* dst[i] = (int64) src[i]: the LongTensor label / query-index vectors of `Instances` (llava_phi.py:317-323, 428-447) */
+int psalm_cast_i32_i64(const int* src, long long* dst, long n, void* stream);
 /* Template instantiation (as a kernel trace names it, e.g. "gemm_bf16_glds_kernel<float, 256, 256, 2, 4, 2, false, 64, 3, 3, true>") of the
  * calling thread's most recent GEMM launch through psalm_gemm / psalm_gemm_x3* / psalm_conv2d_nhwc / psalm_gemm_ln. */
 const char* psalm_gemm_last_kernel(void);

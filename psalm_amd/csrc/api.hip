@@ -29,6 +29,18 @@ extern "C" int psalm_memset_zero(void* p, long bytes, void* stream) {
     if (e != hipSuccess) { psalm_set_error("psalm_memset_zero: hipMemsetAsync failed"); return (int)e; }
     return 0;
 }
+// int32 -> int64 (the label / query-index vectors of the results: the reference hands out LongTensors) as a kernel of this library, so that a
+// captured launch sequence of the path holds no framework kernel
+__global__ void cast_i32_i64_kernel(const int* __restrict__ src, long long* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (long long)src[i];
+}
+extern "C" int psalm_cast_i32_i64(const int* src, long long* dst, long n, void* stream) {
+    if (n <= 0) return 0;
+    PSALM_CHECK_ARG(dst != nullptr && src != nullptr, "psalm_cast_i32_i64: null pointer");
+    hipLaunchKernelGGL(cast_i32_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    PSALM_LAUNCH_END("psalm_cast_i32_i64");
+}
 extern "C" int psalm_copy_d2d(void* dst, const void* src, long bytes, void* stream) {
     if (bytes <= 0) return 0;
     PSALM_CHECK_ARG(dst != nullptr && src != nullptr, "psalm_copy_d2d: null pointer");

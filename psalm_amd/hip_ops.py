@@ -184,6 +184,14 @@ class Ops:
         self._check(self.lib.psalm_memset_zero(self._p(t), c_long(t.numel() * t.element_size()), self._stream()), "psalm_memset_zero")
         return t
 
+    def to_i64(self, t):
+        """int32 vector -> int64 (psalm_cast_i32_i64): the reference's label / index tensors are LongTensors"""
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise PsalmHipError("to_i64: contiguous int32 tensor")
+        out = self.empty(*t.shape, dtype=torch.int64)
+        self._check(self.lib.psalm_cast_i32_i64(self._p(t), self._p(out), c_long(t.numel()), self._stream()), "psalm_cast_i32_i64")
+        return out
+
     def copy_(self, dst, src):
         """dst <- src for two contiguous device tensors of equal dtype / numel, as a stream copy (no framework kernel)."""
         if dst.dtype != src.dtype or dst.numel() != src.numel() or not (dst.is_contiguous() and src.is_contiguous()) or src.device != dst.device:

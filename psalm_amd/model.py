@@ -1222,7 +1222,7 @@ class PSALM:
             probs, _, _, _ = o.class_softmax(cls, (Q + 63) // 64 * 64, probsT_dtype=self.wdt)
             mscore = o.mask_scores(mflat)
             sc, cl, qq, cnt = o.topk_select(probs, C1 - 1, Q, None, mscore)
-            res["_pending"] = ("instance", sc, cl, qq, cnt, o.binarize_gather(mp, Q, qq, cnt))
+            res["_pending"] = ("instance", sc, o.to_i64(cl), o.to_i64(qq), cnt, o.binarize_gather(mp, Q, qq, cnt), o.zeros(sc.shape[0], 4))
             res["mask_pred"] = mp
             return res
         if task == "panoptic":
@@ -1238,17 +1238,19 @@ class PSALM:
             inst_masks = o.binarize_gather(mp, Q, qq, cnt)
             pan, pinfo, ninfo = o.panoptic(mp, score, label, thing, C1 - 1, cfg.object_mask_threshold, cfg.overlap_threshold,
                                            info_out=counts[2:].view(Q, 3), ninfo_out=counts[1:2])
-            res["_pending"] = ("panoptic", sc, cl, qq, counts, inst_masks, pan)
+            # (LongTensor labels / indices and the all-zero pred_boxes of `Instances` are made HERE, inside the captured launch sequence,
+            #  by this library's cast / memset: _finalize only slices -- no framework kernel per image)
+            res["_pending"] = ("panoptic", sc, o.to_i64(cl), o.to_i64(qq), counts, inst_masks, pan, o.zeros(sc.shape[0], 4))
         elif task == "referring":
             mscore = o.mask_scores(mflat)
             sc, cl, qq, cnt = o.topk_select(r["pred_SEG_logits"], 1, Q, None, mscore, apply_sigmoid=True)    # LP:308-324
             inst_masks = o.binarize_gather(mp, Q, qq, cnt)
-            res["_pending"] = ("referring", sc, qq, inst_masks)
+            res["_pending"] = ("referring", sc, o.to_i64(qq), inst_masks, o.zeros(inst_masks.shape[0], 4))
         elif task == "region":
             mscore = o.mask_scores(mflat)
             scores = o.region_scores(r["pred_region_logits"], mscore)                                        # LP:387-400
             inst_masks = o.binarize_gather(mp, Q)
-            res["_pending"] = ("region", scores, inst_masks)
+            res["_pending"] = ("region", scores, inst_masks, o.zeros(Q, 4))
         else:
             raise NotImplementedError(f"seg_task {task}")
         res["mask_pred"] = mp
@@ -1270,31 +1272,27 @@ class PSALM:
         if pend[0] == "semantic":
             return res
         if pend[0] == "instance":
-            _, sc, cl, qq, cnt, inst_masks = pend
+            _, sc, cl, qq, cnt, inst_masks, boxes = pend
             n = int(cnt.item())
-            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n].to(torch.int64),
-                                         query_index=qq[:n].to(torch.int64), pred_boxes=torch.zeros(n, 4, device=self.device))
+            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n], query_index=qq[:n], pred_boxes=boxes[:n])
             return res
         if pend[0] == "panoptic":
-            _, sc, cl, qq, counts, inst_masks, pan = pend
+            _, sc, cl, qq, counts, inst_masks, pan, boxes = pend
             hc = counts.cpu().tolist()                            # the image's one host round trip: both counts + the segment table
             n, ni = hc[0], hc[1]
-            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n].to(torch.int64),
-                                         query_index=qq[:n].to(torch.int64), pred_boxes=torch.zeros(n, 4, device=self.device))
+            res["instances"] = Instances(hw, pred_masks=inst_masks[:n], scores=sc[:n], pred_classes=cl[:n], query_index=qq[:n], pred_boxes=boxes[:n])
             rows = [hc[2 + 3 * i: 5 + 3 * i] for i in range(ni)]
             res["panoptic_seg"] = (pan, [{"id": a, "isthing": bool(b), "category_id": c} for a, b, c in rows])
         elif pend[0] == "referring":
-            _, sc, qq, inst_masks = pend
-            res["instances"] = Instances(hw, pred_masks=inst_masks, scores=sc, query_index=qq.to(torch.int64),
-                                         pred_boxes=torch.zeros(inst_masks.shape[0], 4, device=self.device))
+            _, sc, qq, inst_masks, boxes = pend
+            res["instances"] = Instances(hw, pred_masks=inst_masks, scores=sc, query_index=qq, pred_boxes=boxes)
         else:
-            _, scores, inst_masks = pend
+            _, scores, inst_masks, boxes = pend
             gt = info["instances"].gt_masks
             gt = gt.tensor if hasattr(gt, "tensor") else gt
             gt = gt.to(self.device, torch.float32).contiguous()
             res["gt"] = self.ops.resize_planes(gt, hw[0], hw[1], crop=(oh, ow))                              # LP:1458-1461
-            Q = inst_masks.shape[0]
-            res["instances"] = Instances(hw, pred_masks=inst_masks, scores=scores, pred_boxes=torch.zeros(Q, 4, device=self.device))
+            res["instances"] = Instances(hw, pred_masks=inst_masks, scores=scores, pred_boxes=boxes)
         return res
 
     # ---- hipGraph execution: the ~600 launches of one call are captured once per input signature and replayed
