@@ -175,7 +175,7 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
     cfg = PsalmConfig.tiny(task)
     sd = make_state_dict(cfg, seed=21)
     inputs = make_inputs(cfg, task, size=96, batch=batch, seed=6, num_classes=7)            # batch 2: ragged prompts, padded key mask
-    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8=False)    # (the x8 weight form exists only with the hand-over)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
     assert model.fuse_split and not model.llm_x8 and model.so_paired and any(model.paired.values())
     kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
     torch.manual_seed(5)
@@ -183,7 +183,7 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
     model.fuse_split = False                              # its fc1 / linear1 rows are permuted for the paired stores of the hand-over: refused
     with pytest.raises(Exception, match="paired"):
         model.forward_logits(**kw)
-    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8=False, paired_split_stores=False)
+    model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", paired_split_stores=False)
     assert not any(model.paired.values())
     model.fuse_split = False
     torch.manual_seed(5)
@@ -199,8 +199,8 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
 def test_tiny_f16x3_llm_cross_terms_in_e4m3_match_three_products():
     """The Phi GEMMs in the x8 operand form (cross terms lo.hi + hi.lo as one e4m3 dot product) against the same model with three f16 products
     everywhere: the cross terms are 2^-11 of a product and carry 3 mantissa bits -> ~2^-16 per GEMM.  Both GEMMs ("both": every x8 kernel
-    path -- LayerNorm / GEMM epilogue / attention emitting the form, the x8 K loop with and without split-f16 output) and the default
-    (only [dense|fc2]: see PSALM.__init__)."""
+    path -- LayerNorm / GEMM epilogue / attention emitting the form, the x8 K loop with and without split-f16 output) and "w2" (a
+    three-product [k|v|q|fc1] emitting the x8 operand of [dense|fc2]).  The default is three products everywhere (PSALM.__init__)."""
     cfg = PsalmConfig.tiny("panoptic")
     sd = make_state_dict(cfg, seed=8)
     inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=3, num_classes=9)
@@ -214,7 +214,8 @@ def test_tiny_f16x3_llm_cross_terms_in_e4m3_match_three_products():
     b = m3.forward_logits(stages=st3, **kw)[0]
     assert _rel(st8["hidden_states"], st3["hidden_states"]) < 2e-4
     assert 0 < _rel(a["pred_masks"], b["pred_masks"]) < 5e-4
-    md = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
+    assert not PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3").llm_x8          # the default: three products (PSALM.__init__)
+    md = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8="w2")
     assert md.llm_x8 and md.llm_x8_w2 and not md.llm_x8_w1 and md.w["llm0.w1"].form == 0 and md.w["llm0.w2"].form == 2
     d = md.forward_logits(stages=std, **kw)[0]
     assert _rel(std["hidden_states"], st3["hidden_states"]) < 2e-4

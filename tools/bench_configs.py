@@ -1,5 +1,5 @@
 """BASELINE.json configs other than the headline one, as side-lines (bench.py stays on configs[1]): throughput of the HIP path in the
-QUALIFYING mode (f16x3: split-f16 GEMMs, Phi cross terms in e4m3 -- the default product mode) and, for contrast, the bf16 fast mode; parity
+QUALIFYING mode (f16x3: split-f16 GEMMs, three products -- the default product mode) and, for contrast, the bf16 fast mode; parity
 against the CPU oracle over several seeded inputs ("the configs' lines in the mode that meets the bar"), and which kernel
 instantiation dominates each.
 
@@ -9,8 +9,8 @@ instantiation dominates each.
   config 5  interactive (region prompts) 1024x1024 batch=2
 Per line: images/s (hipGraph replay, results consumed per step), the graph's own GPU time, parity min-over-seeds (mean / pooled IoU, IoU over
 reference masks of >= 64 pixels, mask-logit error, and for panoptic the semantic / panoptic agreement), the three launches that take most of
-a step with their share.  fp8 (e4m3) for WHOLE operands is not a mode any more: profiles/r03a_cross_term_precision.jsonl -- only the cross
-terms of the Phi GEMMs tolerate it, which is what f16x3 does."""
+a step with their share.  fp8 (e4m3) for WHOLE operands is not a mode any more (profiles/r03a_cross_term_precision.jsonl); for the cross
+terms of the Phi GEMMs it is the opt-in fast form PSALM(llm_cross_fp8="both") -- `--x8 both` runs the f16x3 lines in it."""
 import json
 import os
 import sys
@@ -62,7 +62,8 @@ def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
         sd_cache.clear()
         sd_cache[task] = make_state_dict(cfg, seed=0)
     sd = sd_cache[task]
-    model = PSALM(cfg, sd, precision=precision, use_graphs=True)
+    x8 = sys.argv[sys.argv.index("--x8") + 1] if "--x8" in sys.argv and precision == "f16x3" else None
+    model = PSALM(cfg, sd, precision=precision, use_graphs=True, llm_cross_fp8=x8)
     model.graph_outputs = "alias"
     inputs = make_inputs(cfg, task, size=size, batch=batch, seed=3)
     inputs["images"] = inputs["images"].cuda()
