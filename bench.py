@@ -422,7 +422,7 @@ def main():
             parity["meets_bar_plain_mean"] = bool(parity["seeds"]["mask_iou_mean_min"] >= 0.999 and parity["seeds"]["semantic_argmax_agreement_min"] >= 0.999)
         if not args.no_side_modes and args.precision == "f16x3" and not model_info.llm_x8:
             # side line: the f16x3 FAST form -- e4m3 cross terms in both Phi GEMMs (PSALM(llm_cross_fp8="both")).  NOT `value`: it passes this
-            # gate (and every panoptic / region input it was tried on) but ~5 % of referring inputs move by 1e-3 of the logit range in it
+            # gate when run as the main mode, but ~5 % of inputs move by 1e-3 or more of the logit range in it
             # (PSALM.__init__) -- so the default, and `value`, are three f16 products everywhere.
             try:
                 mx = PSALM(cfg, sd, precision="f16x3", use_graphs=not args.eager, llm_cross_fp8="both")
