@@ -147,9 +147,9 @@ class PSALM:
         # OFF by default since the end of r03: the form passed the 5-seed gate of bench.py and all but one input of the GPU runs, but ~5 % of
         # the inputs (referring and panoptic alike) move by 1e-3 .. 6e-2 of the logit range instead of 3e-6, whichever of the two GEMMs
         # carries it (one GPU image of 20 below the bar with [k|v|q|fc1] in the form, profiles/r03n_* / r03o_*; CPU restatement of the
-        # arithmetic on the oracle, tools/exp_x8_cpu.py, profiles/r03s_*: 3 / 52 referring images with either GEMM and 2 / 16 panoptic ones, 0 / 48 + 0 / 2 with three products):
-        # a 2^-15-level perturbation of the Phi stage is enough to tip the mask decoder's thresholded attention masks on such inputs, a
-        # 2^-22-level one was not observed to.  The form stays available as the fast mode (bench.py reports it as a side line).
+        # arithmetic on the oracle, tools/exp_x8_cpu.py, profiles/r03s_*: 5 of 68 inputs moved in the x8 form (up to 6e-2), 1 of 64 with three products (9e-4)):
+        # a 2^-15-level perturbation of the Phi stage tips the mask decoder's thresholded attention masks on such inputs four times as often,
+        # and further, than the 2^-22-level one every re-implementation carries.  The form stays available as the fast mode (bench.py reports it as a side line).
         sel = {None: "", False: "", True: "w1w2", "w1": "w1", "w2": "w2", "both": "w1w2"}[llm_cross_fp8] if can_x8 else ""
         self.llm_x8_w1, self.llm_x8_w2 = "w1" in sel, "w2" in sel
         self.llm_x8 = self.llm_x8_w1 or self.llm_x8_w2
