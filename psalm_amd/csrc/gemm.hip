@@ -375,10 +375,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || X3 == 3 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel / x8 form, or 32-deep slices in two stages");
     static_assert(X3 != 3 || (PH8 == 3 && BK == 64), "x8 form: the phased 256 x 256 K loop");
-    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BK == 64 && !CONV), "PH8 configuration");
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && (BK == 64 || (BK == 32 && X3 == 2 && PH8 == 3)) && !CONV), "PH8 configuration");
     static_assert(!X3 || !CONV, "split-f16 variants: plain GEMM");
     static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
-    static_assert(X3 != 2 || (!PH8 && (BK == 64 || BK == 32)), "split-f16 slice form: generic K loop");
+    static_assert(X3 != 2 || ((!PH8 && (BK == 64 || BK == 32)) || (PH8 == 3 && BK == 32)), "split-f16 slice form: generic K loop, or the phased 256 x 256 loop on 32-deep slices");
     constexpr int XS = X3 == 2 ? 2 : 1;                          // operand images per stage (slice form: hi and lo)
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -409,13 +409,20 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     const bf16_t* W = (const bf16_t*)g.W;
 
     // per-lane global sources of this wave's chunks (chunk c covers tile rows 8c..8c+7; lane -> row 8c + lane/8, slot lane%8)
+    constexpr bool PHS = PH8 != 0 && X3 == 2;                    // phased loop on 32-deep slices: 16-row chunks, one (hi, lo) copy pair per wave per half
+    // A chunk of copy i.  PHS: copy q of every wave together = "A half q" = m-tiles {2q, 2q+1} of BOTH wave rows (16-row groups 4q..4q+3
+    // and 8+4q..8+4q+3, one per wave).
+    auto a_chunk = [&](int i) -> int {
+        if constexpr (PHS) return 4 * i + (wave & 3) + 8 * (wave >> 2);
+        else return wave + NW * i;
+    };
     const bf16_t* asrc[A_CH];
     const bf16_t* bsrc[B_CH];
     const int lrow = lane / SLOTS, slot = lane % SLOTS;
     int ay[A_CH], ax[A_CH];                                      // CONV: top-left input pixel of this lane's output pixel
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int r = (wave + NW * i) * RPC + lrow;
+        const int r = a_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
         const int m = min(bm + r, g.M - 1);
         if constexpr (CONV) {
@@ -431,7 +438,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
     // columns of n-tile h of all four wave columns (= "B half h": the rows one phase reads), two copies per wave per half.
     auto b_chunk = [&](int i) -> int {
-        if constexpr (PH8) { const int e = 2 * wave + (i & 1); return 8 * (e >> 2) + 4 * (i >> 1) + (e & 3); }
+        if constexpr (PHS) return 4 * (wave >> 1) + 2 * i + (wave & 1);      // copy j of every wave = "B half j": n-tile j of all four wave columns
+        else if constexpr (PH8) { const int e = 2 * wave + (i & 1); return 8 * (e >> 2) + 4 * (i >> 1) + (e & 3); }
         else return wave + NW * i;
     };
 #pragma unroll
@@ -466,12 +474,12 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const int y = ay[i] + ky, x = ax[i] + kx;
                 const bool in = y >= 0 && y < fa.cH && x >= 0 && x < fa.cW;
                 const bf16_t* src = in ? asrc[i] + ((long)y * fa.cW + x) * fa.cC + c0 : fa.zeros;
-                psalm_glds16(src, As + (wave + NW * i) * RPC * BK);
+                psalm_glds16(src, As + a_chunk(i) * RPC * BK);
             }
         } else {
             const int ka = x3_acol(koff);
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + ka, As + (wave + NW * i) * RPC * BK);
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + ka, As + a_chunk(i) * RPC * BK);
         }
         const int kw = x3_wcol(koff);
 #pragma unroll
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             bf16_t* Al = smem[buf] + (BM + BN) * BK;
             bf16_t* Bl = Al + BM * BK;
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + fa.x3_kp + koff, Al + (wave + NW * i) * RPC * BK);
+            for (int i = 0; i < A_CH; ++i) psalm_glds16(asrc[i] + fa.x3_kp + koff, Al + a_chunk(i) * RPC * BK);
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) psalm_glds16(bsrc[i] + fa.x3_kp + koff, Bl + b_chunk(i) * RPC * BK);
         }
@@ -504,7 +512,109 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     // with the stage read in step kt-1, which is then refilled with tile kt+NS-1.
     constexpr int LPT = (A_CH + B_CH) * XS;                      // copy instructions per wave per tile
     const int nk = (kend - kbeg) / BK;
-    if constexpr (PH8) {
+    if constexpr (PHS) {
+        // ---- PH8 schedule on 32-deep SLICES of the split-f16 operands (r04).  A stage holds the FOUR images of one slice of the true K range
+        // (A hi | W hi | A lo | W lo, 16 KB each: the 128 KB of the K-panel form's two 64-deep stages) and a phase forms the three products
+        // hi.hi + lo.hi + hi.lo of its 64 x 32 quadrant: 12 matrix instructions per phase instead of 8, per 2 copies and 6 + 6 fragment reads
+        // -- 2/3 of the K-panel form's L2 -> LDS bytes and LDS fragment reads per product, 2/3 of its barriers, and W hi is fetched ONCE (the
+        // K-panel form walks it twice, 32 K steps apart: its second pass missed the XCD's L2 -- counter traffic 1.8x compulsory, r03p).
+        // Halves, phases, refill points, hazards and the vmcnt counts are those of the 64-deep schedule below: a half is the SAME rows, now
+        // as a (hi, lo) pair of 16-row chunks per wave instead of two 8-row chunks.
+        static_assert(PH8 == 3, "slice form: copies inside the MFMA segment, bare barriers");
+        constexpr int LO = (BM + BN) * BK;                       // the lo images sit behind the hi images of a stage
+        bf16x8 ah[2][2], al[2][2], bh[2], bl[2];                 // [m-tile of the half][kk] / [kk]
+        auto read_a = [&](const bf16_t* As_, int q) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int off = (a_row0 + 32 * (2 * q + i)) * BK + co;
+                    ah[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[off]));
+                    al[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[LO + off]));
+                }
+            }
+        };
+        auto read_b = [&](const bf16_t* Bs_, int j) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int off = (b_row0 + 32 * j) * BK + ((2 * kk + hi) ^ fsw) * 8;
+                bh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs_[off]));
+                bl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs_[LO + off]));
+            }
+        };
+        // half copies: which = 0 the hi image's chunk, 1 the lo image's, 2 both
+        auto stage_a = [&](int buf, int koff, int q, int which = 2) {
+            bf16_t* d = smem[buf] + a_chunk(q) * RPC * BK;
+            if (which != 1) psalm_glds16(asrc[q] + koff, d);
+            if (which != 0) psalm_glds16(asrc[q] + fa.x3_kp + koff, d + LO);
+        };
+        auto stage_b = [&](int buf, int koff, int j, int which = 2) {
+            bf16_t* d = smem[buf] + BM * BK + b_chunk(j) * RPC * BK;
+            if (which != 1) psalm_glds16(bsrc[j] + koff, d);
+            if (which != 0) psalm_glds16(bsrc[j] + fa.x3_kp + koff, d + LO);
+        };
+        // 12 matrix instructions, the two accumulators of the quadrant alternating; the phase's two copies after the 2nd and the 8th
+        auto mma = [&](int q, int j, auto&& copy) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(ah[i][kk], bh[kk], acc[2 * q + i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                copy(kk);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(al[i][kk], bh[kk], acc[2 * q + i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(ah[i][kk], bl[kk], acc[2 * q + i][j]);
+            }
+        };
+#define PHS_ENTER_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
+                              __builtin_amdgcn_s_setprio(1); } while (0)
+#define PHS_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); \
+                              __builtin_amdgcn_sched_barrier(0); } while (0)
+        // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
+        auto tile_phases = [&](int t, int mode) {
+            const int cur = t & 1;
+            const bf16_t* As_ = smem[cur];
+            const bf16_t* Bs_ = smem[cur] + BM * BK;
+            read_b(Bs_, 0);                                      // P1
+            read_a(As_, 0);
+            PHS_ENTER_MFMA();
+            mma(0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
+            PHS_LEAVE_MFMA();
+            read_b(Bs_, 1);                                      // P2
+            PHS_ENTER_MFMA();
+            mma(0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
+            PHS_LEAVE_MFMA();
+            read_a(As_, 1);                                      // P3
+            PHS_ENTER_MFMA();
+            mma(1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
+            PHS_LEAVE_MFMA();
+            read_b(Bs_, 0);                                      // P4
+            // everything but the 2 most recent halves has landed = all of tile t+1 (this phase's copies are issued after the wait)
+            if (mode == 0) wait_vmcnt_le<4>();
+            else if (mode == 1) wait_vmcnt_le<0>();
+            PHS_ENTER_MFMA();
+            mma(1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
+            PHS_LEAVE_MFMA();
+        };
+        stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
+        stage_a(1, BK, 0); stage_b(1, BK, 1); stage_a(1, BK, 1);                       // tile 1 except B0 (6 copies)
+        PSALM_TL(1);
+        wait_vmcnt_le<6>();
+        PSALM_RAW_BARRIER();
+        PSALM_TL(2);
+        if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
+        int t = 0;
+#pragma unroll 1
+        for (; t + 2 < nk; ++t) tile_phases(t, 0);
+        tile_phases(t, 1);
+        tile_phases(t + 1, 2);
+        if (wm == 0) PSALM_RAW_BARRIER();                        // pairs with wave row 1's last barrier
+#undef PHS_ENTER_MFMA
+#undef PHS_LEAVE_MFMA
+    } else if constexpr (PH8) {
         // ---- PH8 schedule (256 x 256 tile, host guarantees nk >= 2).  A K tile is consumed in 4 phases, one 64 x 32 quadrant of
         // the wave's 128 x 64 output each (8 MFMAs):   P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
         // where A-half q = m-tiles {2q, 2q+1} of both wave rows (copies q, q+2 of every wave) and B-half j = n-tile j of all four
@@ -1584,6 +1694,10 @@ static int g_ph8 = 3;
 // with 1.5x the matrix work per copy round trip and 2/3 of the copies: 3-17 % faster on 17 of 21 shapes of the image (M5184 N512 K512
 // 22.0 -> 18.3 us, M21504 N256 K1024 60.3 -> 52.6, M65536 N128 K512 43.4 -> 38.1), equal within noise on the rest: the automatic choice.
 static int g_x3_slice = 0;
+// split-f16 GEMMs on the 256 x 256 tile: 1 = the phased K loop walks 32-deep SLICES (four operand images per stage, three products per
+// phase: 2/3 of the L2 -> LDS bytes, fragment reads and barriers of the K-panel form, W hi fetched once), 0 = the K-panel form (3 Kp-long
+// loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).
+static int g_ph8_slice = 0;
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
@@ -1592,6 +1706,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
+    if (bm == 2580 || bm == 2581) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices
     if (bm >= 3300 && bm <= 3305) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
@@ -1699,7 +1814,11 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
     int slice = !x3 || x8 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
-    if (fa.so && slice != 3) slice = 0;                           // split-f16 output: K-panel form or form 3
+    if (x3 && !x8 && BM == 256 && g_ph8 && g_ph8_slice) {        // 256 x 256: the phased loop on 32-deep slices (form 6) when every K slice of the grid has >= 2 of them
+        const int kp_ = fa.x3_kp, kps_ = splits > 1 ? cdiv(cdiv(kp_, 64), splits) * 64 : kp_, sp_ = cdiv(kp_, kps_);
+        if (kps_ >= 64 && kp_ - (sp_ - 1) * kps_ >= 64) slice = 6;
+    }
+    if (fa.so && slice != 3 && slice != 6) slice = 0;             // split-f16 output: K-panel form, form 3 or form 6
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
         kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
@@ -1719,7 +1838,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     const dim3 grid((unsigned)tiles, splits);
     if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
         const bool ph_ = x3 && !x8 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
-        if (!(x8 || slice == 3 || ph_) || fa.so_col_start % BN != 0) {
+        if (!(x8 || slice == 3 || slice == 6 || ph_) || fa.so_col_start % BN != 0) {
             psalm_set_error("psalm_gemm_x3_split: paired output is not available under this tile policy / for this column start");
             return -1;
         }
@@ -1737,7 +1856,10 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
         // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
         // with 1.5x the matrix work per copy round trip
-        if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
+        if (slice == 6 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true, true);
+        else if (slice == 6 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true);
+        else if (slice == 6) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, false);
+        else if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (slice == 3 && fa.so && fa.so_paired) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);
         else if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);

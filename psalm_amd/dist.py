@@ -76,22 +76,27 @@ def _flat_weights(model):
 
 
 def weights_checksum(model) -> int:
-    """Order-independent integer checksum of every prepared weight tensor's BYTES (sum of the 16-bit words, per tensor weighted by a
-    name hash): equal on two ranks iff -- up to a 2^-60-ish collision -- their weight arenas are bit-identical."""
+    """Integer checksum of every prepared weight tensor's BYTES, position dependent: per tensor  sum_i byte_i * (i mod 65521 + 1)  (int64, in
+    16 MiB pieces), weighted by a hash of the tensor's name, modulo 2^61.  Two arenas that differ in one byte, or hold the same bytes in
+    another order (a row permutation, a transposed layout), get different sums up to a ~2^-60 collision; not a cryptographic hash."""
     total = 0
     for k, t in sorted(_flat_weights(model).items()):
-        t = t.contiguous()
-        nb = t.numel() * t.element_size()
-        words = t.view(torch.int16) if nb % 2 == 0 else t.view(torch.uint8)
+        b = t.contiguous().reshape(-1).view(torch.uint8)            # reshape first: 0-dim tensors and odd last dimensions view cleanly
+        acc = 0
+        for off in range(0, b.numel(), 1 << 24):
+            piece = b[off:off + (1 << 24)].to(torch.int64)
+            idx = (torch.arange(off, off + piece.numel(), device=b.device, dtype=torch.int64) % 65521) + 1
+            acc += int((piece * idx).sum().item())
         h = sum((i + 1) * ord(c) for i, c in enumerate(k)) % 1000003 + 1
-        total = (total + h * int(words.sum(dtype=torch.int64).item())) % (1 << 61)
+        total = (total + h * (acc % (1 << 61))) % (1 << 61)
     return total
 
 
-def check_weights_identical(model, device=None) -> Tuple[bool, int]:
-    """All ranks hold the same weights?  MIN / MAX all-reduce of the per-rank checksum (two 31-bit halves: exact in any backend)."""
+def check_weights_identical(model, device=None, force: bool = False) -> Tuple[bool, int]:
+    """All ranks hold the same weights?  MIN / MAX all-reduce of the per-rank checksum (two 31-bit halves: exact in any backend).
+    `force`: run the all-reduces in a one-rank group too (bench.py --force-dist: RCCL dry run on one GPU)."""
     c = weights_checksum(model)
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return True, c
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -394,6 +394,10 @@ class Ops:
         self._cdll_raw.psalm_gemm_describe(M, N, K, BF16 if a_bf16 else F32, BF16 if w_bf16 else F32, c_long(self.GEMM_WS_BYTES), out)
         return tuple(out)
 
+    def gemm_last_kernel(self) -> str:
+        """template instantiation of this thread's last direct-to-LDS GEMM launch, as a kernel trace spells it"""
+        return self._cdll_raw.psalm_gemm_last_kernel().decode()
+
     def gemm_tile_policy(self, bm: int):
         """0 = automatic, 256 / 128 / 64 = force the direct-to-LDS kernel's tile height (tuning / tests)."""
         self._check(self.lib.psalm_gemm_set_tile_policy(bm), "psalm_gemm_set_tile_policy")

@@ -433,6 +433,35 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
                           split_col_start=col_start, act_col_start=col_start, out=out, split_form=1 if x8 else 0, paired=True)
 
 
+@pytest.mark.parametrize("M,N,K,has_bias,has_res,act", [
+    (300, 520, 192, True, True, H.ACT_GELU_NEW),                    # 6 slices: steady state + drain
+    (257, 256, 64, True, False, H.ACT_NONE),                        # 2 slices: prologue + drain only
+    (270, 300, 704, True, True, H.ACT_RELU | H.ACT_POST_RESIDUAL),  # split-K slabs over the TRUE K range (4 x 192 / 128)
+    (515, 300, 128, False, False, H.ACT_RELU),                      # three row tiles, ragged last
+])
+def test_gemm_x3_256_phased_slice_form(ops, M, N, K, has_bias, has_res, act):
+    """r04: the 256 x 256 phased K loop on 32-deep slices (policy 2581; four operand images per stage, three products per phase) -- same
+    accuracy contract as every split-f16 GEMM form, and the launch really is the <.., 32, 3, 2, ..> instantiation."""
+    ops.gemm_tile_policy(2581)
+    try:
+        test_gemm_x3(ops, M, N, K, has_bias, has_res, act, 256, 3300)
+        assert "256, 256, 2, 4, 2, false, 32, 3, 2" in ops.gemm_last_kernel()
+    finally:
+        ops.gemm_tile_policy(2580)
+
+
+def test_gemm_x3_256_phased_slice_form_split_output(ops):
+    """... with split-f16 output: LDS-transposed stores (two passes) and paired stores straight from the accumulators"""
+    ops.gemm_tile_policy(2581)
+    try:
+        test_gemm_x3_split_output(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
+        assert "256, 256, 2, 4, 2, false, 32, 3, 2, true" in ops.gemm_last_kernel() or "skinny" in ops.gemm_last_kernel() or "64, 128" in ops.gemm_last_kernel()
+        test_gemm_x3_split_output(ops, 300, 520, 128, H.ACT_GELU, 256, 256, 0, True)
+        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, False)
+    finally:
+        ops.gemm_tile_policy(2580)
+
+
 def test_gemm_x3_split_output_k_panel_form(ops):
     """the automatic K loop of the 128 / 64-row tiles is the 32-deep slice form (policy 3303); the K-panel form (3305) stays selectable"""
     test_gemm_x3_split_output(ops, 300, 264, 192, H.ACT_RELU, 128, 0, 64, False, kloop=3305)

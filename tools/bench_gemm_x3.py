@@ -12,7 +12,7 @@ SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512,
           (21504, 288, 256), (1296, 3072, 1024), (17424, 768, 256), (69696, 384, 128), (256, 2048, 18432), (1024, 1024, 4096)]
 # 3301 / 3302: slice forms with one block per CU (r02l: lose); 3303 / 3304: 32-deep slices in a 2- / 3-deep ring (the K-panel form's LDS footprint)
 POLICIES = [("auto", [0]), ("auto_s3", [3303]), ("t128", [128]), ("t128_s3", [128, 3303]), ("t64", [64]), ("t64_s3", [64, 3303]), ("t64_s4", [64, 3304]),
-            ("t64_slice", [64, 3301]), ("t256", [256])]
+            ("t64_slice", [64, 3301]), ("t256", [256]), ("auto_ps", [2581]), ("t256_ps", [256, 2581])]     # _ps: 256 x 256 phased loop on 32-deep slices (r04)
 
 
 def main():
@@ -39,13 +39,14 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / reps * 1e3
-                row[name] = {"us": round(us, 1), "TF_alg": round(2.0 * M * N * K / us / 1e6, 1), "describe": ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)}
+                row[name] = {"us": round(us, 1), "TF_alg": round(2.0 * M * N * K / us / 1e6, 1), "describe": ops.gemm_describe(M, N, 3 * asp.Kp, x3=True), "kernel": ops.gemm_last_kernel()}
             except Exception as ex:  # noqa
                 row[name] = {"error": str(ex)[:80]}
             finally:
                 ops.gemm_tile_policy(1282)
                 ops.gemm_tile_policy(640)
                 ops.gemm_tile_policy(3300)
+                ops.gemm_tile_policy(2580)
                 ops.gemm_tile_policy(0)
         out[f"M{M} N{N} K{K}"] = row
         print(M, N, K, {k: v.get("us") for k, v in row.items()}, flush=True)
