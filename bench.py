@@ -63,9 +63,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"])
-    ap.add_argument("--llm-cross-fp8", default=None, choices=["w1", "w2", "both", "off"],
-                    help="f16x3: which Phi GEMMs form their cross terms as e4m3 dot products (default: the model's default = none; "
-                         "the 'both' form is measured as a side line anyway)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 side-line measurement (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-seeds", type=int, default=5, help="inputs the parity leg compares with the CPU oracle (rank 0, N=1; ~12 s of CPU each)")
@@ -127,12 +124,9 @@ def main():
     # rank 0 owns the (seeded) checkpoint; the other ranks build their weight arena from placeholders of the same shapes and receive
     # rank 0's prepared weights through the broadcast -- which is thereby real, not a copy of identical data onto itself
     sd = make_state_dict(cfg, seed=0, shapes_only=rank != 0)
-    model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager,
-                  llm_cross_fp8={None: None, "off": False}.get(args.llm_cross_fp8, args.llm_cross_fp8))
+    model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
-    model_info = type("I", (), {"llm_x8": bool(getattr(model, "llm_x8", False)),
-                                "x8_gemms": [n for n, f in (("[k|v|q|fc1]", getattr(model, "llm_x8_w1", False)), ("[dense|fc2]", getattr(model, "llm_x8_w2", False))) if f]})      # (the model object itself is released before the JSON line)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"
@@ -366,15 +360,13 @@ def main():
                     tj = json.load(f).get("kernels", {})
                 traffic = tj.get(kname.split(" + ")[0], {}).get("hbm_bytes_per_launch")
             targs = [t.strip() for t in kname.split("<", 1)[1].split(">", 1)[0].split(",")] if "glds_kernel<" in kname else []
-            x3_form = int(targs[9]) if len(targs) >= 11 else 0                   # template argument X3: 1 / 2 split-f16 (3 products), 3 = x8 form
+            x3_form = int(targs[9]) if len(targs) >= 11 else 0                   # template argument X3: 1 / 2 = split-f16 K-panel / slice form (3 products)
             is_x3 = x3_form != 0
-            prods = 2 if x3_form == 3 else 3                                     # f16-product equivalents issued per algorithmic product
+            prods = 3                                                            # f16 products issued per algorithmic product
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues " +
-                             ("hi.hi on the f16 matrix cores + both cross terms as one e4m3 dot product at twice the f16 rate = 2 f16-product "
-                              "equivalents" if prods == 2 else "3 f16 MFMA products (hi.hi + lo.hi + hi.lo)") +
-                             " per algorithmic product, see `mfma_issue`") if is_x3 else None,
+                    "note": ("split-f16 kernel: `achieved` counts the ALGORITHMIC 2*M*N*K of the fp32-class product; the kernel issues "
+                             "3 f16 MFMA products (hi.hi + lo.hi + hi.lo) per algorithmic product, see `mfma_issue`") if is_x3 else None,
                     "mfma_issue": {"f16_product_equivalents": prods, "TFLOPs": round(prods * ach, 1),
                                    "frac_of_f16_peak": round(prods * ach / PEAK_BF16_TFLOPS, 4)} if is_x3 else None,
                     "launches_per_step": n / nprof, "avg_launch_us": round(ms / n * 1e3, 2),
@@ -543,8 +535,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
-                       "arithmetic": ("GEMMs in split-f16 (22-bit operands as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulate)" +
-                                      (("; Phi " + " and ".join(model_info.x8_gemms) + " GEMM: hi.hi in f16 + both cross terms as one e4m3 dot product") if getattr(model_info, "llm_x8", False) else "") +
+                       "arithmetic": ("GEMMs in split-f16 (22-bit operands as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulate)"
                                       "; fp32 norms / softmax / attention") if args.precision == "f16x3" else args.precision,
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},

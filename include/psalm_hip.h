@@ -23,6 +23,10 @@ extern "C" {
 #define PSALM_BF16 1
 
 const char* psalm_last_error(void);
+/* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
+ * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
+ * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04). */
+#define PSALM_ABI_VERSION 4
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
 
@@ -91,13 +95,9 @@ int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* W
  * psalm_split_f16: x (rows,K) f32 -> out (rows, 2*Kp) f16 = [hi | lo], Kp = ceil64(K), x*s = hi + lo with s a per-row power of two
  *   (row max in [2^13,2^14)); inv_scale[row] = 1/s.   K % 8 == 0, 16-byte aligned rows.
  * psalm_gemm_x3: C = act(A.W^T + bias) + residual, C / residual fp32, from split operands A2 (M,2Kp) / W2 (N,2Kp) + their scales:
- *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo, fp32 accumulate, scales in the epilogue; tiles / split-K as psalm_gemm.
- * "x8" operand form (Phi decoder GEMMs, modeling_phi.py:189-260; `form` / `x8` / `split_form` arguments below): the second half-word of an
- *   element holds, instead of lo as f16, the pair of OCP e4m3 bytes (e(hi 2^-6), e(lo 2^6)) -- A operands, form 1 -- or (e(lo 2^6),
- *   e(hi 2^-6)) -- W operands, form 2; Kp = ceil128(K).  With x8 != 0 the GEMM forms hi.hi on the f16 matrix cores and BOTH cross terms as
- *   one e4m3 dot product over the 2*Kp bytes of the second halves (block-scaled 32x32x64 instruction, unit scales, twice the f16 rate): 2
- *   instead of 3 f16-product equivalents, result ~2^-16 relative instead of 2^-21 (where that suffices: tools/exp_fp8cross.py). */
-int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, int form, void* stream);
+ *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo (or, slice by slice, the same three products), fp32 accumulate, scales in
+ *   the epilogue; tiles / split-K as psalm_gemm. */
+int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream);
 /* im2col (K order ky,kx,c; as psalm_im2col_nhwc) emitted directly in split form -- the convolution-as-GEMM A operand of the f16x3 mode
  * (F.conv2d at multimodal_projector/builder.py:85-111 and msdeformattn.py:248-254) without the fp32 im2col matrix in HBM. */
 int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
@@ -105,14 +105,14 @@ int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, i
  * msdeformattn.py:57-66): y = LN(x) fp32 (optional) + split(y) (optional) + split(y + add[row % add_rows]) (optional), each split as
  * psalm_split_f16 writes it (rows of 2*ceil64(C) f16 + inv_scale).  fp32 in, C % 8 == 0, C <= 2048. */
 int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C, float eps,
-                          void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, int form, void* stream);
+                          void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2, void* stream);
 /* f16x3 forms of the two Swin LayerNorm-fused data-movement steps (swin_trans.py:206-227 norm1 + pad + shift + window partition;
  * :235-251 window reverse + un-shift + residual, then norm2): the normalised rows leave as the split-f16 A operand of the GEMM they feed. */
 int psalm_swin_window_gather_split(const float* x, void* out, float* inv_out, const float* gamma, const float* beta, int B, int H, int W, int C,
                                    int ws, int shift, float eps, void* stream);
 int psalm_swin_window_merge_ln_split(const float* win, const float* shortcut, float* out_x, void* h_split, float* h_inv, const float* gamma,
                                      const float* beta, int B, int H, int W, int C, int ws, int shift, float eps, void* stream);
-int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                   const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act, int act_col_start,
                   void* workspace, long workspace_bytes, void* stream);
 /* psalm_gemm_x3 whose output columns >= split_col_start leave the kernel already in split form -- the A operand of the NEXT split-f16 GEMM
@@ -124,7 +124,7 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
  * bound for values ANOTHER kernel writes into the same rows, see psalm_causal_attention_f32_split);  bound_r * scale in [2^12, 2^13);
  * 1/scale -> split_inv[r].  Columns < split_col_start go to C (fp32) as in psalm_gemm_x3.  No residual, no split-K; N and the column
  * arguments are multiples of 8.  Columns of split_out this call does not write (K padding) are the caller's to zero.
- * split_form: 0 f16 lo / 1 e4m3 pairs (x8 A operand), + 4 = PAIRED stores: the caller has permuted the W rows (with their w_scale and
+ * paired != 0 = PAIRED stores: the caller has permuted the W rows (with their w_scale and
  * bias entries) >= split_col_start inside every group of 64 -- physical row 64 g + 32 b + n holds logical row 64 g + 2 n + b -- so that a
  * lane of the accumulator layout owns two ADJACENT output columns and the operand leaves in 4-byte stores of whole 128-byte row segments
  * straight from the registers (no LDS transpose).  Output identical bit for bit.  Needs split_col_start % 256 == 0,
@@ -133,13 +133,13 @@ int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2
  * fp32 rows ln_out): the residual GEMM + the following block's input LayerNorm of a pre-norm layer (Phi [dense | fc2] + residual, then the
  * next input_layernorm, modeling_phi.py:263-300).  With split-K the partial-sum reduce, epilogue, LayerNorm and split are ONE row pass.
  * N % 64 == 0, N <= 2048; split_out rows of 2*N f16 as psalm_split_f16 writes them (exact row-maximum scale), split_inv (M). */
-int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                            const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, const float* ln_gamma,
-                           const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out, float* split_inv, int split_form,
+                           const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out, float* split_inv,
                            void* workspace, long workspace_bytes, void* stream);
-int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                         const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out, long ld_split,
-                        int split_kp, int split_col_off, int split_col_start, int split_form, float* split_inv, const float* bound_par,
+                        int split_kp, int split_col_off, int split_col_start, int paired, float* split_inv, const float* bound_par,
                         int global_rows, void* workspace, long workspace_bytes, void* stream);
 
 /* Eval-time image pre-processing on the device: replaces detectron2 `T.ResizeShortestEdge` (= Pillow
@@ -189,7 +189,7 @@ int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, 
  * gets hi at columns split_col_off + head*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the row scales a preceding
  * psalm_gemm_x3_split wrote for the same rows (its bound has to cover |v|: the output is a convex combination of v rows). */
 int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split, int split_kp,
-                                     int split_col_off, int split_form, const float* split_inv, const float* cos_table, const float* sin_table,
+                                     int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
                                      const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
                                      void* stream);
 

@@ -1,5 +1,6 @@
 // Error reporting + library identity for the C ABI (include/psalm_hip.h).
 #include "common.h"
+#include "psalm_hip.h"      // PSALM_ABI_VERSION (and every declaration checked against its definition in this translation unit)
 
 #include <cstring>
 
@@ -10,7 +11,7 @@ extern "C" void psalm_set_error(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* psalm_last_error() { return g_err; }
-extern "C" int psalm_abi_version() { return 3; }   // 3: operand-form arguments of the split-f16 entry points (x8)
+extern "C" int psalm_abi_version() { return PSALM_ABI_VERSION; }
 // "hip-gfx950" for the product library; the host-emulation build used by the CPU tests reports "emu".
 extern "C" const char* psalm_backend() {
 #ifdef PSALM_EMU_BUILD

@@ -637,7 +637,7 @@ template <bool SO>
 __global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(2)
 causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr, const unsigned char* __restrict__ Mk,
                                    const float* __restrict__ base, long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
-                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair, int so_form) {
+                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
@@ -764,8 +764,8 @@ causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     unsigned h0, h1, l0, l1;
-                    psalm_split_words(acc[2 * k] * sc, so_form, h0, l0);
-                    psalm_split_words(acc[2 * k + 1] * sc, so_form, h1, l1);
+                    psalm_split_words(acc[2 * k] * sc, h0, l0);
+                    psalm_split_words(acc[2 * k + 1] * sc, h1, l1);
                     hw[k] = h0 | (h1 << 16);
                     lw[k] = l0 | (l1 << 16);
                 }
@@ -790,7 +790,7 @@ extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
 static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k_off, int v_off, void* out, long ldo, int o_off,
                                      const float* cos_table, const float* sin_table, const unsigned char* key_mask, void* workspace,
                                      int B, int L, int heads, int head_dim, int rot, void* stream, const float* so_inv, int so_kp,
-                                     const char* name, int so_form = 0) {
+                                     const char* name) {
     PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_f32: head_dim 64, rotary dim 32 (Phi-1.5)");
     PSALM_CHECK_ARG(ld % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && (uintptr_t)qkv % 16 == 0 &&
                         (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0 &&
@@ -805,16 +805,15 @@ static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phi_rope_prep_f32_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, cos_table, sin_table, key_mask,
                        Qr, Kr, Mk, L, Lp, heads, scale);
-    static int pair = -1;                                                 // PSALM_ATTN_PAIR=0: one query tile per block (tuning / A-B)
-    if (pair < 0) { const char* e = getenv("PSALM_ATTN_PAIR"); pair = e ? (atoi(e) != 0) : 1; }
+    const int pair = 1;                                                   // balanced pairs of query tiles per block (r02n; the one-tile form stays in the kernel)
     const int nqt = Lp / 32;
     const dim3 grid(pair ? (nqt + 1) / 2 : nqt, heads, B);
     if (so_inv)
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair, so_form);
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
     else
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair, 0);
+                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
     PSALM_LAUNCH_END(name);
 }
 extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
@@ -827,14 +826,13 @@ extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, 
 // stride ld_split f16) receives hi at columns split_col_off + h*64 + d and lo split_kp columns further, scaled by 1 / split_inv[r] -- the
 // row scales psalm_gemm_x3_split wrote for the same rows (its bound covers the attention output: a convex combination of v rows).
 extern "C" int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split,
-                                                int split_kp, int split_col_off, int split_form, const float* split_inv, const float* cos_table,
+                                                int split_kp, int split_col_off, const float* split_inv, const float* cos_table,
                                                 const float* sin_table, const unsigned char* key_mask, void* workspace, int B, int L,
                                                 int heads, int head_dim, int rot, void* stream) {
-    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_causal_attention_f32_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand)");
     PSALM_CHECK_ARG(split_out && split_inv && ld_split >= 2L * split_kp && split_col_off + heads * 64 <= split_kp,
                     "psalm_causal_attention_f32_split: split buffer rows of >= 2*split_kp f16 and the row scales");
     return causal_attention_f32_impl(qkv, ld, q_off, k_off, v_off, split_out, ld_split, split_col_off, cos_table, sin_table, key_mask, workspace,
-                                     B, L, heads, head_dim, rot, stream, split_inv, split_kp, "psalm_causal_attention_f32_split", split_form);
+                                     B, L, heads, head_dim, rot, stream, split_inv, split_kp, "psalm_causal_attention_f32_split");
 }
 
 extern "C" int psalm_causal_attention(const void* qkv, int dtype, long ld, int q_off, int k_off, int v_off, void* out, long ldo,

@@ -31,33 +31,6 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); 
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-// OCP fp8 e4m3fn (gfx950's FP8 format; NOT MI300X's fnuz): 1-4-3, bias 7, max 448, no inf, NaN = 0x7f.
-// Software round-to-nearest-even with saturation, bit-identical on the device and in the CPU test build.
-__device__ __forceinline__ unsigned char f32_to_e4m3(float f) {
-    const unsigned u = __builtin_bit_cast(unsigned, f);
-    const unsigned sign = (u >> 24) & 0x80u;
-    const unsigned au = u & 0x7fffffffu;
-    const float a = __builtin_bit_cast(float, au);
-    if (au > 0x7f800000u) return (unsigned char)(sign | 0x7f);                 // NaN
-    if (a < 0.015625f) {                                                          // below the smallest normal 2^-6: step 2^-9
-        const float q = __builtin_rintf(a * 512.0f);                              // 0..8 (8 == code of 2^-6)
-        return (unsigned char)(sign | (unsigned)q);
-    }
-    const unsigned r = au + 0x7ffffu + ((au >> 20) & 1u);                         // RNE on the 20 dropped mantissa bits
-    const int e = (int)(r >> 23) - 127 + 7;
-    const unsigned m = (r >> 20) & 7u;
-    if (e > 15 || (e == 15 && m == 7)) return (unsigned char)(sign | 0x7e);       // saturate to 448
-    return (unsigned char)(sign | ((unsigned)e << 3) | m);
-}
-__device__ __forceinline__ float e4m3_to_f32(unsigned char v) {
-    const unsigned e = (v >> 3) & 15u, m = v & 7u;
-    float a;
-    if (e == 0) a = (float)m * 0.001953125f;                                      // subnormal: m * 2^-9
-    else if (e == 15 && m == 7) a = __builtin_bit_cast(float, 0x7fc00000u);       // NaN
-    else a = __builtin_bit_cast(float, ((e + 120u) << 23) | (m << 20));
-    return (v & 0x80u) ? -a : a;
-}
-
 // 8 consecutive elements per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses; p must be 16-byte aligned.
 struct alignas(16) psalm_u32x4 { unsigned x, y, z, w; };
 struct alignas(8) psalm_u32x2 { unsigned x, y; };
@@ -130,32 +103,13 @@ __device__ __forceinline__ float psalm_rcp(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float psalm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  /* v_exp_f32 (no denormal range fix-up: callers add 1) */
 #endif
 
-// ---- split-f16 operand rows, second half-word of an element.  An operand row is [hi (Kp) | second (Kp)] 16-bit words with x s = hi + lo
-// (s: the row's power-of-two scale, |hi| < 2^14, |lo| <= ulp(hi) / 2 <= 4).  The second word is
-//   form 0 ("x3"): lo as f16 -- the GEMM forms hi.hi + lo.hi + hi.lo as three f16 products (22-bit operands);
-//   form 1 / 2 ("x8", A / W operand): the pair of OCP e4m3 bytes (e(hi 2^-6), e(lo 2^6)) for an A operand, (e(lo 2^6), e(hi 2^-6)) for
-//     a W operand: the two CROSS terms lo.hi + hi.lo then are ONE fp8 dot product over the 2 Kp bytes of the second halves (byte i of A
-//     meets byte i of W; the fixed exponent offsets cancel in the products), on the block-scaled fp8 matrix instruction at twice the f16
-//     rate with unit scales -- 2 instead of 3 f16-product equivalents per GEMM.  The cross terms are 2^-11 of the main term, so their
-//     3-bit mantissas leave the result at ~2^-16 relative (tools/exp_fp8cross.py, profiles/r03d_*: on the Phi decoder indistinguishable
-//     from the three-product form over 10 seeds; NOT on the Swin / pixel-decoder GEMMs, which keep form 0).
-#ifdef PSALM_EMU_BUILD
-__device__ __forceinline__ unsigned psalm_pk_e4m3(float a, float b) { return (unsigned)f32_to_e4m3(a) | ((unsigned)f32_to_e4m3(b) << 8); }
-#else
-__device__ __forceinline__ unsigned psalm_pk_e4m3(float a, float b) {                                // v_cvt_pk_fp8_f32 (OCP e4m3 on gfx950, RNE)
-    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
-}
-#endif
-// y = x s (the scaled element): hi word and second word (form as above)
-__device__ __forceinline__ void psalm_split_words(float y, int form, unsigned& hw, unsigned& sw) {
+// ---- split-f16 operand rows.  An operand row is [hi (Kp) | lo (Kp)] f16 words with x s = hi + lo (s: the row's power-of-two scale,
+// |hi| < 2^14, |lo| <= ulp(hi) / 2 <= 4): the GEMM forms hi.hi + lo.hi + hi.lo as three f16 products (22-bit operands).
+// y = x s (the scaled element) -> hi word and lo word
+__device__ __forceinline__ void psalm_split_words(float y, unsigned& hw, unsigned& sw) {
     const _Float16 h = (_Float16)y;
-    const float lo = y - (float)h;
     hw = (unsigned)__builtin_bit_cast(unsigned short, h);
-    if (form == 0) sw = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo);
-    else {
-        const float a = (float)h * 0.015625f, b = lo * 64.0f;
-        sw = form == 1 ? psalm_pk_e4m3(a, b) : psalm_pk_e4m3(b, a);
-    }
+    sw = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(y - (float)h));
 }
 
 // Bounds-checked 4-byte accesses through a buffer descriptor (buffer_store_dword / buffer_load_dword ... offen): an access at a byte offset

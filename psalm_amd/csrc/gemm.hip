@@ -317,9 +317,8 @@ struct GemmFastArgs {
     unsigned short* so = nullptr;
     long ldso = 0;
     int so_kp = 0, so_col_off = 0, so_col_start = 0, so_global = 0;
-    int so_form = 0;    // second half-word of the emitted operand: 0 f16 lo, 1 e4m3 pair of an A operand (psalm_split_words)
     // so_paired: the W rows (and bias / w_scale entries) >= so_col_start were PERMUTED by the caller inside every group of 64 -- physical row
-    // 64 g + 32 b + n holds logical row 64 g + 2 n + b (psalm_gemm_x3_split, split_form bit 2) -- so that the two 32-column MFMA tiles of a
+    // 64 g + 32 b + n holds logical row 64 g + 2 n + b (psalm_gemm_x3_split, `paired`) -- so that the two 32-column MFMA tiles of a
     // wave hold ADJACENT logical columns in the same lane: the 2-byte outputs leave as 4-byte stores of 128-byte row segments straight from
     // the accumulators (the fp32 tiles' store pattern, r03b: 5.6 TB/s) instead of through the LDS transpose.
     int so_paired = 0;
@@ -373,8 +372,8 @@ template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false
           bool SO = false, bool PAIR = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
-    static_assert(!SO || X3 == 1 || X3 == 3 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel / x8 form, or 32-deep slices in two stages");
-    static_assert(X3 != 3 || (PH8 == 3 && BK == 64), "x8 form: the phased 256 x 256 K loop");
+    static_assert(!SO || X3 == 1 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel form, or 32-deep slices in two stages");
+    static_assert(X3 >= 0 && X3 <= 2, "X3: 0 bf16 operands, 1 split-f16 K-panel form, 2 split-f16 slice form");
     static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && (BK == 64 || (BK == 32 && X3 == 2 && PH8 == 3)) && !CONV), "PH8 configuration");
     static_assert(!X3 || !CONV, "split-f16 variants: plain GEMM");
     static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
@@ -432,7 +431,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             asrc[i] = A + (long)b * fa.cH * fa.cW * fa.cC + kc * 8;           // + ((y*W + x)*C + c0) per K tile
         } else {
             ay[i] = ax[i] = 0;
-            asrc[i] = A + (long)m * g.lda + ((X3 == 1 || X3 == 3) ? 0 : kbeg) + kc * 8;
+            asrc[i] = A + (long)m * g.lda + (X3 == 1 ? 0 : kbeg) + kc * 8;
         }
     }
     // 1 KiB copy i of this wave covers W-tile rows 8 * b_chunk(i) ...  PH8: copies {2h, 2h+1} of every wave together cover the
@@ -446,17 +445,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int i = 0; i < B_CH; ++i) {
         const int r = b_chunk(i) * RPC + lrow;
         const int kc = slot ^ ((r >> SWS) & (SLOTS - 1));
-        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + ((X3 == 1 || X3 == 3) ? 0 : kbeg) + kc * 8;
+        bsrc[i] = W + (long)min(bn + r, g.N - 1) * g.ldw + (X3 == 1 ? 0 : kbeg) + kc * 8;
     }
     // operand column of the K tile at offset koff of this block's K range (identity except for the split-f16 variant)
     auto x3_acol = [&](int koff) -> int {
         if constexpr (X3 == 1) { const int k = kbeg + koff; return k < 2 * fa.x3_kp ? k : k - 2 * fa.x3_kp; }
-        else if constexpr (X3 == 3) return kbeg + koff;              // x8 form: the row [hi | e4m3 pairs] is walked once, left to right
         else return koff;
     };
     auto x3_wcol = [&](int koff) -> int {
         if constexpr (X3 == 1) { const int k = kbeg + koff; return k < fa.x3_kp ? k : k - fa.x3_kp; }
-        else if constexpr (X3 == 3) return kbeg + koff;
         else return koff;
     };
     auto mma16 = [&](const bf16x8& a_, const bf16x8& b_, const f32x16& c_) -> f32x16 {
@@ -629,32 +626,19 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         //   tile t:  P1 refills B0 of the OTHER buffer with tile t+1 (last read: P4 of tile t-1);  P2 / P3 / P4 refill A0 / B1 / A1
         //   of THIS buffer with tile t+2 (last read: P1 / P2 / P3 of tile t).  Copies never drain inside the loop.
         bf16x8 af[2][BK / 16], bq[BK / 16];
-        // x8 form (X3 == 3): the tiles of the second half of the K range hold e4m3 bytes -- same 128-byte rows, copies and swizzle; a
-        // matrix instruction (32x32x64, block-scaled form with unit scales) contracts 64 bytes, of which a lane supplies 32 consecutive
-        // ones: fragment register kk of an fp8 tile is 16-byte chunk 4 (kk >> 1) + 2 hi + (kk & 1) instead of 2 kk + hi, and registers
-        // (2 q2, 2 q2 + 1) together are the operand of instruction q2.  F8 = std::true_type / false_type selects the tile kind.
-        typedef int v8i32 __attribute__((ext_vector_type(8)));
-        auto chunk_of = [&](auto F8, int kk) -> int {
-            if constexpr (decltype(F8)::value) return 4 * (kk >> 1) + 2 * hi + (kk & 1);
-            else return 2 * kk + hi;
-        };
-        auto cat8 = [&](const bf16x8& lo_, const bf16x8& hi_) -> v8i32 {
-            const u32x4_s a_ = __builtin_bit_cast(u32x4_s, lo_), b_ = __builtin_bit_cast(u32x4_s, hi_);
-            return v8i32{(int)a_.x, (int)a_.y, (int)a_.z, (int)a_.w, (int)b_.x, (int)b_.y, (int)b_.z, (int)b_.w};
-        };
-        auto read_a = [&](auto F8, const bf16_t* As_, int q) {
+        auto read_a = [&](const bf16_t* As_, int q) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                const int co = (chunk_of(F8, kk) ^ fsw) * 8;
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     af[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[(a_row0 + 32 * (2 * q + i)) * BK + co]));
             }
         };
-        auto read_b = [&](auto F8, const bf16_t* Bs_, int j) {
+        auto read_b = [&](const bf16_t* Bs_, int j) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                const int co = (chunk_of(F8, kk) ^ fsw) * 8;
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
                 bq[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs_[(b_row0 + 32 * j) * BK + co]));
             }
         };
@@ -674,19 +658,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // PH8 == 2: the phase's two copies are issued INSIDE the MFMA segment (after the 2nd and the 6th MFMA: the matrix pipe is
         // busy with the MFMA just issued while the copy is accepted), not in the read segment -- r01 PMC: the copies' issue stalls
         // (~80 cycles each behind the other waves' copies) made the read segment ~1.8x the MFMA segment it runs beside.
-        auto mma = [&](auto F8, int q, int j, auto&& copy) {
-            if constexpr (decltype(F8)::value) {
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[2 * q + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(af[i][2 * q2], af[i][2 * q2 + 1]), cat8(bq[2 * q2], bq[2 * q2 + 1]),
-                                                                                            acc[2 * q + i][j], 0, 0, 0, 127, 0, 127);
-                    __builtin_amdgcn_sched_barrier(0);
-                    copy(q2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
+        auto mma = [&](int q, int j, auto&& copy) {
+            {
 #pragma unroll
                 for (int kk = 0; kk < BK / 16; ++kk) {
 #pragma unroll
@@ -710,35 +683,35 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #define PH8_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); PH8_BAR(); \
                               __builtin_amdgcn_sched_barrier(0); } while (0)
         // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
-        auto tile_phases = [&](auto F8, int t, int mode) {
+        auto tile_phases = [&](int t, int mode) {
             const int cur = t & 1;
             const bf16_t* As_ = smem[cur];
             const bf16_t* Bs_ = smem[cur] + BM * BK;
             constexpr bool early = PH8 == 1;                     // copies in the read segment (1) or inside the MFMA segment (2)
-            read_b(F8, Bs_, 0);                                  // P1
-            read_a(F8, As_, 0);
+            read_b(Bs_, 0);                                  // P1
+            read_a(As_, 0);
             if (early && mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0);
             PH8_ENTER_MFMA();
-            mma(F8, 0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
+            mma(0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
             PH8_LEAVE_MFMA();
-            read_b(F8, Bs_, 1);                                  // P2
+            read_b(Bs_, 1);                                  // P2
             if (early && mode == 0) stage_a(cur, (t + 2) * BK, 0);
             PH8_ENTER_MFMA();
-            mma(F8, 0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
+            mma(0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
             PH8_LEAVE_MFMA();
-            read_a(F8, As_, 1);                                  // P3
+            read_a(As_, 1);                                  // P3
             if (early && mode == 0) stage_b(cur, (t + 2) * BK, 1);
             PH8_ENTER_MFMA();
-            mma(F8, 1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
+            mma(1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
             PH8_LEAVE_MFMA();
-            read_b(F8, Bs_, 0);                                  // P4
+            read_b(Bs_, 0);                                  // P4
             if (early && mode == 0) stage_a(cur, (t + 2) * BK, 1);
             // everything but the most recent halves has landed = all of tile t+1  (PH8 == 1: 3 halves issued since tile t+1's B0;
             // PH8 == 2: 2 -- this phase's copies are issued after the wait)
             if (mode == 0) { if constexpr (early) wait_vmcnt_le<6>(); else wait_vmcnt_le<4>(); }
             else if (mode == 1) wait_vmcnt_le<0>();
             PH8_ENTER_MFMA();
-            mma(F8, 1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
+            mma(1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
             PH8_LEAVE_MFMA();
         };
         stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
@@ -749,22 +722,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         PSALM_TL(2);
         if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
         int t = 0;
-        constexpr std::false_type F16T{};
-        constexpr std::true_type FP8T{};
-        if constexpr (X3 == 3) {
-            const int tsw = min(nk, max(0, (fa.x3_kp - kbeg) / BK));   // this block's first e4m3 tile (its K range may lie on either side)
 #pragma unroll 1
-            for (; t + 2 < nk && t < tsw; ++t) tile_phases(F16T, t, 0);
-#pragma unroll 1
-            for (; t + 2 < nk; ++t) tile_phases(FP8T, t, 0);
-            if (t < tsw) tile_phases(F16T, t, 1); else tile_phases(FP8T, t, 1);
-            if (t + 1 < tsw) tile_phases(F16T, t + 1, 2); else tile_phases(FP8T, t + 1, 2);
-        } else {
-#pragma unroll 1
-            for (; t + 2 < nk; ++t) tile_phases(F16T, t, 0);
-            tile_phases(F16T, t, 1);
-            tile_phases(F16T, t + 1, 2);
-        }
+        for (; t + 2 < nk; ++t) tile_phases(t, 0);
+        tile_phases(t, 1);
+        tile_phases(t + 1, 2);
         if (wm == 0) PSALM_RAW_BARRIER();                        // pairs with wave row 1's last barrier
 #undef PH8_ENTER_MFMA
 #undef PH8_LEAVE_MFMA
@@ -969,13 +930,12 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const unsigned cbyte = lc + 1 < g.N ? (unsigned)(fa.so_col_off + (lc - fa.so_col_start)) * 2u : PSALM_BUF_OOB;
                 const unsigned second = (unsigned)fa.so_kp * 2u;
                 const bool writes_inv = bn == fa.so_col_start && wn == 0 && n32 == 0;
-                // The element code is instantiated for the launch's (activation, operand form) as compile-time constants and selected ONCE,
+                // The element code is instantiated for the launch's activation as a compile-time constant and selected ONCE,
                 // outside the loops: with run-time codes every element carried the activation switch, the per-lane act_col_start branch
                 // and the form branch (r03k: 33 us of epilogue on the Phi fc1 tiles whichever way the words were stored -- 4 scalar
                 // branches and an exec-mask region per element, no overlap between the 128 dependent chains of a lane).
-                auto body = [&](auto AC, auto FC) {
-                    constexpr int A = decltype(AC)::value, F = decltype(FC)::value;
-                    const int form = F < 0 ? fa.so_form : F;
+                auto body = [&](auto AC) {
+                    constexpr int A = decltype(AC)::value;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int row0 = bm + wm * (BM / WM) + i * 32 + 4 * hi;
@@ -997,25 +957,18 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                             x0 = actc[0] ? y0 : x0;
                             x1 = actc[1] ? y1 : x1;
                             unsigned h0, s0, h1, s1;
-                            psalm_split_words(x0 * sc[r], form, h0, s0);
-                            psalm_split_words(x1 * sc[r], form, h1, s1);
+                            psalm_split_words(x0 * sc[r], h0, s0);
+                            psalm_split_words(x1 * sc[r], h1, s1);
                             const unsigned off = row < g.M && cbyte != PSALM_BUF_OOB ? (unsigned)row * (unsigned)(fa.ldso * 2) + cbyte : PSALM_BUF_OOB;
                             psalm_buf_store_u32(h0 | (h1 << 16), srs, off);
                             psalm_buf_store_u32(s0 | (s1 << 16), srs, off == PSALM_BUF_OOB ? off : off + second);
                         }
                     }
                 };
-                if constexpr (X3 == 3) {
-                    if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
-                    else if (act == ACT_GELU_NEW && fa.so_form == 0) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
-                    else body(psalm_ic<-1>{}, psalm_ic<-1>{});
-                } else {
-                    if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});
-                    else if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{}, psalm_ic<0>{});
-                    else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{}, psalm_ic<0>{});
-                    else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
-                    else body(psalm_ic<-1>{}, psalm_ic<0>{});
-                }
+                if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{});
+                else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{});
+                else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{});
+                else body(psalm_ic<-1>{});
                 PSALM_TL(4);
                 PSALM_TL_DRAIN();
                 PSALM_TL(5);
@@ -1027,10 +980,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             auto pass = [&](auto EC) {                                // (the pass index is a compile-time constant: acc[e * TMP + ii] is a register choice)
                 constexpr int e = decltype(EC)::value;
                 if (e > 0) __syncthreads();                           // previous pass read out
-                // (element code instantiated for compile-time (activation, operand form) and selected once per pass: see the paired form above)
-                auto body = [&](auto AC, auto FC) {
-                    constexpr int A = decltype(AC)::value, F = decltype(FC)::value;
-                    const int form = F < 0 ? fa.so_form : F;
+                // (element code instantiated for a compile-time activation and selected once per pass: see the paired form above)
+                auto body = [&](auto AC) {
+                    constexpr int A = decltype(AC)::value;
 #pragma unroll
                     for (int ii = 0; ii < TMP; ++ii) {
                         const int i = e * TMP + ii;
@@ -1051,23 +1003,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                                 const float y = apply_act_t<A>(x, act);
                                 x = actc[j] ? y : x;
                                 unsigned hw_, sw_;
-                                psalm_split_words(x * sc[r], form, hw_, sw_);
+                                psalm_split_words(x * sc[r], hw_, sw_);
                                 const unsigned word = soc[j] ? (hw_ | (sw_ << 16)) : __builtin_bit_cast(unsigned, x);
                                 Cw[(prow0 + (r & 3) + 8 * (r >> 2)) * BN + wn * (BN / WN) + j * 32 + n32] = word;
                             }
                     }
                 };
-                if constexpr (X3 == 3) {
-                    if (act == ACT_GELU_NEW && fa.so_form == 1) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<1>{});
-                    else if (act == ACT_GELU_NEW && fa.so_form == 0) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
-                    else body(psalm_ic<-1>{}, psalm_ic<-1>{});
-                } else {
-                    if (fa.so_form != 0) body(psalm_ic<-1>{}, psalm_ic<-1>{});
-                    else if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{}, psalm_ic<0>{});
-                    else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{}, psalm_ic<0>{});
-                    else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{}, psalm_ic<0>{});
-                    else body(psalm_ic<-1>{}, psalm_ic<0>{});
-                }
+                if (act == ACT_GELU) body(psalm_ic<ACT_GELU>{});
+                else if (act == ACT_RELU) body(psalm_ic<ACT_RELU>{});
+                else if (act == ACT_GELU_NEW) body(psalm_ic<ACT_GELU_NEW>{});
+                else body(psalm_ic<-1>{});
                 __syncthreads();
                 if (col0 >= g.N) return;
 #pragma unroll
@@ -1397,7 +1342,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
                                                                const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
                                                                float ln_eps, TL* __restrict__ ln_out, long ld_ln,
                                                                unsigned short* __restrict__ sp_out = nullptr, float* __restrict__ sp_inv = nullptr,
-                                                               int sp_kp = 0, int sp_form = 0) {
+                                                               int sp_kp = 0) {
     __shared__ float red[12];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int act = g.act & 15;
@@ -1511,8 +1456,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_ln_kernel(GemmArgs g, const
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     unsigned h0, h1, l0, l1;
-                    psalm_split_words(x4[2 * k], sp_form, h0, l0);
-                    psalm_split_words(x4[2 * k + 1], sp_form, h1, l1);
+                    psalm_split_words(x4[2 * k], h0, l0);
+                    psalm_split_words(x4[2 * k + 1], h1, l1);
                     hw[k] = h0 | (h1 << 16);
                     lw[k] = l0 | (l1 << 16);
                 }
@@ -1754,30 +1699,10 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     }
 }
 
-// x8 form of the split-f16 GEMM (K = 2 Kp): always 256 x 256 tiles on the phased kernel; split-K slices to fill the 256 CUs.
-static int x8_splits(int M, int N, int K, bool have_ws, long workspace_bytes) {
-    const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    int splits = 1;
-    if (tiles256 < 160 && have_ws && K >= 1024) {
-        splits = (int)((256 + tiles256 - 1) / tiles256);
-        if (splits > K / 512) splits = K / 512;                          // >= 8 K-steps per slice
-        if (splits > 32) splits = 32;
-        const long per = (long)M * N * (long)sizeof(float);
-        if ((long)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
-        if (splits < 2) splits = 1;
-    }
-    if (splits > 1) { const int kps = cdiv(cdiv(K, 64), splits) * 64; splits = cdiv(K, kps); }
-    return splits;
-}
-
 // Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS, 2 skinny), out[1] = BM,
 // out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
 extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
     const bool x3 = a_dtype == 2 && w_dtype == 2;                              // dtype code 2: split-f16 operands (psalm_gemm_x3, K = 3 Kp)
-    if (a_dtype == 3 && w_dtype == 3) {                                        // dtype code 3: their x8 form (K = 2 Kp)
-        out4[0] = 1; out4[1] = 256; out4[2] = 256; out4[3] = x8_splits(M, N, K, workspace_bytes > 0, workspace_bytes);
-        return 0;
-    }
     if (x3 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;
     } else if (x3) {
@@ -1798,23 +1723,22 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
 }
 
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
-struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; int split_form = 0; };
+struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; };
 extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
                                      float eps, void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2,
-                                     int form, void* stream);
+                                     void* stream);
 extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream);
 
 static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void* workspace, long workspace_bytes, hipStream_t s,
-                       const LnEpilogue* ln = nullptr, bool x3 = false, bool x8 = false) {
+                       const LnEpilogue* ln = nullptr, bool x3 = false) {
     const int M = g.M, N = g.N, K = g.K;
     int BM, BN, splits;
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
-    if (x8) { BM = BN = 256; splits = x8_splits(M, N, K, workspace != nullptr, workspace_bytes); }   // x8 form: the phased 256 x 256 kernel only
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-    int slice = !x3 || x8 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
-    if (x3 && !x8 && BM == 256 && g_ph8 && g_ph8_slice) {        // 256 x 256: the phased loop on 32-deep slices (form 6) when every K slice of the grid has >= 2 of them
+    int slice = !x3 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
+    if (x3 && BM == 256 && g_ph8 && g_ph8_slice) {        // 256 x 256: the phased loop on 32-deep slices (form 6) when every K slice of the grid has >= 2 of them
         const int kp_ = fa.x3_kp, kps_ = splits > 1 ? cdiv(cdiv(kp_, 64), splits) * 64 : kp_, sp_ = cdiv(kp_, kps_);
         if (kps_ >= 64 && kp_ - (sp_ - 1) * kps_ >= 64) slice = 6;
     }
@@ -1837,8 +1761,8 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
                          (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
     const dim3 grid((unsigned)tiles, splits);
     if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
-        const bool ph_ = x3 && !x8 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
-        if (!(x8 || slice == 3 || slice == 6 || ph_) || fa.so_col_start % BN != 0) {
+        const bool ph_ = x3 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
+        if (!(slice == 3 || slice == 6 || ph_) || fa.so_col_start % BN != 0) {
             psalm_set_error("psalm_gemm_x3_split: paired output is not available under this tile policy / for this column start");
             return -1;
         }
@@ -1870,11 +1794,6 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 2, false);
         else if (slice == 2) GO(256, "float", float, 64, 128, 2, 2, 4, false, 32, 0, 2, false);
         else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);
-    } else if (x8) {                                              // split-f16 operands with e4m3 cross-term halves (K range 2 Kp)
-        if (fa.k_per_split < 128 || (K - (splits - 1) * fa.k_per_split) < 128) { psalm_set_error("psalm_gemm_x3 (x8): K range too short"); return -1; }
-        if (fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true, true);
-        else if (fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, true);
-        else GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 3, false);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
         const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
         const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
@@ -1923,7 +1842,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (splits > 1) {
         if (ln && ln->split_out) {                                // ... + the normalised rows in split-f16 form (psalm_gemm_x3_ln_split)
 #define RLNS_LAUNCH(NV_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<float, NV_, true>), dim3(M), dim3(256), 0, s, g, (const float*)workspace, splits, \
-                                            ln->gamma, ln->beta, ln->eps, (float*)ln->out, ln->ld, (unsigned short*)ln->split_out, ln->split_inv, N, ln->split_form)
+                                            ln->gamma, ln->beta, ln->eps, (float*)ln->out, ln->ld, (unsigned short*)ln->split_out, ln->split_inv, N)
             const int nv = N <= 1024 ? 1 : (N <= 2048 ? 2 : (N <= 4096 ? 4 : 8));
             if (nv == 1) RLNS_LAUNCH(1); else if (nv == 2) RLNS_LAUNCH(2); else if (nv == 4) RLNS_LAUNCH(4); else RLNS_LAUNCH(8);
 #undef RLNS_LAUNCH
@@ -1951,7 +1870,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         if (e != hipSuccess) { psalm_set_error("psalm_gemm_ln: GEMM launch failed"); return (int)e; }
         if (ln->split_out)
             return psalm_layernorm_split((const float*)g.C, g.ldc, (float*)ln->out, ln->ld, ln->gamma, ln->beta, M, N, ln->eps, ln->split_out,
-                                         ln->split_inv, nullptr, 0, nullptr, nullptr, ln->split_form, (void*)s);
+                                         ln->split_inv, nullptr, 0, nullptr, nullptr, (void*)s);
         return psalm_layernorm(g.C, PSALM_F32, g.ldc, ln->out, ln->dtype, ln->ld, nullptr, 0, ln->gamma, ln->beta, M, N, ln->eps, (void*)s);
     }
     PSALM_LAUNCH_END("psalm_gemm");
@@ -2117,7 +2036,7 @@ extern "C" int psalm_gemm_ln(const void* A, int a_dtype, long lda, const void* W
 // with one wavefront per row a K = 128 row (Swin stage 0, 65536 rows) kept 16 of 64 lanes busy.
 template <int LPR>
 __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
-                                                        float* __restrict__ inv_scale, int rows, int K, int Kp, int form) {
+                                                        float* __restrict__ inv_scale, int rows, int K, int Kp) {
     constexpr int RPW = 64 / LPR;                                // rows per wavefront
     const int lane = threadIdx.x & 63, sub = lane % LPR;
     const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -2153,8 +2072,8 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned h0, h1, l0, l1;
-            psalm_split_words(v[2 * k] * sc, form, h0, l0);
-            psalm_split_words(v[2 * k + 1] * sc, form, h1, l1);
+            psalm_split_words(v[2 * k] * sc, h0, l0);
+            psalm_split_words(v[2 * k + 1] * sc, h1, l1);
             hw[k] = h0 | (h1 << 16);
             lw[k] = l0 | (l1 << 16);
         }
@@ -2166,7 +2085,7 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float* __restrict_
 // Few, long rows (Phi: 899 tokens x 2048 / 10240 columns): a whole 256-thread block per row -- one wavefront per row was a 20-iteration
 // dependent load loop on 899 wavefronts (r02e: ~14 us per launch, 2.6 ms per image).
 __global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ out, long ldo,
-                                                            float* __restrict__ inv_scale, int K, int Kp, int form) {
+                                                            float* __restrict__ inv_scale, int K, int Kp) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const long row = blockIdx.x;
@@ -2201,8 +2120,8 @@ __global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned h0, h1, l0, l1;
-            psalm_split_words(v[2 * k] * sc, form, h0, l0);
-            psalm_split_words(v[2 * k + 1] * sc, form, h1, l1);
+            psalm_split_words(v[2 * k] * sc, h0, l0);
+            psalm_split_words(v[2 * k + 1] * sc, h1, l1);
             hw[k] = h0 | (h1 << 16);
             lw[k] = l0 | (l1 << 16);
         }
@@ -2211,44 +2130,42 @@ __global__ void __launch_bounds__(256) split_f16_row_kernel(const float* __restr
     }
 }
 
-extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, int form, void* stream) {
+extern "C" int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream) {
     if (rows == 0) return 0;
-    PSALM_CHECK_ARG(form >= 0 && form <= 2, "psalm_split_f16: form 0 (f16 lo), 1 (e4m3 pairs, A operand) or 2 (e4m3 pairs, W operand)");
-    const int Kp = form ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;     // x8 forms: whole 128-byte e4m3 K tiles
+    const int Kp = (K + 63) / 64 * 64;
     PSALM_CHECK_ARG(K > 0 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0, "psalm_split_f16: K % 8 == 0, 16-byte aligned input rows");
     PSALM_CHECK_ARG((uintptr_t)out % 16 == 0 && (ldo * 2) % 16 == 0 && ldo >= 2L * Kp, "psalm_split_f16: output rows of >= 2*ceil64(K) f16, 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (Kp >= 1024 && rows <= 4096) {
-        hipLaunchKernelGGL(split_f16_row_kernel, dim3(rows), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, K, Kp, form);
+        hipLaunchKernelGGL(split_f16_row_kernel, dim3(rows), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, K, Kp);
         PSALM_LAUNCH_END("psalm_split_f16");
     }
-    if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
-    else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
-    else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp, form);
+    if (Kp <= 128) hipLaunchKernelGGL((split_f16_kernel<16>), dim3(cdiv(rows, 16)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
+    else if (Kp <= 256) hipLaunchKernelGGL((split_f16_kernel<32>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
+    else hipLaunchKernelGGL((split_f16_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, (unsigned short*)out, ldo, inv_scale, rows, K, Kp);
     PSALM_LAUNCH_END("psalm_split_f16");
 }
 
 // C = act((A . W^T) + bias) + residual from split-f16 operands:  A2 (M, 2 Kp) / W2 (N, 2 Kp) f16 [hi | lo] with row strides lda / ldw
 // (elements) and per-row scales a_scale (M) / w_scale (N) as written by psalm_split_f16;  Kp % 64 == 0.  C / residual fp32.
 // Same tile selection, split-K and epilogue as psalm_gemm (on a K range of 3 Kp); M <= 128 problems take the skinny kernel.
-struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; int so_form; int so_paired; };
-static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+struct SplitOut { void* so; long ldso; int so_kp, so_col_off, so_col_start, so_global; float* so_inv; const float* so_par; int so_paired; };
+static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                         const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
                         int act_col_start, void* workspace, long workspace_bytes, void* stream, const SplitOut* so, const char* name,
                         const LnEpilogue* ln = nullptr) {
     if (M == 0 || N == 0) return 0;
     PSALM_CHECK_ARG(Kp > 0 && Kp % 64 == 0, "psalm_gemm_x3: Kp must be a positive multiple of 64");
-    PSALM_CHECK_ARG(!x8 || Kp % 128 == 0, "psalm_gemm_x3: x8 operands (e4m3 cross-term halves) need Kp % 128 == 0");
     PSALM_CHECK_ARG((uintptr_t)A2 % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)W2 % 16 == 0 && (ldw * 2) % 16 == 0 && lda >= 2L * Kp && ldw >= 2L * Kp,
                     "psalm_gemm_x3: 16-byte aligned operand rows of >= 2*Kp f16");
     PSALM_CHECK_ARG(a_scale && w_scale, "psalm_gemm_x3: scales required");
     GemmArgs g;
     g.A = A2; g.W = W2; g.bias = bias; g.res = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = (x8 ? 2 : 3) * Kp; g.act = act; g.act_col_start = act_col_start;     // x8: hi.hi over Kp f16 + both cross terms over 2 Kp e4m3 bytes
+    g.M = M; g.N = N; g.K = 3 * Kp; g.act = act; g.act_col_start = act_col_start;
     g.row_fast = 0; g.tiles_m = g.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (!x8 && !so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
+    if (!so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
         snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_bf16_skinny_kernel<float, true>");
         hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
@@ -2262,14 +2179,14 @@ static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const vo
     if (so) {
         fa.so = (unsigned short*)so->so; fa.ldso = so->ldso; fa.so_kp = so->so_kp; fa.so_col_off = so->so_col_off;
         fa.so_col_start = so->so_col_start; fa.so_global = so->so_global; fa.so_inv = so->so_inv; fa.so_par = so->so_par;
-        fa.so_form = so->so_form; fa.so_paired = so->so_paired;
+        fa.so_paired = so->so_paired;
     }
-    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, true, x8 != 0);
+    return launch_fast(g, fa, false, PSALM_F32, workspace, workspace_bytes, s, ln, true);
 }
-extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                              const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N, int act,
                              int act_col_start, void* workspace, long workspace_bytes, void* stream) {
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, residual, ldr, C, ldc, M, N, act, act_col_start, workspace,
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, act, act_col_start, workspace,
                         workspace_bytes, stream, nullptr, "psalm_gemm_x3");
 }
 
@@ -2280,13 +2197,12 @@ extern "C" int psalm_gemm_x3(const void* A2, long lda, const float* a_scale, con
 // max(a_scale[r] * par[0] + par[1],  (global_rows ? max_r a_scale[r] : 0) * g1 + g0).  1/scale -> split_inv[r].  Columns below
 // split_col_start are written to C as usual (C may be NULL when split_col_start == 0).  No residual, no split-K; N, split_col_start,
 // split_col_off, split_kp multiples of 8.  The un-written columns of split_out (K padding of the consumer) are the caller's to zero.
-extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                                    const float* bias, void* C, long ldc, int M, int N, int act, int act_col_start, void* split_out,
-                                   long ld_split, int split_kp, int split_col_off, int split_col_start, int split_form, float* split_inv,
+                                   long ld_split, int split_kp, int split_col_off, int split_col_start, int paired, float* split_inv,
                                    const float* bound_par, int global_rows, void* workspace, long workspace_bytes, void* stream) {
-    const int paired = (split_form >> 2) & 1;                    // bit 2: W rows >= split_col_start permuted for paired stores (GemmFastArgs::so_paired)
-    split_form &= 3;
-    PSALM_CHECK_ARG(split_form == 0 || split_form == 1, "psalm_gemm_x3_split: split_form 0 (f16 lo) or 1 (e4m3 pairs of an A operand), + 4: paired");
+    // paired != 0: the W rows >= split_col_start were permuted by the caller for paired stores (GemmFastArgs::so_paired)
+    PSALM_CHECK_ARG(paired == 0 || paired == 1, "psalm_gemm_x3_split: paired is 0 or 1");
     PSALM_CHECK_ARG(!paired || (split_col_start % 256 == 0 && (N - split_col_start) % 64 == 0 && (long)M * ld_split * 2 < (1L << 31)),
                     "psalm_gemm_x3_split: paired output needs split_col_start % 256 == 0, (N - split_col_start) % 64 == 0, split_out < 2 GiB");
     PSALM_CHECK_ARG(split_out && split_inv && bound_par, "psalm_gemm_x3_split: split output, scale array and bound parameters required");
@@ -2295,8 +2211,8 @@ extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scal
                         split_col_off + (N - split_col_start) <= split_kp && ld_split >= 2L * split_kp,
                     "psalm_gemm_x3_split: N / column offsets multiples of 8, 16-byte aligned split rows of >= 2*split_kp f16");
     PSALM_CHECK_ARG(C || split_col_start == 0, "psalm_gemm_x3_split: C required for the columns below split_col_start");
-    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par, split_form, paired};
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
+    SplitOut so{split_out, ld_split, split_kp, split_col_off, split_col_start, global_rows, split_inv, bound_par, paired};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, nullptr, 0, C, ldc, M, N, act, act_col_start, workspace, workspace_bytes,
                         stream, &so, "psalm_gemm_x3_split");
 }
 
@@ -2306,17 +2222,16 @@ extern "C" int psalm_gemm_x3_split(const void* A2, long lda, const float* a_scal
 // input_layernorm of the following layer, modeling_phi.py:263-300).  With split-K (the usual case for this GEMM: few tiles, long K) the
 // partial-sum reduce, epilogue, LayerNorm and split run as ONE row pass; otherwise the LayerNorm is psalm_layernorm_split on C.
 // N % 64 == 0, N <= 2048; split_out rows of 2*N f16 (contiguous), split_inv (M).
-extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp, int x8,
+extern "C" int psalm_gemm_x3_ln_split(const void* A2, long lda, const float* a_scale, const void* W2, long ldw, const float* w_scale, int Kp,
                                       const float* bias, const void* residual, long ldr, void* C, long ldc, int M, int N,
                                       const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, long ld_ln, void* split_out,
-                                      float* split_inv, int split_form, void* workspace, long workspace_bytes, void* stream) {
-    PSALM_CHECK_ARG(split_form == 0 || (split_form == 1 && N % 128 == 0), "psalm_gemm_x3_ln_split: split_form 0, or 1 with N % 128 == 0");
+                                      float* split_inv, void* workspace, long workspace_bytes, void* stream) {
     PSALM_CHECK_ARG(N % 64 == 0 && N <= 2048 && split_out && split_inv && C, "psalm_gemm_x3_ln_split: N % 64 == 0, N <= 2048, outputs required");
     PSALM_CHECK_ARG((uintptr_t)C % 16 == 0 && (ldc * 4) % 16 == 0 && (uintptr_t)ln_gamma % 16 == 0 && (uintptr_t)ln_beta % 16 == 0 &&
                         (uintptr_t)split_out % 16 == 0 && (!ln_out || ((uintptr_t)ln_out % 16 == 0 && (ld_ln * 4) % 16 == 0)) &&
                         (!residual || ((uintptr_t)residual % 16 == 0 && (ldr * 4) % 16 == 0)),
                     "psalm_gemm_x3_ln_split: 16-byte aligned rows");
-    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, PSALM_F32, ld_ln, split_out, split_inv, split_form};
-    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, x8, bias, residual, ldr, C, ldc, M, N, 0, 0, workspace, workspace_bytes, stream,
+    LnEpilogue ln{ln_gamma, ln_beta, ln_eps, ln_out, PSALM_F32, ld_ln, split_out, split_inv};
+    return gemm_x3_impl(A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, 0, 0, workspace, workspace_bytes, stream,
                         nullptr, "psalm_gemm_x3_ln_split", &ln);
 }

@@ -553,8 +553,7 @@ extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* prob
     if ((unsigned long)C * (unsigned long)HW * 4ul < (1ul << 31) && (unsigned long)Q * (unsigned long)HW * 4ul < (1ul << 31)) {          // the buffer descriptor of the stores spans `out` (offsets >= 2^31: dropped)
         const int nt64 = (int)((HW + 63) / 64);
         const int grid2 = nt64 < 512 ? (nt64 + 1) / 2 : 256;                  // 1 persistent block (two wave groups) per CU
-        static int order_env = -1;                                            // PSALM_SEM_ORDER=1: contiguous pixel range per block (A/B)
-        if (order_env < 0) { const char* e = getenv("PSALM_SEM_ORDER"); order_env = e ? atoi(e) : 0; }
+        const int order_env = 0;                                              // strided tile order (the contiguous-range order measured equal: profiles/r03n_semantic_tile_order.jsonl)
         if (Q <= 112)
             hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<112>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
                                mask_score ? workspace : nullptr, Q, C, HW, nt64, order_env);

@@ -7,14 +7,13 @@
 // ---------------------------------------------------------------- LayerNorm core (one wave, one row)
 // Two-pass (mean, then centred variance) like torch.nn.functional.layer_norm; the row is re-read from L1/L2.
 // split-f16 emission helpers (f16x3 mode; see psalm_split_f16 in gemm.hip)
-// (form: the second half-word of an element -- 0 f16 lo, 1 e4m3 pair of an A operand; see psalm_split_words in common.h)
-__device__ __forceinline__ void emit_split8(const float* o8, float sc, unsigned short* hi_dst, unsigned short* lo_dst, int form = 0) {
+__device__ __forceinline__ void emit_split8(const float* o8, float sc, unsigned short* hi_dst, unsigned short* lo_dst) {
     unsigned hw[4], lw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         unsigned h0, h1, l0, l1;
-        psalm_split_words(o8[2 * k] * sc, form, h0, l0);
-        psalm_split_words(o8[2 * k + 1] * sc, form, h1, l1);
+        psalm_split_words(o8[2 * k] * sc, h0, l0);
+        psalm_split_words(o8[2 * k + 1] * sc, h1, l1);
         hw[k] = h0 | (h1 << 16);
         lw[k] = l0 | (l1 << 16);
     }
@@ -156,7 +155,7 @@ __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C,
                                                               float eps, unsigned short* __restrict__ s1, float* __restrict__ inv1,
                                                               const float* __restrict__ add, long add_rows, unsigned short* __restrict__ s2,
-                                                              float* __restrict__ inv2, int Kp, int form) {
+                                                              float* __restrict__ inv2, int Kp) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -215,7 +214,7 @@ __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __res
         const int c = (i * 64 + lane) * 8;
         if (c < Kp) {
             const bool in = c < C;
-            if (s1) emit_split8(in ? v[i] : zero8, sc1, s1 + row * 2L * Kp + c, s1 + row * 2L * Kp + Kp + c, form);
+            if (s1) emit_split8(in ? v[i] : zero8, sc1, s1 + row * 2L * Kp + c, s1 + row * 2L * Kp + Kp + c);
             if (s2) {
                 float t8[8];
                 if (in) {
@@ -223,7 +222,7 @@ __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __res
 #pragma unroll
                     for (int k = 0; k < 8; ++k) t8[k] += v[i][k];
                 }
-                emit_split8(in ? t8 : zero8, sc2, s2 + row * 2L * Kp + c, s2 + row * 2L * Kp + Kp + c, form);
+                emit_split8(in ? t8 : zero8, sc2, s2 + row * 2L * Kp + c, s2 + row * 2L * Kp + Kp + c);
             }
         }
     }
@@ -233,10 +232,9 @@ __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __res
 // add_rows]) or NULL (add (add_rows, C) f32).  Split rows are 2 * ceil64(C) f16, contiguous.  C % 8 == 0, C <= 2048, 16-byte aligned rows.
 extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
                                      float eps, void* split1, float* inv1, const float* add, long add_rows, void* split2, float* inv2,
-                                     int form, void* stream) {
+                                     void* stream) {
     if (rows == 0) return 0;
     PSALM_CHECK_ARG(C % 8 == 0 && C > 0 && C <= 2048, "psalm_layernorm_split: C % 8 == 0, C <= 2048");
-    PSALM_CHECK_ARG(form == 0 || (form == 1 && C % 128 == 0), "psalm_layernorm_split: form 0, or 1 (e4m3 pairs) with C % 128 == 0");
     PSALM_CHECK_ARG((uintptr_t)x % 16 == 0 && (ldx * 4) % 16 == 0 && (!y || ((uintptr_t)y % 16 == 0 && (ldy * 4) % 16 == 0)) &&
                         (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0 && (!split1 || (uintptr_t)split1 % 16 == 0) &&
                         (!split2 || ((uintptr_t)split2 % 16 == 0 && add && add_rows > 0 && (uintptr_t)add % 16 == 0)),
@@ -244,7 +242,7 @@ extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ld
     PSALM_CHECK_ARG((!split1 || inv1) && (!split2 || inv2) && (split1 || split2 || y), "psalm_layernorm_split: outputs / scale arrays missing");
     const int Kp = (C + 63) / 64 * 64;
     hipLaunchKernelGGL(layernorm_split_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, rows, C, eps,
-                       (unsigned short*)split1, inv1, add, add_rows, (unsigned short*)split2, inv2, Kp, form);
+                       (unsigned short*)split1, inv1, add, add_rows, (unsigned short*)split2, inv2, Kp);
     PSALM_LAUNCH_END("psalm_layernorm_split");
 }
 

@@ -48,6 +48,9 @@ def _dt(t: torch.Tensor) -> int:
         raise PsalmHipError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
 
 
+ABI_VERSION = 4        # == PSALM_ABI_VERSION of include/psalm_hip.h (tests/test_0_abi.py compares the two and the built library's answer)
+
+
 class _ProfiledLib:
     """Transparent proxy over the CDLL: when `records` is a list, every psalm_* launch is bracketed by a pair of
     HIP events on the launch stream (torch's current stream) so bench.py can attribute time per kernel family."""
@@ -95,14 +98,11 @@ class _ProfiledLib:
 
 class SplitF16:
     """A matrix in split-f16 form (psalm_split_f16): `t` (rows, 2*Kp) float16 = [hi | lo], `inv_scale` (rows,) float32, logical
-    shape (rows, K).  Either operand of `Ops.gemm` may be one; in the "f16x3" mode GEMM weights are kept in this form.
-    `form`: 0 = the second half-words are lo as float16 (three f16 products per GEMM); 1 / 2 = the "x8" form of an A / W operand -- pairs
-    of e4m3 bytes for the two cross terms (psalm_split_words in csrc/common.h; Kp = ceil128(K)).  A GEMM takes operands of form (0, 0) or
-    (1, 2)."""
-    __slots__ = ("t", "inv_scale", "K", "Kp", "form")
+    shape (rows, K), Kp = ceil64(K).  Either operand of `Ops.gemm` may be one; in the "f16x3" mode GEMM weights are kept in this form."""
+    __slots__ = ("t", "inv_scale", "K", "Kp")
 
-    def __init__(self, t, inv_scale, K, form=0):
-        self.t, self.inv_scale, self.K, self.Kp, self.form = t, inv_scale, K, t.shape[1] // 2, form
+    def __init__(self, t, inv_scale, K):
+        self.t, self.inv_scale, self.K, self.Kp = t, inv_scale, K, t.shape[1] // 2
 
     @property
     def shape(self):
@@ -120,6 +120,12 @@ class Ops:
                 f"{lib_path} not found: build the HIP kernels first (python -m psalm_amd.build). "
                 "psalm_amd has no CPU / PyTorch fallback by design.")
         cdll = ctypes.CDLL(lib_path)
+        # the binary interface this binding was written against (include/psalm_hip.h PSALM_ABI_VERSION): checked BEFORE any other call -- a
+        # stale prebuilt library would take this binding's integers for pointers (silent memory corruption, not an error)
+        got = cdll.psalm_abi_version() if hasattr(cdll, "psalm_abi_version") else -1
+        if got != ABI_VERSION:
+            raise PsalmHipError(f"{lib_path}: psalm_abi_version() = {got}, this binding needs {ABI_VERSION}: rebuild the library "
+                                "(python -m psalm_amd.build --force)")
         cdll.psalm_last_error.restype = c_char_p
         cdll.psalm_backend.restype = c_char_p
         cdll.psalm_gemm_last_kernel.restype = c_char_p
@@ -227,39 +233,30 @@ class Ops:
         self._check(rc, "psalm_gemm")
         return out
 
-    def split_f16(self, x, form=0):
-        """x (rows,K) float32 (row-strided view) -> SplitF16: x * s = hi + lo in float16 with a per-row power-of-two scale (form 0), or with
-        the e4m3 cross-term pairs of an A (form 1) / W (form 2) operand in the second halves."""
+    def split_f16(self, x):
+        """x (rows,K) float32 (row-strided view) -> SplitF16: x * s = hi + lo in float16 with a per-row power-of-two scale."""
         if isinstance(x, SplitF16):
-            if x.form != form and form != 0:
-                raise PsalmHipError(f"split_f16: operand already split in form {x.form}, form {form} wanted")
             return x
         if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
             raise PsalmHipError("split_f16: 2-D float32 input with a contiguous last dimension")
         rows, K = x.shape
-        Kp = (K + 127) // 128 * 128 if form else (K + 63) // 64 * 64
+        Kp = (K + 63) // 64 * 64
         t = self.empty(rows, 2 * Kp, dtype=torch.float16)
         inv = self.empty(rows, dtype=torch.float32)
-        rc = self.lib.psalm_split_f16(self._pv(x), c_long(x.stride(0)), self._p(t), c_long(2 * Kp), self._p(inv), rows, K, form, self._stream())
+        rc = self.lib.psalm_split_f16(self._pv(x), c_long(x.stride(0)), self._p(t), c_long(2 * Kp), self._p(inv), rows, K, self._stream())
         self._check(rc, "psalm_split_f16")
-        return SplitF16(t, inv, K, form)
+        return SplitF16(t, inv, K)
 
     def _x3_operands(self, a, w):
-        """(a, w, x8) for a split-f16 GEMM: float32 tensors are split on the fly in the form the other operand already has."""
-        if isinstance(w, SplitF16) and w.form == 2:
-            a = self.split_f16(a, 1)
-        elif isinstance(a, SplitF16) and a.form == 1:
-            w = self.split_f16(w, 2)
+        """(a, w) for a split-f16 GEMM: float32 tensors are split on the fly."""
         a, w = self.split_f16(a), self.split_f16(w)
-        if (a.form, w.form) not in ((0, 0), (1, 2)):
-            raise PsalmHipError(f"split-f16 GEMM: operand forms (A {a.form}, W {w.form}); (0, 0) or (1, 2) expected")
         if a.K != w.K or a.Kp != w.Kp:
             raise PsalmHipError(f"gemm shape mismatch {a.shape} x {w.shape}")
-        return a, w, 1 if a.form else 0
+        return a, w
 
     def gemm_x3(self, a, w, bias=None, residual=None, act=ACT_NONE, act_col_start=0, out=None, out_dtype=None):
         """gemm() on split-f16 operands (float32 tensors are split on the fly): fp32-class result on the f16 matrix cores."""
-        a, w, x8 = self._x3_operands(a, w)
+        a, w = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if out is None:
             if out_dtype not in (None, torch.float32):
@@ -271,16 +268,16 @@ class Ops:
         if bias is not None and (bias.dtype != torch.float32 or bias.numel() != (M if act & ACT_BIAS_ROW else N)):
             raise PsalmHipError("gemm bias must be float32 (N,) -- or (M,) with ACT_BIAS_ROW")
         rc = self.lib.psalm_gemm_x3(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                    self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(residual),
+                                    self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
                                     c_long(residual.stride(0) if residual is not None else 0), self._pv(out), c_long(out.stride(0)),
                                     M, N, act, act_col_start, self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3")
         return out
 
-    def gemm_x3_ln_split(self, a, w, bias, residual, gamma, beta, eps, want_y=False, split_form=0):
+    def gemm_x3_ln_split(self, a, w, bias, residual, gamma, beta, eps, want_y=False):
         """x = a.w^T + bias + residual (float32), h = LayerNorm(x): returns (x, SplitF16(h), h float32 | None) -- the split-K reduce, the
-        LayerNorm and the split of h are one row pass (psalm_gemm_x3_ln_split).  split_form: form of the emitted h (0, or 1 = x8 A operand)."""
-        a, w, x8 = self._x3_operands(a, w)
+        LayerNorm and the split of h are one row pass (psalm_gemm_x3_ln_split)."""
+        a, w = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if residual is not None and (residual.dtype != torch.float32 or tuple(residual.shape) != (M, N) or residual.stride(-1) != 1):
             raise PsalmHipError("gemm_x3_ln_split: float32 (M,N) residual")
@@ -288,20 +285,20 @@ class Ops:
         y = self.empty(M, N, dtype=torch.float32) if want_y else None
         so, inv = self.empty(M, 2 * N, dtype=torch.float16), self.empty(M, dtype=torch.float32)
         rc = self.lib.psalm_gemm_x3_ln_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                             self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(residual),
+                                             self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(residual),
                                              c_long(residual.stride(0) if residual is not None else 0), self._p(x), c_long(N), M, N,
                                              self._p(gamma), self._p(beta), c_float(eps), self._pv(y), c_long(N), self._p(so), self._p(inv),
-                                             split_form, self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+                                             self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_ln_split")
-        return x, SplitF16(so, inv, N, split_form), y
+        return x, SplitF16(so, inv, N), y
 
     def gemm_x3_split(self, a, w, bias, act, split_out, split_inv, bound_par, split_col_off=0, split_col_start=0, act_col_start=0,
-                      out=None, global_rows=False, split_form=0, paired=False):
+                      out=None, global_rows=False, paired=False):
         """gemm_x3 whose columns >= split_col_start are written as the split-f16 A operand of the next GEMM: into `split_out` (a SplitF16's
         .t buffer (M, 2*Kp_out) f16) at columns split_col_off.. (hi) / Kp_out + split_col_off.. (lo), row scales (inverse) into split_inv;
         bound_par: 4 device floats, see psalm_gemm_x3_split.  Columns below split_col_start go to `out` (M, >= split_col_start...) fp32.
         paired: the rows of `w` (and bias) >= split_col_start were permuted with `so_pair_perm` (stores straight from the accumulators)."""
-        a, w, x8 = self._x3_operands(a, w)
+        a, w = self._x3_operands(a, w)
         M, N = a.t.shape[0], w.t.shape[0]
         if split_out.dtype != torch.float16 or split_out.dim() != 2 or split_out.shape[0] != M or split_out.stride(1) != 1:
             raise PsalmHipError("gemm_x3_split: split_out must be a (M, 2*Kp) float16 buffer")
@@ -312,10 +309,10 @@ class Ops:
         if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
             raise PsalmHipError("gemm bias must be float32 (N,)")
         rc = self.lib.psalm_gemm_x3_split(self._p(a.t), c_long(a.t.stride(0)), self._p(a.inv_scale), self._p(w.t), c_long(w.t.stride(0)),
-                                          self._p(w.inv_scale), a.Kp, x8, self._pv(bias), self._pv(out),
+                                          self._p(w.inv_scale), a.Kp, self._pv(bias), self._pv(out),
                                           c_long(out.stride(0) if out is not None else 0), M, N, act, act_col_start,
                                           self._p(split_out), c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
-                                          split_col_start, split_form | (4 if paired else 0), self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
+                                          split_col_start, int(bool(paired)), self._p(split_inv), self._p(bound_par), int(bool(global_rows)),
                                           self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_gemm_x3_split")
         if _DEBUG_BOUNDS or self.debug_bounds:
@@ -324,8 +321,8 @@ class Ops:
 
     @staticmethod
     def so_pair_perm(n: int) -> torch.Tensor:
-        """Row permutation of a weight (and its bias) whose GEMM emits split-f16 output with paired stores (psalm_gemm_x3_split, split_form
-        bit 2): index tensor `c` with W_physical = W_logical[c]; physical row 64 g + 32 b + j holds logical row 64 g + 2 j + b.  n % 64 == 0."""
+        """Row permutation of a weight (and its bias) whose GEMM emits split-f16 output with paired stores (psalm_gemm_x3_split,
+        `paired`): index tensor `c` with W_physical = W_logical[c]; physical row 64 g + 32 b + j holds logical row 64 g + 2 j + b.  n % 64 == 0."""
         if n % 64:
             raise PsalmHipError("so_pair_perm: n % 64 == 0")
         p = torch.arange(n)
@@ -381,13 +378,9 @@ class Ops:
         self._check(rc, "psalm_conv2d_nhwc")
         return out
 
-    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True, x3=False, x8=False):
-        """(path, BM, BN, splits) psalm_gemm / psalm_gemm_x3 (x3=True, K = 3*Kp; x8=True, K = 2*Kp) uses for this problem (path 1 =
-        direct-to-LDS kernel)."""
+    def gemm_describe(self, M, N, K, a_bf16=True, w_bf16=True, x3=False):
+        """(path, BM, BN, splits) psalm_gemm / psalm_gemm_x3 (x3=True, K = 3*Kp) uses for this problem (path 1 = direct-to-LDS kernel)."""
         out = (c_int * 4)()
-        if x8:
-            self._cdll_raw.psalm_gemm_describe(M, N, K, 3, 3, c_long(self.GEMM_WS_BYTES), out)
-            return tuple(out)
         if x3:
             self._cdll_raw.psalm_gemm_describe(M, N, K, 2, 2, c_long(self.GEMM_WS_BYTES), out)
             return tuple(out)
@@ -422,15 +415,13 @@ class Ops:
         self._check(rc, "psalm_layernorm3")
         return out
 
-    def layernorm_split(self, x, gamma, beta, eps=1e-5, want_y=False, want_split=True, add=None, form=0):
-        """LayerNorm of float32 rows whose result leaves as the next GEMM's split-f16 A operand (f16x3 mode; form 1: its x8 form).
+    def layernorm_split(self, x, gamma, beta, eps=1e-5, want_y=False, want_split=True, add=None):
+        """LayerNorm of float32 rows whose result leaves as the next GEMM's split-f16 A operand (f16x3 mode).
         Returns (y float32 | None, SplitF16(y) | None, SplitF16(y + add[row % r]) | None)."""
         rows, C = x.shape
         if x.dtype != torch.float32 or x.stride(1) != 1:
             raise PsalmHipError("layernorm_split: float32 rows")
-        Kp = (C + 127) // 128 * 128 if form else (C + 63) // 64 * 64
-        if form and Kp != C:
-            raise PsalmHipError("layernorm_split: the x8 form needs C % 128 == 0")
+        Kp = (C + 63) // 64 * 64
         y = self.empty(rows, C, dtype=torch.float32) if want_y else None
         s1 = i1 = s2 = i2 = None
         if want_split:
@@ -441,9 +432,9 @@ class Ops:
             s2, i2 = self.empty(rows, 2 * Kp, dtype=torch.float16), self.empty(rows, dtype=torch.float32)
         rc = self.lib.psalm_layernorm_split(self._pv(x), c_long(x.stride(0)), self._p(y), c_long(C), self._p(gamma), self._p(beta), rows, C,
                                             c_float(eps), self._p(s1), self._p(i1), self._p(add), c_long(add.shape[0] if add is not None else 0),
-                                            self._p(s2), self._p(i2), form, self._stream())
+                                            self._p(s2), self._p(i2), self._stream())
         self._check(rc, "psalm_layernorm_split")
-        return y, (SplitF16(s1, i1, C, form) if want_split else None), (SplitF16(s2, i2, C, form) if add is not None else None)
+        return y, (SplitF16(s1, i1, C) if want_split else None), (SplitF16(s2, i2, C) if add is not None else None)
 
     def swin_window_gather(self, x, gamma, beta, B, H, W, ws, shift, eps=1e-5, out_dtype=None):
         """x (B*H*W, C) -> LN + pad + roll(-shift) + window partition -> (B*nW*ws*ws, C)."""
@@ -621,7 +612,7 @@ class Ops:
         return out
 
     def causal_attention_split(self, buf, q_off, k_off, v_off, split_out, split_inv, split_col_off, cos, sin, key_mask, B, L, heads,
-                               head_dim, rot, split_form=0):
+                               head_dim, rot):
         """causal_attention on an fp32 buffer whose output goes, in split-f16 form under the row scales 1/split_inv, into columns
         split_col_off.. of `split_out` ((B*L, 2*Kp) float16; lo part Kp columns further) -- see psalm_causal_attention_f32_split."""
         if buf.dtype != torch.float32 or split_out.dtype != torch.float16 or split_inv.dtype != torch.float32:
@@ -633,7 +624,7 @@ class Ops:
         if ws is None:
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         rc = self.lib.psalm_causal_attention_f32_split(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._p(split_out),
-                                                       c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off, split_form,
+                                                       c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off,
                                                        self._p(split_inv), self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
                                                        B, L, heads, head_dim, rot, self._stream())
         self._check(rc, "psalm_causal_attention_f32_split")

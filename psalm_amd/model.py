@@ -18,10 +18,8 @@ Precision modes
             bar on this network (the mask decoder's thresholded attention-mask feedback amplifies operand rounding into label flips;
             measured threshold between 15 and 17 operand bits, tools/exp_bits.py); this mode does, at 3 f16 MFMA passes instead of
             the fp32 MFMA's 16x lower rate.  Activations, norms, softmax and the attention kernels are those of "fp32".
-            With `llm_cross_fp8="both"` (or "w1" / "w2"; off by default) the Phi GEMMs carry their two cross terms lo.hi + hi.lo as ONE OCP
-            e4m3 dot product on the block-scaled fp8 matrix instruction (2 instead of 3 f16-product equivalents; BASELINE.json
-            configs[4] names an "fp8 MFMA LLM path" -- this is the form that comes closest: +13 % images/s, at the bar on ~95 % of the
-            inputs; why it is not the default is written at PSALM.__init__).
+            (r03 carried an opt-in form of the Phi GEMMs with e4m3 cross terms -- BASELINE.json configs[4]'s "fp8 MFMA LLM path"; it moved
+            ~5 % of the inputs by 1e-3 .. 6e-2 of the logit range and was removed in r04: DESIGN.md section 0, tools/exp_x8_cpu.py.)
 
 Layout: activations are token-major (rows = pixels/tokens, cols = channels; NHWC for feature maps), so 1x1
 convolutions are GEMMs, 3x3 / strided convolutions are im2col + GEMM, and LayerNorm/softmax rows are contiguous.
@@ -98,8 +96,7 @@ class PSALM:
     DEFAULT_PRECISION = "f16x3"
 
     def __init__(self, cfg: PsalmConfig, state_dict: Dict[str, torch.Tensor], ops: Optional[H.Ops] = None,
-                 precision: Optional[str] = None, use_graphs: bool = False, llm_cross_fp8=None,
-                 paired_split_stores: Optional[bool] = None):
+                 precision: Optional[str] = None, use_graphs: bool = False, paired_split_stores: Optional[bool] = None):
         precision = precision or self.DEFAULT_PRECISION
         if precision not in ("bf16", "fp32", "f16x3"):
             raise ValueError("precision must be 'f16x3', 'fp32' or 'bf16'")
@@ -132,27 +129,9 @@ class PSALM:
         self.fuse_split = precision == "f16x3"
         # ... and where the emitting kernel is a GEMM (Swin fc1, encoder linear1, Phi fc1) the weight rows are stored PERMUTED inside groups
         # of 64 (H.Ops.so_pair_perm) so that the 2-byte operand leaves in 4-byte stores of whole 128-byte row segments straight from the
-        # accumulators (psalm_gemm_x3_split, split_form bit 2) -- results bit for bit those of the un-permuted layout.  A construction-time
+        # accumulators (psalm_gemm_x3_split, `paired`) -- results bit for bit those of the un-permuted layout.  A construction-time
         # choice (the weights are laid out for it): such a model cannot be switched to fuse_split = False afterwards.
         self.so_paired = self.fuse_split if paired_split_stores is None else (bool(paired_split_stores) and self.fuse_split)
-        # f16x3: a Phi GEMM can form its two cross terms (lo.hi + hi.lo, 2^-11 of the result) as ONE e4m3 dot product on the
-        # block-scaled fp8 matrix instruction (operand form "x8", csrc/common.h psalm_split_words): 2 instead of 3 f16-product equivalents
-        # (the two Phi GEMMs are 2/3 of the path's GEMM flops).  Decided on numerics first (tools/exp_fp8cross.py, profiles/r03d_*: over 10 weight / input
-        # seeds the Phi stage in this arithmetic is indistinguishable from the three-product form -- mask logits move by 5e-6 of their
-        # range, mean mask IoU vs exact fp32 >= 0.99999 -- while the Swin and pixel-decoder GEMMs are NOT tolerant and keep three
-        # products).  Needs hidden and hidden + intermediate to be multiples of 128 and the fused operand hand-over (fuse_split).
-        Hd_, I_ = cfg.hidden_size, cfg.intermediate_size
-        can_x8 = self.fuse_split and Hd_ % 128 == 0 and (Hd_ + I_) % 128 == 0 and Hd_ <= 2048 and cfg.head_dim == 64 and cfg.rotary_dim == 32
-        # llm_cross_fp8: None / False = three f16 products everywhere (DEFAULT); "w1" / "w2" / "both" (= True) = which Phi GEMM takes the form.
-        # OFF by default since the end of r03: the form passed the 5-seed gate of bench.py and all but one input of the GPU runs, but ~5 % of
-        # the inputs (referring and panoptic alike) move by 1e-3 .. 6e-2 of the logit range instead of 3e-6, whichever of the two GEMMs
-        # carries it (one GPU image of 20 below the bar with [k|v|q|fc1] in the form, profiles/r03n_* / r03o_*; CPU restatement of the
-        # arithmetic on the oracle, tools/exp_x8_cpu.py, profiles/r03s_*: 5 of 68 inputs moved in the x8 form (up to 6e-2), 1 of 64 with three products (9e-4)):
-        # a 2^-15-level perturbation of the Phi stage tips the mask decoder's thresholded attention masks on such inputs four times as often,
-        # and further, than the 2^-22-level one every re-implementation carries.  The form stays available as the fast mode (bench.py reports it as a side line).
-        sel = {None: "", False: "", True: "w1w2", "w1": "w1", "w2": "w2", "both": "w1w2"}[llm_cross_fp8] if can_x8 else ""
-        self.llm_x8_w1, self.llm_x8_w2 = "w1" in sel, "w2" in sel
-        self.llm_x8 = self.llm_x8_w1 or self.llm_x8_w2
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
@@ -333,11 +312,7 @@ class PSALM:
             w2 = torch.cat([sd[a + "dense.weight"], sd[p + "mlp.fc2.weight"]], 1)
             b1 = torch.cat([sd[a + "k_proj.bias"], sd[a + "v_proj.bias"], sd[a + "q_proj.bias"], sd[p + "mlp.fc1.bias"]], 0)
             w1, b1, self.paired[f"llm{i}"] = self._pair_rows(w1, b1, 3 * cfg.hidden_size)      # the fc1 rows: gelu(fc1) leaves as fc2's operand
-            for nm, mat, x8_ in (("w1", w1, self.llm_x8_w1), ("w2", w2, self.llm_x8_w2)):
-                if x8_:                            # split-f16 with e4m3 cross-term halves (W operand form)
-                    w[f"llm{i}.{nm}"] = self.ops.split_f16(self._aligned(mat.detach().to(torch.float32).contiguous().to(self.device)), 2)
-                else:
-                    w[f"llm{i}.{nm}"] = W(mat)
+            w[f"llm{i}.w1"], w[f"llm{i}.w2"] = W(w1), W(w2)
             w[f"llm{i}.b1"] = Fp(b1)
             w[f"llm{i}.b2"] = Fp(sd[a + "dense.bias"].float() + sd[p + "mlp.fc2.bias"].float())
             norm(f"llm{i}.ln", p + "input_layernorm")
@@ -775,16 +750,11 @@ class PSALM:
             a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)
             inv2 = o.empty(B * L, dtype=torch.float32)
         fused = self.adt == torch.bfloat16           # residual projection + the NEXT layer's LayerNorm in one call (psalm_gemm_ln)
-        # operand forms of this decoder's two GEMMs (weights were prepared to match): f1 = the LayerNorm output feeding [k|v|q|fc1],
-        # f2 = [attn | gelu(fc1)] feeding [dense|fc2]
-        f1, f2 = (1 if self.llm_x8_w1 and fuse_split else 0), (1 if self.llm_x8_w2 and fuse_split else 0)
-        if self.llm_x8 and not fuse_split:
-            raise H.PsalmHipError("llm_cross_fp8: the Phi weights are in the x8 form but the fused operand hand-over is off")
         if self.paired.get("llm0", False) and not fuse_split:
             raise H.PsalmHipError("the Phi fc1 rows are laid out for paired split-f16 stores but the fused operand hand-over is off "
                                   "(build the model with paired_split_stores=False)")
         if self.x3:                                  # f16x3: LayerNorm emits the [k|v|q|fc1] GEMM's split-f16 A operand directly
-            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, form=f1)[1]
+            h = o.layernorm_split(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps)[1]
         else:
             h = o.layernorm(x, w["llm0.ln.g"], w["llm0.ln.b"], cfg.layer_norm_eps, out_dtype=self.adt)
         for i in range(cfg.num_layers):
@@ -792,17 +762,17 @@ class PSALM:
             ng, nb = (w["llm.final.g"], w["llm.final.b"]) if last else (w[f"llm{i + 1}.ln.g"], w[f"llm{i + 1}.ln.b"])
             if fuse_split:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
-                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True, split_form=f2,
+                                split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True,
                                 paired=self.paired.get(f"llm{i}", False))
                 o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                         cfg.rotary_dim, split_form=f2)
+                                         cfg.rotary_dim)
                 if last or Hd % 64 != 0 or Hd > 2048:
-                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I, f2), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
+                    x = o.gemm(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                     h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \
-                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps, form=f1)[1]
+                        o.layernorm_split(x, ng, nb, cfg.layer_norm_eps)[1]
                 else:                                 # residual GEMM + the next layer's LayerNorm + its split: one pass after the K slices
-                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I, f2), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb,
-                                                 cfg.layer_norm_eps, split_form=f1)
+                    x, h, _ = o.gemm_x3_ln_split(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], x, ng, nb,
+                                                 cfg.layer_norm_eps)
                 continue
             o.gemm(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], act=H.ACT_GELU_NEW, act_col_start=3 * Hd, out=big)
             # columns: [k | v | q | gelu_new(fc1)];  attention output overwrites q in place

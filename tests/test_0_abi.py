@@ -30,7 +30,22 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/psalm_hip.h but not exported by {lib}: {missing}"
     so.psalm_backend.restype = ctypes.c_char_p
     assert so.psalm_backend() == b"hip-gfx950"
-    assert so.psalm_abi_version() >= 1
+    # the built library, the header constant and the binding's constant are one number (a stale library under a newer binding
+    # would take integers for pointers)
+    import re
+    from psalm_amd import hip_ops as H
+    hdr = int(re.search(r"#define\s+PSALM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert so.psalm_abi_version() == hdr == H.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(tmp_path, monkeypatch):
+    """Ops.__init__ compares psalm_abi_version() with the version it was written against BEFORE any other call."""
+    from psalm_amd import build as hip_build
+    from psalm_amd import hip_ops as H
+    lib = hip_build.build(verbose=False)
+    monkeypatch.setattr(H, "ABI_VERSION", H.ABI_VERSION + 1)
+    with pytest.raises(H.PsalmHipError, match="psalm_abi_version"):
+        H.Ops(lib)
 
 
 def test_every_exported_entry_point_is_declared():

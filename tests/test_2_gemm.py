@@ -390,14 +390,13 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     assert ((y1 - y2).abs() <= 8 * 2.0 ** -22 * mag + 1e-9).all()
 
 
-@pytest.mark.parametrize("M,N,K,act,policy,col_start,col_off,glob,x8", [
-    (300, 256, 128, H.ACT_GELU, 64, 0, 0, False, False),
-    (300, 512, 192, H.ACT_RELU, 128, 0, 64, False, False),
-    (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, False),     # Phi layout on the 256 x 256 tile: [.. | fc1], fc1 columns paired
-    (140, 768, 256, H.ACT_GELU_NEW, 256, 256, 128, True, True),      # ... in the x8 operand form (e4m3 second words)
+@pytest.mark.parametrize("M,N,K,act,policy,col_start,col_off,glob", [
+    (300, 256, 128, H.ACT_GELU, 64, 0, 0, False),
+    (300, 512, 192, H.ACT_RELU, 128, 0, 64, False),
+    (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True),     # Phi layout on the 256 x 256 tile: [.. | fc1], fc1 columns paired
 ])
-def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start, col_off, glob, x8):
-    """split_form bit 2: with the W rows / bias >= col_start permuted by so_pair_perm the emitted operand, its scales and the fp32 columns are
+def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start, col_off, glob):
+    """`paired`: with the W rows / bias >= col_start permuted by so_pair_perm the emitted operand, its scales and the fp32 columns are
     bit for bit those of the un-permuted call (same dot products; only the store path differs: registers -> 4-byte stores, no LDS pass)."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
@@ -413,13 +412,13 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
     try:
         for paired in (False, True):
             wq, bq = (w[perm], bias[perm]) if paired else (w, bias)
-            asp = ops.split_f16(a.to(d), 1 if x8 else 0)
-            wsp = ops.split_f16(wq.to(d), 2 if x8 else 0)
+            asp = ops.split_f16(a.to(d))
+            wsp = ops.split_f16(wq.to(d))
             so = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
             inv = torch.full((M,), -1.0, device=d)
             out = torch.full((M, N), 7.0, device=d) if col_start else None
             ops.gemm_x3_split(asp, wsp, bq.to(d), act, so, inv, par, split_col_off=col_off, split_col_start=col_start, act_col_start=col_start,
-                              out=out, global_rows=glob, split_form=1 if x8 else 0, paired=paired)
+                              out=out, global_rows=glob, paired=paired)
             res.append((so.cpu(), inv.cpu(), out.cpu() if out is not None else None))
     finally:
         ops.gemm_tile_policy(0)
@@ -429,8 +428,8 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
     if col_start:
         assert torch.equal(out0, out1)
     with pytest.raises(H.PsalmHipError):                       # a column count the permutation is not defined for
-        ops.gemm_x3_split(asp, ops.split_f16(w[:N - 8].to(d), 2 if x8 else 0), bias[:N - 8].to(d), act, so, inv, par, split_col_off=col_off,
-                          split_col_start=col_start, act_col_start=col_start, out=out, split_form=1 if x8 else 0, paired=True)
+        ops.gemm_x3_split(asp, ops.split_f16(w[:N - 8].to(d)), bias[:N - 8].to(d), act, so, inv, par, split_col_off=col_off,
+                          split_col_start=col_start, act_col_start=col_start, out=out, paired=True)
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,has_res,act", [
@@ -457,7 +456,7 @@ def test_gemm_x3_256_phased_slice_form_split_output(ops):
         test_gemm_x3_split_output(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
         assert "256, 256, 2, 4, 2, false, 32, 3, 2, true" in ops.gemm_last_kernel() or "skinny" in ops.gemm_last_kernel() or "64, 128" in ops.gemm_last_kernel()
         test_gemm_x3_split_output(ops, 300, 520, 128, H.ACT_GELU, 256, 256, 0, True)
-        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, False)
+        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
     finally:
         ops.gemm_tile_policy(2580)
 
@@ -633,149 +632,6 @@ def test_gemm_x3_direct_epilogue_edges(ops, policy, mode):
     got = big.cpu().double()
     assert ((got[:M, 8:8 + N] - y).abs() <= 6 * 2.0 ** -22 * mag + 4e-7 * y.abs() + 1e-6).all()
     assert (got[M:] == 7).all() and (got[:, :8] == 7).all() and (got[:, 8 + N:] == 7).all()
-
-
-# ------------------------------------------------------------------------------------------------ "x8" operand form (e4m3 cross terms)
-def _e4m3(v):
-    """OCP e4m3 rounding of float64 / float32 values (nearest even, 3 mantissa bits, subnormal step 2^-9, saturating at 448) -> float64"""
-    v = v.double().clamp(-448.0, 448.0)
-    a = v.abs()
-    _, e2 = torch.frexp(a)
-    step = torch.exp2((e2 - 1).clamp_min(-6).double() - 3)
-    return torch.sign(v) * (torch.round(a / step) * step).clamp_max(448.0)
-
-
-def _e4m3_bytes_to_f64(b):
-    b = b.to(torch.int32)
-    e, m = (b >> 3) & 15, b & 7
-    mag = torch.where(e == 0, m.double() * 2.0 ** -9, (1.0 + m.double() / 8.0) * torch.exp2(e.double() - 7))
-    return torch.where((b & 0x80) != 0, -mag, mag)
-
-
-def _x8_parts(sp):
-    """SplitF16 (form 1 / 2) -> (hi float64 (rows,K), cross-term bytes decoded (rows, K, 2) float64, inv_scale float64)"""
-    t = sp.t.cpu()
-    hi = t[:, :sp.K].double()
-    sec = t[:, sp.Kp:sp.Kp + sp.K].view(torch.int16).to(torch.int32) & 0xffff
-    return hi, torch.stack([_e4m3_bytes_to_f64(sec & 0xff), _e4m3_bytes_to_f64(sec >> 8)], -1), sp.inv_scale.cpu().double()
-
-
-def _x8_ref(asp, wsp):
-    """exact value of what the x8 GEMM computes from its operands: sa sw (hi.hi + sum_bytes A_byte * W_byte)"""
-    ah, ab, ai = _x8_parts(asp)
-    wh, wb, wi = _x8_parts(wsp)
-    acc = ah @ wh.t() + ab[..., 0] @ wb[..., 0].t() + ab[..., 1] @ wb[..., 1].t()
-    return acc * ai[:, None] * wi[None, :]
-
-
-@pytest.mark.parametrize("rows,K,form", [(37, 256, 1), (9, 200, 2), (130, 1152, 1)])
-def test_split_f16_x8_forms(ops, rows, K, form):
-    g = torch.Generator().manual_seed(rows + K + form)
-    x = torch.randn(rows, K, generator=g) * torch.exp2(torch.randint(-20, 20, (rows, 1), generator=g).float())
-    x[0] = 0.0
-    sp = ops.split_f16(x.to(ops.device), form)
-    ref = ops.split_f16(x.to(ops.device))                       # form 0: same scales, same hi
-    Kp = (K + 127) // 128 * 128
-    assert sp.Kp == Kp and sp.form == form and torch.equal(sp.inv_scale.cpu(), ref.inv_scale.cpu())
-    t, t0 = sp.t.cpu(), ref.t.cpu()
-    assert torch.equal(t[:, :K], t0[:, :K]) and (t[:, K:Kp] == 0).all() and (t[:, Kp + K:].view(torch.int16) == 0).all()
-    hi = t0[:, :K].double()
-    lo = x.double() / sp.inv_scale.cpu().double()[:, None] - hi                # the exact remainder x s - hi (what the kernel rounds to e4m3)
-    _, by, _ = _x8_parts(sp)
-    eh, el = _e4m3(hi * 2.0 ** -6), _e4m3(lo * 2.0 ** 6)
-    first, second = (eh, el) if form == 1 else (el, eh)
-    assert torch.equal(by[..., 0], first) and torch.equal(by[..., 1], second)
-
-
-X8_CASES = [
-    # M, N, K, bias, res, act
-    (300, 520, 256, True, True, H.ACT_RELU),                # 4 f16 + 4 e4m3 K tiles, ragged tiles, fp32 direct epilogue
-    (257, 256, 128, False, False, H.ACT_NONE),              # 2 + 2 tiles: prologue / drain only, the kind switch inside the drain
-    (140, 100, 1920, True, True, H.ACT_NONE),               # split-K: slices on either side of the hi / e4m3 boundary and one across it
-    (100, 72, 384, True, False, H.ACT_GELU),                # M <= 128 (no skinny kernel in this form), erf epilogue through the LDS
-]
-
-
-@pytest.mark.parametrize("M,N,K,has_bias,has_res,act", X8_CASES)
-def test_gemm_x8(ops, M, N, K, has_bias, has_res, act):
-    """The x8 GEMM: hi.hi on the f16 matrix cores + both cross terms as one e4m3 dot product.  (1) It computes EXACTLY (fp32 accumulation
-    aside) the sum its operands define; (2) that sum is the fp32 product to ~2^-15 of sum |a||w| (the cross terms carry 3 mantissa bits)."""
-    g = torch.Generator().manual_seed(M + N + K)
-    a = (torch.randn(M, K, generator=g) + torch.arange(M)[:, None] * 0.01) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())
-    w = (torch.randn(N, K, generator=g) * 0.5) * torch.exp2(torch.randint(-6, 6, (N, 1), generator=g).float())
-    bias = torch.randn(N, generator=g) if has_bias else None
-    res = torch.randn(M, N, generator=g) if has_res else None
-    d = ops.device
-    asp, wsp = ops.split_f16(a.to(d), 1), ops.split_f16(w.to(d), 2)
-    got = ops.gemm_x3(asp, wsp, bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()
-    got2 = ops.gemm(a.to(d), wsp, bias.to(d) if has_bias else None, res.to(d) if has_res else None, act, 0).cpu().double()   # A split on the fly
-    assert torch.equal(got, got2)
-
-    def epi(y):
-        if has_bias:
-            y = y + bias.double()
-        if act & 15:
-            y = {H.ACT_RELU: torch.relu, H.ACT_GELU: torch.nn.functional.gelu}[act & 15](y)
-        return y + res.double() if has_res else y
-    mag = a.abs().double() @ w.abs().double().t()
-    exact = epi(_x8_ref(asp, wsp))
-    assert ((got - exact).abs() <= 2.0 ** -21 * mag + 3e-6 * exact.abs() + 1e-6).all(), (got - exact).abs().max()    # fp32 accumulation only (a mis-paired byte would show at 2^-12)
-    want = epi(a.double() @ w.double().t())
-    assert ((got - want).abs() <= 2.0 ** -14 * mag + 1e-6).all()
-    assert ((got - want).abs().mean() <= 2.0 ** -17 * mag.mean() + 1e-7)
-
-
-def test_gemm_x8_rejects_mixed_forms(ops):
-    d = ops.device
-    a, w = torch.randn(64, 128).to(d), torch.randn(64, 128).to(d)
-    with pytest.raises(H.PsalmHipError):
-        ops.gemm_x3(ops.split_f16(a, 1), ops.split_f16(w, 0))
-    with pytest.raises(H.PsalmHipError):
-        ops.gemm_x3(ops.split_f16(a, 2), ops.split_f16(w, 2))
-
-
-def test_gemm_x8_split_output_and_ln_split(ops):
-    """Phi layer data flow in the x8 form: [k|v|q|fc1] GEMM with x8 operands whose fc1 columns leave as an x8 A operand (split_form 1), then
-    the residual GEMM + LayerNorm whose normalised rows leave in the x8 form as well; each checked against the form-0 twin."""
-    M, K, N, cs = 300, 256, 768, 512
-    g = torch.Generator().manual_seed(5)
-    d = ops.device
-    a = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) * 0.2
-    bias = torch.randn(N, generator=g)
-    par = split_bound_par(w[cs:], bias[cs:], 2.0 ** 14 * 3.0, 0.5).to(d)
-    outs = {}
-    for form in (0, 1):
-        asp, wsp = (ops.split_f16(a.to(d), 1), ops.split_f16(w.to(d), 2)) if form else (ops.split_f16(a.to(d)), ops.split_f16(w.to(d)))
-        Kp_out = 512
-        so = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
-        inv = torch.zeros(M, device=d)
-        out = torch.full((M, N), 7.0, device=d)
-        ops.gemm_x3_split(asp, wsp, bias.to(d), H.ACT_GELU_NEW, so, inv, par, split_col_off=256, split_col_start=cs, act_col_start=cs, out=out,
-                          global_rows=True, split_form=form)
-        outs[form] = (so.cpu(), inv.cpu(), out.cpu())
-    (so0, inv0, out0), (so1, inv1, out1) = outs[0], outs[1]
-    assert torch.equal(inv0, inv1) and (out1[:, cs:] == 7).all()
-    assert torch.allclose(out1[:, :cs], out0[:, :cs], rtol=0, atol=2.0 ** -13 * float(out0.abs().max()))      # cross terms at 3 mantissa bits
-    hi1, by1, _ = _x8_parts(H.SplitF16(so1, inv1, 512, 1))
-    v0 = (so0[:, 256:512].double() + so0[:, 512 + 256:].double())                    # form-0 value in scaled units
-    rec1 = hi1[:, 256:] + by1[:, 256:, 1] * 2.0 ** -6                                # hi + lo8 / 2^6
-    assert ((rec1 - v0).abs() <= 2.0 ** -12 * v0.abs().amax(1, keepdim=True)).all()  # the GEMM inputs differ at 2^-15; the emitted pairs themselves:
-    assert torch.equal(by1[:, 256:, 0], _e4m3(hi1[:, 256:] * 2.0 ** -6))             # first byte = e4m3(hi 2^-6) exactly
-    # residual GEMM + LayerNorm -> x8 operand
-    w2 = torch.randn(128, 256, generator=g) * 0.3
-    x0 = torch.randn(M, 128, generator=g)
-    gam, bet = torch.randn(128, generator=g), torch.randn(128, generator=g)
-    a2 = torch.randn(M, 256, generator=g)
-    r0 = ops.gemm_x3_ln_split(ops.split_f16(a2.to(d)), ops.split_f16(w2.to(d)), None, x0.to(d), gam.to(d), bet.to(d), 1e-5, want_y=True)
-    r1 = ops.gemm_x3_ln_split(ops.split_f16(a2.to(d), 1), ops.split_f16(w2.to(d), 2), None, x0.to(d), gam.to(d), bet.to(d), 1e-5, want_y=True, split_form=1)
-    assert r1[1].form == 1 and torch.allclose(r1[0].cpu(), r0[0].cpu(), atol=2.0 ** -13 * float(r0[0].abs().max()), rtol=0)
-    y1 = r1[2].cpu().double()
-    hi, by, inv = _x8_parts(r1[1])
-    assert ((hi * inv[:, None] - y1).abs() <= 2.0 ** -10 * y1.abs().amax(1, keepdim=True)).all()
-    assert torch.equal(by[..., 0], _e4m3(hi * 2.0 ** -6))
-    lo = y1 / inv[:, None] - hi
-    assert ((by[..., 1] * 2.0 ** -6 - lo).abs() <= 2.0 ** -4 * lo.abs() + 2.0 ** -15).all()
 
 
 def test_split_output_bound_debug_check_heavy_tailed_weights(ops):

@@ -176,7 +176,7 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
     sd = make_state_dict(cfg, seed=21)
     inputs = make_inputs(cfg, task, size=96, batch=batch, seed=6, num_classes=7)            # batch 2: ragged prompts, padded key mask
     model = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3")
-    assert model.fuse_split and not model.llm_x8 and model.so_paired and any(model.paired.values())
+    assert model.fuse_split and model.so_paired and any(model.paired.values())
     kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
     torch.manual_seed(5)
     model_out_a = model.forward_logits(**kw)
@@ -194,32 +194,6 @@ def test_tiny_f16x3_fused_split_outputs_match_unfused(task, batch, keys):
             assert _rel(a[k], b[k]) < 2e-5, (i, k)
         if i + 1 < batch:
             a, b = model_out_a[i + 1], model_out_b[i + 1]
-
-
-def test_tiny_f16x3_llm_cross_terms_in_e4m3_match_three_products():
-    """The Phi GEMMs in the x8 operand form (cross terms lo.hi + hi.lo as one e4m3 dot product) against the same model with three f16 products
-    everywhere: the cross terms are 2^-11 of a product and carry 3 mantissa bits -> ~2^-16 per GEMM.  Both GEMMs ("both": every x8 kernel
-    path -- LayerNorm / GEMM epilogue / attention emitting the form, the x8 K loop with and without split-f16 output) and "w2" (a
-    three-product [k|v|q|fc1] emitting the x8 operand of [dense|fc2]).  The default is three products everywhere (PSALM.__init__)."""
-    cfg = PsalmConfig.tiny("panoptic")
-    sd = make_state_dict(cfg, seed=8)
-    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=3, num_classes=9)
-    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
-    st8, st3, std = {}, {}, {}
-    m8 = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8="both")
-    assert m8.llm_x8 and m8.w["llm0.w1"].form == 2 and m8.w["llm0.w2"].form == 2
-    a = m8.forward_logits(stages=st8, **kw)[0]
-    m3 = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8=False)
-    assert not m3.llm_x8 and m3.w["llm0.w1"].form == 0 and m3.w["llm0.w2"].form == 0
-    b = m3.forward_logits(stages=st3, **kw)[0]
-    assert _rel(st8["hidden_states"], st3["hidden_states"]) < 2e-4
-    assert 0 < _rel(a["pred_masks"], b["pred_masks"]) < 5e-4
-    assert not PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3").llm_x8          # the default: three products (PSALM.__init__)
-    md = PSALM(cfg, sd, ops=make_ops("emu"), precision="f16x3", llm_cross_fp8="w2")
-    assert md.llm_x8 and md.llm_x8_w2 and not md.llm_x8_w1 and md.w["llm0.w1"].form == 0 and md.w["llm0.w2"].form == 2
-    d = md.forward_logits(stages=std, **kw)[0]
-    assert _rel(std["hidden_states"], st3["hidden_states"]) < 2e-4
-    assert 0 < _rel(d["pred_masks"], b["pred_masks"]) < 5e-4
 
 
 def test_replica_shares_weights_owns_state_and_agrees():

@@ -9,8 +9,8 @@ instantiation dominates each.
   config 5  interactive (region prompts) 1024x1024 batch=2
 Per line: images/s (hipGraph replay, results consumed per step), the graph's own GPU time, parity min-over-seeds (mean / pooled IoU, IoU over
 reference masks of >= 64 pixels, mask-logit error, and for panoptic the semantic / panoptic agreement), the three launches that take most of
-a step with their share.  fp8 (e4m3) for WHOLE operands is not a mode any more (profiles/r03a_cross_term_precision.jsonl); for the cross
-terms of the Phi GEMMs it is the opt-in fast form PSALM(llm_cross_fp8="both") -- `--x8 both` runs the f16x3 lines in it."""
+a step with their share.  No fp8 form is a mode any more: e4m3 for whole operands (r02) and for the cross terms of the Phi GEMMs (r03) both
+missed the parity bar (profiles/r03a_cross_term_precision.jsonl, profiles/r03s_*) and were removed; configs[4] runs in the default arithmetic."""
 import json
 import os
 import sys
@@ -62,8 +62,7 @@ def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
         sd_cache.clear()
         sd_cache[task] = make_state_dict(cfg, seed=0)
     sd = sd_cache[task]
-    x8 = sys.argv[sys.argv.index("--x8") + 1] if "--x8" in sys.argv and precision == "f16x3" else None
-    model = PSALM(cfg, sd, precision=precision, use_graphs=True, llm_cross_fp8=x8)
+    model = PSALM(cfg, sd, precision=precision, use_graphs=True)
     model.graph_outputs = "alias"
     inputs = make_inputs(cfg, task, size=size, batch=batch, seed=3)
     inputs["images"] = inputs["images"].cuda()
@@ -75,8 +74,7 @@ def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
         model.eval_seg(**inputs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision, "llm_x8": bool(model.llm_x8),
-           "x8_gemms": [n for n, f in (("w1", getattr(model, "llm_x8_w1", False)), ("w2", getattr(model, "llm_x8_w2", False))) if f],
+    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision,
            "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 2)}
     ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
     if len(ents) == 1:

@@ -25,7 +25,7 @@ def main():
     for mode in modes:
         parts = mode.split("+")                      # e.g. f16x3+overlap, f16x3+overlap+nofuse (split-f16 outputs of GEMMs / attention off)
         nofuse = "nofuse" in parts                    # (then: un-permuted fc1 rows and three f16 products in the Phi GEMMs too)
-        m = PSALM(cfg, sd, precision=parts[0], use_graphs=True, **({"paired_split_stores": False, "llm_cross_fp8": False} if nofuse else {"paired_split_stores": False} if "nopair" in parts else {}))
+        m = PSALM(cfg, sd, precision=parts[0], use_graphs=True, **({"paired_split_stores": False} if nofuse else {"paired_split_stores": False} if "nopair" in parts else {}))
         m.overlap_streams = "overlap" in parts
         if nofuse:
             m.fuse_split = False

@@ -4,8 +4,7 @@ reordering).  Per pair and mode: mean / min / pooled mask IoU, pixel, semantic-a
 number of reference masks below 64 pixels (whose IoU is quantised in steps of 1/area).
 
     python tools/parity_seeds.py [task=panoptic] [size=1024] [pairs=0:0,0:1,0:2,1:1,2:2]  -> one JSON line per (pair, mode) + a summary line
-Modes: "f16x3" (default product mode: three f16 products everywhere) and "f16x3-x8both" (Phi GEMM cross terms in e4m3; PARITY_X8=w1,w2 adds
-the per-GEMM forms); PARITY_FP32=1 adds the
+Modes: "f16x3" (default product mode: three f16 products everywhere); PARITY_FP32=1 adds the
 exact-fp32 GPU mode (the oracle's arithmetic in another summation order: how far does an input move under re-ordering ALONE?).
 PARITY_BATCH: images per call."""
 import json
@@ -59,9 +58,7 @@ def main():
             torch.cuda.empty_cache()
             sd = make_state_dict(cfg, seed=wseed)
             sd_seed = wseed
-            models = {"f16x3": PSALM(cfg, sd, precision="f16x3"), "f16x3-x8both": PSALM(cfg, sd, precision="f16x3", llm_cross_fp8="both")}
-            for sel in [x for x in os.environ.get("PARITY_X8", "").split(",") if x]:      # e.g. PARITY_X8=w1,w2,both: which Phi GEMMs take e4m3 cross terms
-                models["f16x3-x8" + sel] = PSALM(cfg, sd, precision="f16x3", llm_cross_fp8=sel)
+            models = {"f16x3": PSALM(cfg, sd, precision="f16x3")}
             if os.environ.get("PARITY_FP32") == "1":          # the exact-fp32 GPU mode: same arithmetic as the oracle, another summation order
                 models["fp32"] = PSALM(cfg, sd, precision="fp32")
         inputs = make_inputs(cfg, task, size=size, batch=batch, seed=iseed)
@@ -74,7 +71,7 @@ def main():
             got = m.eval_seg(**inputs)
             torch.cuda.synchronize()
             for b in range(len(got)):
-                r = {"task": task, "size": size, "weights_seed": wseed, "inputs_seed": iseed, "image": b, "mode": mode, "llm_x8": bool(m.llm_x8),
+                r = {"task": task, "size": size, "weights_seed": wseed, "inputs_seed": iseed, "image": b, "mode": mode,
                      **compare(got[b], want[b]), "oracle_seconds": round(t_cpu, 1)}
                 rows.append(r)
                 print(json.dumps(r), flush=True)
