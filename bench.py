@@ -141,6 +141,10 @@ def main():
                  "init_process_group_seconds": round(t_pg, 3)}
         if not same:
             raise SystemExit(f"bench.py: rank {rank}: weights differ across ranks after the broadcast")
+        # RCCL writes a version banner to the C stdout at its first collective (r04a: "RCCL version : 2.26.6 ..." landed BEHIND the JSON line,
+        # flushed at exit): flush it now, on every rank, so that the JSON line is the last thing this job prints
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         if rank != 0:
             del sd                                              # placeholders are not needed any more
     inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
@@ -543,10 +547,14 @@ def main():
             "weight_broadcast": bcast,
             "per_rank_images_per_s": ({"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)} if per_rank else None),
         }
-        print(json.dumps(line))
     if use_dist:
-        dist.barrier()                                           # rank 0's instrumented steps / JSON line are done before anyone leaves
+        dist.barrier()                                           # rank 0's instrumented steps are done before anyone leaves
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                           # anything the native libraries still hold in the C stdout buffer goes first
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)                      # ... and the ONE JSON line is the last line of the job
 
 
 if __name__ == "__main__":

@@ -45,9 +45,16 @@ extern "C" int psalm_gemm_timeline_buffer(void* p) { return (int)hipMemcpyToSymb
             g_psalm_tl[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                    \
     } while (0)
 #define PSALM_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// ... and, in the same experiment build only, ABLATION of the slice-form phased K loop (tools/experiments/gemm_timeline.py --ablate): bit 1 no
+// global -> LDS copies, 2 no LDS fragment reads, 4 no matrix instructions, 8 no phase barriers -- results are garbage, the K-loop time of
+// each combination says which resource the loop waits for.  The product build compiles PSALM_ABL() to the constant 0.
+__device__ int g_psalm_ablate = 0;
+extern "C" int psalm_gemm_ablate(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_psalm_ablate), &v, sizeof(v)); }
+#define PSALM_ABL() g_psalm_ablate
 #else
 #define PSALM_TL(i) do { } while (0)
 #define PSALM_TL_DRAIN() do { } while (0)
+#define PSALM_ABL() 0
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -519,8 +526,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // as a (hi, lo) pair of 16-row chunks per wave instead of two 8-row chunks.
         static_assert(PH8 == 3, "slice form: copies inside the MFMA segment, bare barriers");
         constexpr int LO = (BM + BN) * BK;                       // the lo images sit behind the hi images of a stage
-        bf16x8 ah[2][2], al[2][2], bh[2], bl[2];                 // [m-tile of the half][kk] / [kk]
+        const int abl = PSALM_ABL();                             // (experiment build only; the constant 0 in the product)
+        bf16x8 ah[2][2] = {}, al[2][2] = {}, bh[2] = {}, bl[2] = {};   // [m-tile of the half][kk] / [kk]
         auto read_a = [&](const bf16_t* As_, int q) {
+            if (abl & 2) return;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int co = ((2 * kk + hi) ^ fsw) * 8;
@@ -533,6 +542,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             }
         };
         auto read_b = [&](const bf16_t* Bs_, int j) {
+            if (abl & 2) return;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int off = (b_row0 + 32 * j) * BK + ((2 * kk + hi) ^ fsw) * 8;
@@ -542,17 +552,20 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         };
         // half copies: which = 0 the hi image's chunk, 1 the lo image's, 2 both
         auto stage_a = [&](int buf, int koff, int q, int which = 2) {
+            if (abl & 1) return;
             bf16_t* d = smem[buf] + a_chunk(q) * RPC * BK;
             if (which != 1) psalm_glds16(asrc[q] + koff, d);
             if (which != 0) psalm_glds16(asrc[q] + fa.x3_kp + koff, d + LO);
         };
         auto stage_b = [&](int buf, int koff, int j, int which = 2) {
+            if (abl & 1) return;
             bf16_t* d = smem[buf] + BM * BK + b_chunk(j) * RPC * BK;
             if (which != 1) psalm_glds16(bsrc[j] + koff, d);
             if (which != 0) psalm_glds16(bsrc[j] + fa.x3_kp + koff, d + LO);
         };
         // 12 matrix instructions, the two accumulators of the quadrant alternating; the phase's two copies after the 2nd and the 8th
         auto mma = [&](int q, int j, auto&& copy) {
+            if (abl & 4) { copy(0); copy(1); return; }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -566,9 +579,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(ah[i][kk], bl[kk], acc[2 * q + i][j]);
             }
         };
-#define PHS_ENTER_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
+#define PHS_ENTER_MFMA() do { __builtin_amdgcn_sched_barrier(0); if (!(abl & 8)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
                               __builtin_amdgcn_s_setprio(1); } while (0)
-#define PHS_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); \
+#define PHS_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); if (!(abl & 8)) __builtin_amdgcn_s_barrier(); \
                               __builtin_amdgcn_sched_barrier(0); } while (0)
         // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
         auto tile_phases = [&](int t, int mode) {
@@ -1641,8 +1654,10 @@ static int g_ph8 = 3;
 static int g_x3_slice = 0;
 // split-f16 GEMMs on the 256 x 256 tile: 1 = the phased K loop walks 32-deep SLICES (four operand images per stage, three products per
 // phase: 2/3 of the L2 -> LDS bytes, fragment reads and barriers of the K-panel form, W hi fetched once), 0 = the K-panel form (3 Kp-long
-// loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).
-static int g_ph8_slice = 0;
+// loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).  r04a on MI355X (profiles/r04a_gemm_x3_sweep.json, back to back): Phi
+// [k|v|q|fc1] 158.9 -> 150.5 us, [dense|fc2] on 256^2 tiles 131.1 -> 124.4 us (128^2 tiles: 142), M65536 N256 K2304 231 -> 215; in the model
+// [k|v|q|fc1] 172 -> 164 us by events (profiles/r04a_bench_phased_slice_ab.txt): the default.
+static int g_ph8_slice = 1;
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
@@ -1676,6 +1691,11 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     // tiles (r02 sweep tools/bench_gemm_x3.py, profiles/r02f_gemm_x3_policies.json: M21504 N1024 K256 105 -> 67 us, M65536 N512 K128
     // 112 -> 77, M16384 N1024 K256 67 -> 53, M1024 N4096 K1024 57 -> 42)
     if (x3 && M > 192 && (K <= 1024 || (t128 < 448 && K <= 4096))) { BM = 64; BN = 128; no_split = true; }
+    // split-f16, few 256^2 tiles but a long K (Phi [dense|fc2]: 4 x 8 tiles, Kp 10240): the slice-form phased kernel on 256^2 tiles with the K
+    // range split 256 / tiles ways beats the 128^2 slice kernel (r04a: 142 -> 124 us); shorter K ranges per block lose to it (M1024 N1024 K4096,
+    // M256 N2048 K18432 in the same sweep: 16 / 32 slices of 256 / 576)
+    if (x3 && g_ph8 && g_ph8_slice && !g_tile_policy && M >= 512 && N >= 512 && t256 >= 24 && t256 < 160 && can_split &&
+        (long)K / 3 >= 1024 * ((256 + t256 - 1) / t256)) { BM = 256; BN = 256; no_split = false; }
     g_x3_auto_slice = false;
     if (x3 && !g_tile_policy && M > 192 && t128 < 200 && K >= 4096 && K <= 8192 && (long)cdiv(M, 64) * cdiv(N, 128) >= 200) {
         BM = 64; BN = 128; no_split = true; g_x3_auto_slice = true;      // long K, small grid: 64 x 128 slice form, no split-K

@@ -128,8 +128,59 @@ def main():
         json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
+def ablate():
+    """K-loop time of the slice-form phased kernel (policy 2581) with parts of the loop switched off (psalm_gemm_ablate, experiment build):
+    1 copies, 2 fragment reads, 4 matrix instructions, 8 phase barriers.  One JSON line per (shape, mask)."""
+    import ctypes
+    import torch
+    from psalm_amd import hip_ops as H
+    ops = H.Ops(LIB)
+    nslot = 1 << 16
+    tl = torch.zeros(nslot * 8, dtype=torch.int64, device="cuda")
+    assert ops._cdll_raw.psalm_gemm_timeline_buffer(ctypes.c_void_p(tl.data_ptr())) == 0
+    out = []
+    for (M, N, K, pol) in ((899, 14336, 2048, [2581]), (899, 2048, 10240, [256, 2581]), (4096, 4096, 4096, [256, 2581]), (899, 14336, 2048, [2580])):
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.05
+        asp, wsp = ops.split_f16(a), ops.split_f16(w)
+        c = torch.empty(M, N, device="cuda")
+        for p in pol:
+            ops.gemm_tile_policy(p)
+        try:
+            for mask in ((0,) if 2580 in pol else (0, 1, 2, 4, 8, 3, 5, 6, 9, 7, 11, 13, 14, 15)):
+                assert ops._cdll_raw.psalm_gemm_ablate(mask) == 0
+                for _ in range(3):
+                    ops.gemm_x3(asp, wsp, out=c)
+                tl.zero_()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops.gemm_x3(asp, wsp, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                t = tl.view(nslot, 8).cpu()
+                t = t[t[:, 0] > 0][:, :6].double()
+                us = (t - t[:, 0].min()) / 100.0
+                ph = us[:, 1:] - us[:, :-1]
+                row = {"shape": [M, N, K], "policy": pol, "kernel": ops.gemm_last_kernel(), "ablate": mask,
+                       "off": [n for b, n in ((1, "copies"), (2, "frag_reads"), (4, "mfma"), (8, "barriers")) if mask & b],
+                       "event_us": round(e0.elapsed_time(e1) * 1e3, 1), "k_loop_p50_us": round(float(ph[:, 2].quantile(.5)), 2),
+                       "k_loop_p90_us": round(float(ph[:, 2].quantile(.9)), 2), "span_us": round(float(us[:, 5].max()), 2)}
+                out.append(row)
+                print(json.dumps(row), flush=True)
+        finally:
+            ops._cdll_raw.psalm_gemm_ablate(0)
+            for p in (2580, 0):
+                ops.gemm_tile_policy(p)
+        del a, w, asp, wsp, c
+    if len(sys.argv) > 2:
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
+
+
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    elif "--ablate" in sys.argv:
+        ablate()
     else:
         main()
