@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     ap.add_argument("--gemm-policy", default="", help="comma-separated psalm_gemm_set_tile_policy codes applied before the first call (kernel A/B runs)")
+    ap.add_argument("--attn-fp32", action="store_true", help="f16x3: Phi attention on the fp32 matrix instruction (the r02 / r03 kernel) instead of split-f16 (A/B runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still run init_process_group('nccl'), the weight broadcast, the checksum all-reduce and the barriers (RCCL dry run on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
@@ -127,6 +128,8 @@ def main():
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
+    if args.attn_fp32:
+        model.attn_x3 = False
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"
@@ -288,9 +291,9 @@ def main():
                 Ho, Wo = (H_ + 2 * pd_ - ks) // st + 1, (W_ + 2 * pd_ - ks) // st + 1
                 geo = (B_ * Ho * Wo, Cout, ks * ks * Cin)
             elif name in ("psalm_gemm_x3", "psalm_gemm_x3_ln_split"):            # split-f16 GEMM: ALGORITHMIC flops 2 M N Kp of the fp32 product it stands for
-                geo = (a[13], a[14], a[6])
+                geo = (a[12], a[13], a[6])               # (A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, residual, ldr, C, ldc, M, N, ...)
             elif name == "psalm_gemm_x3_split":
-                geo = (a[11], a[12], a[6])
+                geo = (a[10], a[11], a[6])               # (A2, lda, a_scale, W2, ldw, w_scale, Kp, bias, C, ldc, M, N, ...)
             if geo is not None and kname and "mfma" not in kname and ("glds" in kname or "skinny_kernel<float, true>" in kname or "gemm_bf16" in kname):
                 by_shape.setdefault((kname, geo), []).append(ms)
         agg, shapes, kern = {}, {}, {}

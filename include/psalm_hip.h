@@ -25,8 +25,9 @@ extern "C" {
 const char* psalm_last_error(void);
 /* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
- * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04). */
-#define PSALM_ABI_VERSION 4
+ * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
+ * 5: psalm_causal_attention_x3[_split]. */
+#define PSALM_ABI_VERSION 5
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
 
@@ -192,6 +193,21 @@ int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k
                                      int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
                                      const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
                                      void* stream);
+
+/* Phi prefill attention in SPLIT-f16 arithmetic (precision "f16x3"; modeling_phi.py:189-245, :137-160, :92-122): S = Q.K^T and O = P.V as three
+ * f16 matrix-core products of 22-bit operands each (the arithmetic of psalm_gemm_x3), fp32 softmax statistics -- csrc/attention_x3.hip.
+ * Operands as psalm_causal_attention_f32 / _f32_split plus the bound of |v| the V operand is scaled under:
+ *   max over a_scale[0 .. n_scale) * bound_par[2] + bound_par[3]   (device pointers: the per-row inverse scales of the A operand of the GEMM
+ *   that produced q | k | v, and that GEMM's 4 bound parameters as psalm_gemm_x3_split takes them -- terms 2 / 3 bound the v rows).
+ * workspace: psalm_causal_attention_x3_workspace(B, L, heads) bytes, 16-byte aligned. */
+long psalm_causal_attention_x3_workspace(int B, int L, int heads);
+int psalm_causal_attention_x3(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off, const float* cos_table,
+                              const float* sin_table, const unsigned char* key_mask, const float* a_scale, int n_scale, const float* bound_par,
+                              void* workspace, int B, int L, int heads, int head_dim, int rot, void* stream);
+int psalm_causal_attention_x3_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split, int split_kp,
+                                    int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
+                                    const unsigned char* key_mask, const float* a_scale, int n_scale, const float* bound_par, void* workspace,
+                                    int B, int L, int heads, int head_dim, int rot, void* stream);
 
 /* zero `bytes` bytes / copy `bytes` bytes device-to-device, as stream operations (hipMemsetAsync / hipMemcpyAsync; graph-capturable) */
 int psalm_memset_zero(void* p, long bytes, void* stream);

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
     jobs = []
     objs = []
     for s in srcs:

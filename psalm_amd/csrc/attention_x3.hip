@@ -1,0 +1,370 @@
+// Phi prefill attention in SPLIT-f16 arithmetic (precision "f16x3"; modeling_phi.py:189-245 attention core, :137-160 / :92-122 partial RoPE):
+// the two contractions of the attention -- S = Q.K^T over the 64 head dims and O = P.V over the keys -- run on the f16 matrix cores as
+// three products of 22-bit operands (hi.hi + lo.hi + hi.lo, fp32 accumulate: the arithmetic of every GEMM of this mode, csrc/gemm.hip)
+// instead of on the fp32 matrix instruction; softmax statistics, the online rescale and the merge stay fp32.
+//
+// Why: r04a kernel trace -- causal_attention_f32_splitk_kernel 64.1 us per Phi layer, 1.54 ms per image.  A 32-key tile costs 64
+// v_mfma_f32_32x32x2_f32 = 4096 matrix cycles per wave; here it costs 24 v_mfma_f32_32x32x16_f16 = 768, and the kernel's bound moves from
+// the matrix pipe (37 % busy behind 430 VALU instructions per tile, r02n SQ counters) to that VALU work alone.
+//
+// Structure = the fp32 kernel's (csrc/attention.hip causal_attention_f32_splitk_kernel): a block owns a balanced PAIR of 32-query tiles, its
+// 4 wavefronts take every 4th key tile, swapped products (S^T = K.Q^T, O^T += V^T.P^T: P goes from the accumulators straight into the
+// B operand), private online-softmax state per wave, merge through LDS.  What differs is the operand form, made by the pre-pass:
+//   Qs / Ks (b, h, Lp, 128) f16 = [hi (64) | lo (64)] rows of the RoPE'd (and, Q, pre-scaled) vectors under a per-ROW power-of-two scale
+//           (row maximum in [2^13, 2^14), as psalm_split_f16), 1 / scale in qinv / kinv (b, h, Lp); kinv = 0 marks a masked / padded key;
+//   Vth / Vtl (b, h, 64, Lp) f16 = V TRANSPOSED (rows = head dims, columns = keys) as hi / lo under ONE power-of-two scale for the whole
+//           tensor, derived from a bound of |v| the caller knows before the kernel runs (GemmFastArgs::so bound: max_r a_scale[r] * par[2] +
+//           par[3], the term psalm_gemm_x3_split's row scales already carry for the attention output); the keys of every 16-key group
+//           are stored in the order [0-3, 8-11, 4-7, 12-15] so that a lane's 8 contraction slots of a matrix instruction -- keys
+//           16 s + 8 (e >> 2) + 4 hi + (e & 3), the keys its S^T accumulator elements 8 s + e belong to -- are one 16-byte load.
+//   P (probabilities in [0, 1]) is split in registers: hi = f16(p), lo = f16(p - hi).
+#include "common.h"
+
+typedef float ax3_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 ax3_f16x8 __attribute__((ext_vector_type(8)));
+
+// power-of-two scale of one row from its maximum: amax * sc in [2^13, 2^14)  (psalm_split_f16's rule)
+__device__ __forceinline__ void ax3_row_scale(float amax, float& sc, float& inv) {
+    int se = 13 - ((int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const bool zero = !(amax > 0.f) || !(amax < 3.0e38f);
+    sc = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 + se) << 23);
+    inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
+}
+__device__ __forceinline__ void ax3_emit8(const float* v, float sc, unsigned short* hi_dst, unsigned short* lo_dst) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned h0, h1, l0, l1;
+        psalm_split_words(v[2 * k] * sc, h0, l0);
+        psalm_split_words(v[2 * k + 1] * sc, h1, l1);
+        hw[k] = h0 | (h1 << 16);
+        lw[k] = l0 | (l1 << 16);
+    }
+    *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+}
+
+// Pre-pass: block = 32 tokens of one (batch, head); thread -> token tid / 8, head dims 8 (tid % 8) .. + 7.
+__global__ void __launch_bounds__(256) phi_rope_prep_x3_kernel(const float* __restrict__ base, long ld, int q_off, int k_off, int v_off,
+                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                               const unsigned char* __restrict__ key_mask, unsigned short* __restrict__ Qs,
+                                                               unsigned short* __restrict__ Ks, float* __restrict__ qinv, float* __restrict__ kinv,
+                                                               unsigned short* __restrict__ Vth, unsigned short* __restrict__ Vtl,
+                                                               float* __restrict__ vinv, const float* __restrict__ a_scale, int n_scale,
+                                                               const float* __restrict__ bound_par, int L, int Lp, int heads, float scale) {
+    constexpr int HD = 64, ROT = 32, half = 16, VP = 40;                   // VP: LDS row pitch of the 32-key V tile (16-byte aligned, conflict-spread)
+    __shared__ __attribute__((aligned(16))) unsigned short Vh[HD * VP], Vl[HD * VP];
+    __shared__ float red[4];
+    const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int tl = tid >> 3, c0 = (tid & 7) * 8, t = blockIdx.x * 32 + tl;
+    const long bh = (long)b * heads + h;
+    // ---- the V scale: one power of two for the tensor, from the caller's bound  max_r a_scale[r] * par[2] + par[3]  of |v|
+    float gm = 0.f;
+    for (int i = tid; i < n_scale; i += 256) gm = fmaxf(gm, a_scale[i]);
+    gm = wave_max(gm);
+    if ((tid & 63) == 0) red[tid >> 6] = gm;
+    __syncthreads();
+    gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float vbound = fmaf(gm, bound_par[2], bound_par[3]);
+    vbound = fminf(fmaxf(vbound, 7.888609e-31f), 1.2676506e30f);          // [2^-100, 2^100]
+    const unsigned eb = (__builtin_bit_cast(unsigned, vbound) >> 23) & 0xffu;
+    const float vsc = __builtin_bit_cast(float, (266u - eb) << 23);        // bound * vsc in [2^12, 2^13)
+    if (tid == 0 && blockIdx.x == 0) vinv[bh] = __builtin_bit_cast(float, (eb - 12u) << 23);
+    float q[8], k[8], v[8];
+    const bool live = t < L;
+    if (live) {
+        const float* p = base + ((long)b * L + t) * ld;
+        ld8(p + q_off + h * HD + c0, q);
+        ld8(p + k_off + h * HD + c0, k);
+        ld8(p + v_off + h * HD + c0, v);
+        if (c0 < ROT) {
+            float qo[8], ko[8], cs[8], sn[8];
+            const int oc = c0 < half ? c0 + half : c0 - half;
+            ld8(p + q_off + h * HD + oc, qo);
+            ld8(p + k_off + h * HD + oc, ko);
+            ld8(cosT + (long)t * ROT + c0, cs);
+            ld8(sinT + (long)t * ROT + c0, sn);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                q[i] = q[i] * cs[i] + (c0 < half ? -qo[i] : qo[i]) * sn[i];
+                k[i] = k[i] * cs[i] + (c0 < half ? -ko[i] : ko[i]) * sn[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] *= scale;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { q[i] = 0.f; k[i] = 0.f; v[i] = 0.f; }
+    }
+    // ---- Q / K rows: exact row maximum over the 8 lanes of the token
+    float aq = 0.f, ak = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { aq = fmaxf(aq, fabsf(q[i])); ak = fmaxf(ak, fabsf(k[i])); }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { aq = fmaxf(aq, __shfl_xor(aq, o)); ak = fmaxf(ak, __shfl_xor(ak, o)); }
+    float sq, iq, sk, ik;
+    ax3_row_scale(aq, sq, iq);
+    ax3_row_scale(ak, sk, ik);
+    if (t < Lp) {
+        unsigned short* qd = Qs + (bh * Lp + t) * 128 + c0;
+        unsigned short* kd = Ks + (bh * Lp + t) * 128 + c0;
+        ax3_emit8(q, sq, qd, qd + 64);
+        ax3_emit8(k, sk, kd, kd + 64);
+        if (c0 == 0) {
+            qinv[bh * Lp + t] = iq;
+            kinv[bh * Lp + t] = (live && key_mask[(long)b * L + t]) ? ik : 0.f;       // 0: masked / padded key
+        }
+    }
+    // ---- V: transpose the 32 x 64 tile through LDS; key tl of the tile goes to position 16 (tl >> 4) + perm(tl & 15)
+    {
+        const int jj = tl & 15;
+        const int pos = 16 * (tl >> 4) + (jj < 4 ? jj : (jj < 8 ? jj + 4 : (jj < 12 ? jj - 4 : jj)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned hw, lw;
+            psalm_split_words(v[i] * vsc, hw, lw);
+            Vh[(c0 + i) * VP + pos] = (unsigned short)hw;
+            Vl[(c0 + i) * VP + pos] = (unsigned short)lw;
+        }
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, ch = (tid & 3) * 8;                       // head dim d, 8 key positions
+        const long o = (bh * HD + d) * Lp + (long)blockIdx.x * 32 + ch;
+        *reinterpret_cast<psalm_u32x4*>(Vth + o) = *reinterpret_cast<const psalm_u32x4*>(&Vh[d * VP + ch]);
+        *reinterpret_cast<psalm_u32x4*>(Vtl + o) = *reinterpret_cast<const psalm_u32x4*>(&Vl[d * VP + ch]);
+    }
+}
+
+// SO = true: the output leaves as split-f16 operand columns (hi at `out` + o_off, lo so_kp f16 further; `out` is then the f16 buffer, ldo its
+// row stride in f16) under the per-row scales 1 / so_inv[row] psalm_gemm_x3_split chose for the same rows.
+template <bool SO>
+__global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(2)
+causal_attention_x3_kernel(const unsigned short* __restrict__ Qs, const unsigned short* __restrict__ Ks, const float* __restrict__ qinv,
+                           const float* __restrict__ kinv, const unsigned short* __restrict__ Vth, const unsigned short* __restrict__ Vtl,
+                           const float* __restrict__ vinv, float* out, long ldo, int o_off, int L, int Lp, int heads,
+                           const float* __restrict__ so_inv, int so_kp) {
+    constexpr int HD = 64, OS = HD + 4;
+    __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
+    __shared__ float Ml[4][2][32];                                        // per-wave (m, l) per query
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, nqt = Lp / 32;
+    const long bh = (long)b * heads + h;
+    const float vi = vinv[bh];
+    const int npass = (int)(nqt - 1 - blockIdx.x) > (int)blockIdx.x ? 2 : 1;      // query tiles (nqt-1-p, p): nqt + 1 key tiles whatever p
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qt = pass == 0 ? nqt - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int w0 = pass ? 3 - wave : wave;                                // second tile: key tiles dealt in the opposite wave order
+    if (pass) __syncthreads();                                            // the first tile's merge has been read out of Os / Ml
+    const int qi = qt * 32 + n32;                                         // this lane's query column
+    psalm_u32x4 qh[4], ql[4];
+    {
+        const unsigned short* p = Qs + (bh * Lp + qi) * 128 + 8 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qh[c] = *reinterpret_cast<const psalm_u32x4*>(p + 16 * c);
+            ql[c] = *reinterpret_cast<const psalm_u32x4*>(p + 64 + 16 * c);
+        }
+    }
+    const float qi_inv = qinv[bh * Lp + qi];
+    ax3_f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    for (int kt = w0; kt <= qt; kt += 4) {                                // key tiles 0..qt (the diagonal tile is qt)
+        // ---- fragments of this tile, all loads issued up front
+        psalm_u32x4 kh[4], kl[4], vh[2][2], vl[2][2];
+        {
+            const unsigned short* kp = Ks + (bh * Lp + kt * 32 + n32) * 128 + 8 * hi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kh[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 16 * c);
+                kl[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 64 + 16 * c);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const long o = (bh * HD + 32 * dt + n32) * Lp + kt * 32 + 8 * hi;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                vh[dt][s] = *reinterpret_cast<const psalm_u32x4*>(Vth + o + 16 * s);
+                vl[dt][s] = *reinterpret_cast<const psalm_u32x4*>(Vtl + o + 16 * s);
+            }
+        }
+        float ksc[16];                                                    // inverse scale of key (r & 3) + 8 (r >> 2) + 4 hi; 0 = masked
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const psalm_f32x4 t4 = *reinterpret_cast<const psalm_f32x4*>(kinv + bh * Lp + kt * 32 + 8 * g + 4 * hi);
+            ksc[4 * g] = t4.x; ksc[4 * g + 1] = t4.y; ksc[4 * g + 2] = t4.z; ksc[4 * g + 3] = t4.w;
+        }
+        // ---- S^T = K . Q^T: three products, two accumulators (even / odd head-dim chunks) to halve the dependent chain
+        ax3_f32x16 sa, sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            const ax3_f16x8 k0h = __builtin_bit_cast(ax3_f16x8, kh[c]), k0l = __builtin_bit_cast(ax3_f16x8, kl[c]);
+            const ax3_f16x8 k1h = __builtin_bit_cast(ax3_f16x8, kh[c + 1]), k1l = __builtin_bit_cast(ax3_f16x8, kl[c + 1]);
+            const ax3_f16x8 q0h = __builtin_bit_cast(ax3_f16x8, qh[c]), q0l = __builtin_bit_cast(ax3_f16x8, ql[c]);
+            const ax3_f16x8 q1h = __builtin_bit_cast(ax3_f16x8, qh[c + 1]), q1l = __builtin_bit_cast(ax3_f16x8, ql[c + 1]);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, q0h, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, q1h, sb, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0l, q0h, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1l, q1h, sb, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, q0l, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, q1l, sb, 0, 0, 0);
+        }
+        float sv[16];
+        float mc = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = (kt * 32 + j <= qi) && ksc[r] > 0.f;
+            sv[r] = ok ? (sa[r] + sb[r]) * (ksc[r] * qi_inv) : -3.0e38f;
+            mc = fmaxf(mc, sv[r]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
+        unsigned ph[8], pl[8];                                            // P as packed f16 pairs: word w = elements 2w, 2w + 1
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float p0 = sv[2 * w] > -1.0e38f ? __expf(sv[2 * w] - mn) : 0.f;
+            const float p1 = sv[2 * w + 1] > -1.0e38f ? __expf(sv[2 * w + 1] - mn) : 0.f;
+            psum += p0 + p1;
+            unsigned h0, h1, l0, l1;
+            psalm_split_words(p0, h0, l0);
+            psalm_split_words(p1, h1, l1);
+            ph[w] = h0 | (h1 << 16);
+            pl[w] = l0 | (l1 << 16);
+        }
+        psum += __shfl_xor(psum, 32);
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // ---- O^T += V^T . P^T: contraction slots (s, hi, e) = accumulator elements 8 s + e of this lane = keys 16 s + 8 (e >> 2) + 4 hi + (e & 3)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const ax3_f16x8 pH = __builtin_bit_cast(ax3_f16x8, psalm_u32x4{ph[4 * s], ph[4 * s + 1], ph[4 * s + 2], ph[4 * s + 3]});
+            const ax3_f16x8 pL = __builtin_bit_cast(ax3_f16x8, psalm_u32x4{pl[4 * s], pl[4 * s + 1], pl[4 * s + 2], pl[4 * s + 3]});
+            const ax3_f16x8 v0h = __builtin_bit_cast(ax3_f16x8, vh[0][s]), v0l = __builtin_bit_cast(ax3_f16x8, vl[0][s]);
+            const ax3_f16x8 v1h = __builtin_bit_cast(ax3_f16x8, vh[1][s]), v1l = __builtin_bit_cast(ax3_f16x8, vl[1][s]);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pH, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pH, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, pH, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, pH, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pL, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pL, o1, 0, 0, 0);
+        }
+    }
+    // ---- merge the 4 key-interleaved states: O = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M)
+    {
+        float* ow = &Os[wave][n32 * OS + 4 * hi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                    // rows d = 8g + 4hi + {0..3} (+32 for the second d-tile)
+            *reinterpret_cast<psalm_f32x4*>(ow + 8 * g) = psalm_f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+            *reinterpret_cast<psalm_f32x4*>(ow + 32 + 8 * g) = psalm_f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+        }
+        if (hi == 0) { Ml[wave][0][n32] = m; Ml[wave][1][n32] = l; }
+    }
+    __syncthreads();
+    {
+        const int q = tid >> 3, d0 = (tid & 7) * 8;                       // thread -> query q of the tile, 8 head dims
+        const int tq = qt * 32 + q;
+        if (tq < L) {
+            float M = -3.0e38f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) M = fmaxf(M, Ml[w][0][q]);
+            float Lsum = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float mw_ = Ml[w][0][q];
+                const float f = mw_ > -1.0e38f ? __expf(mw_ - M) : 0.f;
+                Lsum += Ml[w][1][q] * f;
+                const psalm_f32x4 a = *reinterpret_cast<const psalm_f32x4*>(&Os[w][q * OS + d0]);
+                const psalm_f32x4 c = *reinterpret_cast<const psalm_f32x4*>(&Os[w][q * OS + d0 + 4]);
+                acc[0] += a.x * f; acc[1] += a.y * f; acc[2] += a.z * f; acc[3] += a.w * f;
+                acc[4] += c.x * f; acc[5] += c.y * f; acc[6] += c.z * f; acc[7] += c.w * f;
+            }
+            const float inv = (Lsum > 0.f ? 1.f / Lsum : 0.f) * vi;       // ... and the V scale (a power of two)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] *= inv;
+            if constexpr (SO) {
+                const long row = (long)b * L + tq;
+                const float sc = 1.f / so_inv[row];                      // power of two: exact
+                unsigned short* d = reinterpret_cast<unsigned short*>(out) + row * ldo + o_off + h * HD + d0;
+                ax3_emit8(acc, sc, d, d + so_kp);
+            } else {
+                st8(out + ((long)b * L + tq) * ldo + o_off + h * HD + d0, acc);
+            }
+        }
+    }
+    }
+}
+
+// workspace: Qs, Ks (B heads Lp 128 f16 each) | Vth, Vtl (B heads 64 Lp f16 each) | qinv, kinv (B heads Lp f32) | vinv (B heads f32)
+extern "C" long psalm_causal_attention_x3_workspace(int B, int L, int heads) {
+    const long Lp = (L + 31) / 32 * 32, bh = (long)B * heads;
+    return 2 * bh * Lp * 128 * 2 + 2 * bh * 64 * Lp * 2 + 2 * bh * Lp * 4 + bh * 4 + 64;
+}
+
+// Phi prefill attention on fp32 q | k | v columns in split-f16 arithmetic.  Operands as psalm_causal_attention_f32[_split]; in addition the
+// bound of |v| the V operand is scaled under:  max over a_scale[0 .. n_scale) * bound_par[2] + bound_par[3]  (device pointers; bound_par = the
+// 4 floats psalm_gemm_x3_split takes for the GEMM that produced q | k | v, whose terms 2 / 3 are the weight-L1 / bias bound of the v rows;
+// a_scale = the per-row inverse scales of that GEMM's A operand).  split_inv == NULL: fp32 output rows at `out` + o_off, row stride ldo.
+static int causal_attention_x3_impl(const float* qkv, long ld, int q_off, int k_off, int v_off, void* out, long ldo, int o_off,
+                                    const float* cos_table, const float* sin_table, const unsigned char* key_mask, const float* a_scale,
+                                    int n_scale, const float* bound_par, void* workspace, int B, int L, int heads, int head_dim, int rot,
+                                    void* stream, const float* so_inv, int so_kp, const char* name) {
+    PSALM_CHECK_ARG(head_dim == 64 && rot == 32, "psalm_causal_attention_x3: head_dim 64, rotary dim 32 (Phi-1.5)");
+    PSALM_CHECK_ARG(ld % 4 == 0 && q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && (uintptr_t)qkv % 16 == 0 &&
+                        (uintptr_t)out % 16 == 0 && workspace && (uintptr_t)workspace % 16 == 0 &&
+                        (so_inv ? (ldo % 8 == 0 && o_off % 8 == 0 && so_kp % 8 == 0) : (ldo % 4 == 0 && o_off % 4 == 0)),
+                    "psalm_causal_attention_x3: 16-byte aligned rows / offsets and a workspace");
+    PSALM_CHECK_ARG(a_scale && n_scale > 0 && bound_par, "psalm_causal_attention_x3: the bound of |v| (a_scale rows, bound_par) is required");
+    if (B == 0 || L == 0) return 0;
+    const long Lp = (L + 31) / 32 * 32, bh = (long)B * heads;
+    unsigned short* Qs = (unsigned short*)workspace;
+    unsigned short* Ks = Qs + bh * Lp * 128;
+    unsigned short* Vth = Ks + bh * Lp * 128;
+    unsigned short* Vtl = Vth + bh * 64 * Lp;
+    float* qinv = (float*)(Vtl + bh * 64 * Lp);
+    float* kinv = qinv + bh * Lp;
+    float* vinv = kinv + bh * Lp;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(phi_rope_prep_x3_kernel, dim3((unsigned)(Lp / 32), heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, v_off, cos_table,
+                       sin_table, key_mask, Qs, Ks, qinv, kinv, Vth, Vtl, vinv, a_scale, n_scale, bound_par, L, (int)Lp, heads, scale);
+    const int nqt = (int)(Lp / 32);
+    const dim3 grid((nqt + 1) / 2, heads, B);
+    if (so_inv)
+        hipLaunchKernelGGL(causal_attention_x3_kernel<true>, grid, dim3(256), 0, s, (const unsigned short*)Qs, (const unsigned short*)Ks,
+                           (const float*)qinv, (const float*)kinv, (const unsigned short*)Vth, (const unsigned short*)Vtl, (const float*)vinv,
+                           (float*)out, ldo, o_off, L, (int)Lp, heads, so_inv, so_kp);
+    else
+        hipLaunchKernelGGL(causal_attention_x3_kernel<false>, grid, dim3(256), 0, s, (const unsigned short*)Qs, (const unsigned short*)Ks,
+                           (const float*)qinv, (const float*)kinv, (const unsigned short*)Vth, (const unsigned short*)Vtl, (const float*)vinv,
+                           (float*)out, ldo, o_off, L, (int)Lp, heads, (const float*)nullptr, 0);
+    PSALM_LAUNCH_END(name);
+}
+extern "C" int psalm_causal_attention_x3(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,
+                                         const float* cos_table, const float* sin_table, const unsigned char* key_mask, const float* a_scale,
+                                         int n_scale, const float* bound_par, void* workspace, int B, int L, int heads, int head_dim, int rot,
+                                         void* stream) {
+    return causal_attention_x3_impl(qkv, ld, q_off, k_off, v_off, out, ldo, o_off, cos_table, sin_table, key_mask, a_scale, n_scale, bound_par,
+                                    workspace, B, L, heads, head_dim, rot, stream, nullptr, 0, "psalm_causal_attention_x3");
+}
+extern "C" int psalm_causal_attention_x3_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split,
+                                               int split_kp, int split_col_off, const float* split_inv, const float* cos_table,
+                                               const float* sin_table, const unsigned char* key_mask, const float* a_scale, int n_scale,
+                                               const float* bound_par, void* workspace, int B, int L, int heads, int head_dim, int rot,
+                                               void* stream) {
+    PSALM_CHECK_ARG(split_out && split_inv && ld_split >= 2L * split_kp && split_col_off + heads * 64 <= split_kp,
+                    "psalm_causal_attention_x3_split: split buffer rows of >= 2*split_kp f16 and the row scales");
+    return causal_attention_x3_impl(qkv, ld, q_off, k_off, v_off, split_out, ld_split, split_col_off, cos_table, sin_table, key_mask, a_scale,
+                                    n_scale, bound_par, workspace, B, L, heads, head_dim, rot, stream, split_inv, split_kp,
+                                    "psalm_causal_attention_x3_split");
+}

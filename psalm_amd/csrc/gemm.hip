@@ -89,7 +89,9 @@ __device__ __forceinline__ float psalm_erff(float a) {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_GELU) return 0.5f * v * (1.f + psalm_erff(v * 0.70710678118654752440f));
+    // (explicit fmaf: the expression is instantiated in several epilogues whose outputs are compared bit for bit -- r04b: the compiler had
+    //  contracted 0.5 v (1 + erf) differently in two of them, 1 ulp apart on the hardware)
+    if (act == ACT_GELU) { const float hv = 0.5f * v; return fmaf(hv, psalm_erff(v * 0.70710678118654752440f), hv); }
     if (act == ACT_GELU_NEW) {
         // 0.5 v (1 + tanh u) = v / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of the library tanhf (~4x the instructions; the
         // activation runs once per output element in the epilogue's critical path -- 65536 per 256 x 256 tile).  exp(-2u) = inf for
@@ -874,8 +876,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     x[r] = acc[i][j][r];
-                    if constexpr (X3) x[r] *= asc[r] * wsc[j];
-                    x[r] += bias_c[j];
+                    if constexpr (X3) x[r] = fmaf(x[r], asc[r] * wsc[j], bias_c[j]);
+                    else x[r] += bias_c[j];
                     if (actc[j] && !post) x[r] = fmaxf(x[r], 0.f);           // ReLU (the only activation on this path)
                     x[r] += rv[r];
                     if (actc[j] && post) x[r] = fmaxf(x[r], 0.f);
@@ -925,7 +927,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 gmax = wave_max(gmax);
             }
             const float p0 = fa.so_par[0], p1 = fa.so_par[1];
-            const float floor_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax * fa.so_par[2] + fa.so_par[3])));
+            const float floor_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaf(gmax, fa.so_par[2], fa.so_par[3]))));
             float wsc[TN], bias_c[TN];
             bool actc[TN], soc[TN];
 #pragma unroll
@@ -958,14 +960,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                             const int row = row0 + (r & 3) + 8 * (r >> 2);
                             asc[r] = fa.a_scale[min(row, g.M - 1)];
                             float inv_;
-                            split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
+                            split_scale_from_bound(fmaxf(fmaf(asc[r], p0, p1), floor_), sc[r], inv_);
                             if (writes_inv && row < g.M) fa.so_inv[row] = inv_;
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = row0 + (r & 3) + 8 * (r >> 2);
-                            float x0 = acc[i][0][r] * (asc[r] * wsc[0]) + bias_c[0];
-                            float x1 = acc[i][1][r] * (asc[r] * wsc[1]) + bias_c[1];
+                            float x0 = fmaf(acc[i][0][r], asc[r] * wsc[0], bias_c[0]);
+                            float x1 = fmaf(acc[i][1][r], asc[r] * wsc[1], bias_c[1]);
                             const float y0 = apply_act_t<A>(x0, act), y1 = apply_act_t<A>(x1, act);
                             x0 = actc[0] ? y0 : x0;
                             x1 = actc[1] ? y1 : x1;
@@ -1006,13 +1008,13 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                         for (int r = 0; r < 16; ++r) {
                             asc[r] = fa.a_scale[min(bm + lrow0 + (r & 3) + 8 * (r >> 2), g.M - 1)];
                             float inv_;
-                            split_scale_from_bound(fmaxf(asc[r] * p0 + p1, floor_), sc[r], inv_);
+                            split_scale_from_bound(fmaxf(fmaf(asc[r], p0, p1), floor_), sc[r], inv_);
                         }
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                float x = acc[i][j][r] * (asc[r] * wsc[j]) + bias_c[j];
+                                float x = fmaf(acc[i][j][r], asc[r] * wsc[j], bias_c[j]);
                                 const float y = apply_act_t<A>(x, act);
                                 x = actc[j] ? y : x;
                                 unsigned hw_, sw_;
@@ -1045,7 +1047,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                         *reinterpret_cast<u32x4_s*>(d + fa.so_kp) = lv;
                         if (col0 == fa.so_col_start) {
                             float sc_, inv_;
-                            split_scale_from_bound(fmaxf(fa.a_scale[row] * p0 + p1, floor_), sc_, inv_);
+                            split_scale_from_bound(fmaxf(fmaf(fa.a_scale[row], p0, p1), floor_), sc_, inv_);
                             fa.so_inv[row] = inv_;
                         }
                     } else {                                                       // fp32 columns of a tile that straddles so_col_start
@@ -1111,7 +1113,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             }
             so_p0 = fa.so_par[0];
             so_p1 = fa.so_par[1];
-            so_floor = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax * fa.so_par[2] + fa.so_par[3])));
+            so_floor = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaf(gmax, fa.so_par[2], fa.so_par[3]))));
         }
     }
 #pragma unroll 1
@@ -1191,7 +1193,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             if constexpr (SO) {
                 if (so_here) {
                     float sc, inv;
-                    split_scale_from_bound(fmaxf(asc[itc] * so_p0 + so_p1, so_floor), sc, inv);
+                    split_scale_from_bound(fmaxf(fmaf(asc[itc], so_p0, so_p1), so_floor), sc, inv);
                     unsigned hw[4], lw[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

@@ -48,7 +48,7 @@ def _dt(t: torch.Tensor) -> int:
         raise PsalmHipError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
 
 
-ABI_VERSION = 4        # == PSALM_ABI_VERSION of include/psalm_hip.h (tests/test_0_abi.py compares the two and the built library's answer)
+ABI_VERSION = 5        # == PSALM_ABI_VERSION of include/psalm_hip.h (tests/test_0_abi.py compares the two and the built library's answer)
 
 
 class _ProfiledLib:
@@ -628,6 +628,42 @@ class Ops:
                                                        self._p(split_inv), self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
                                                        B, L, heads, head_dim, rot, self._stream())
         self._check(rc, "psalm_causal_attention_f32_split")
+        return split_out
+
+    def _causal_x3_ws(self, B, L, heads):
+        self.lib.psalm_causal_attention_x3_workspace.restype = c_long
+        nbytes = self.lib.psalm_causal_attention_x3_workspace(B, L, heads)
+        key = ("causal_x3_ws", nbytes)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def causal_attention_x3(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot, a_scale, bound_par):
+        """causal_attention on fp32 q | k | v columns in split-f16 arithmetic (psalm_causal_attention_x3): Q.K^T and P.V as three f16
+        matrix-core products of 22-bit operands.  a_scale (n,) / bound_par (4,) float32: the bound of |v|, max(a_scale) * bound_par[2] +
+        bound_par[3] (see psalm_gemm_x3_split)."""
+        if buf.dtype != torch.float32 or out.dtype != torch.float32 or a_scale.dtype != torch.float32 or bound_par.numel() != 4:
+            raise PsalmHipError("causal_attention_x3: float32 buffers, float32 a_scale, 4 bound parameters")
+        rc = self.lib.psalm_causal_attention_x3(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out), c_long(out.stride(0)),
+                                                o_off, self._p(cos), self._p(sin), self._p(key_mask), self._p(a_scale), int(a_scale.numel()),
+                                                self._p(bound_par), self._p(self._causal_x3_ws(B, L, heads)), B, L, heads, head_dim, rot,
+                                                self._stream())
+        self._check(rc, "psalm_causal_attention_x3")
+        return out
+
+    def causal_attention_x3_split(self, buf, q_off, k_off, v_off, split_out, split_inv, split_col_off, cos, sin, key_mask, B, L, heads,
+                                  head_dim, rot, a_scale, bound_par):
+        """... whose output goes, in split-f16 form under the row scales 1/split_inv, into columns split_col_off.. of `split_out`
+        (as causal_attention_split)."""
+        if buf.dtype != torch.float32 or split_out.dtype != torch.float16 or split_inv.dtype != torch.float32 or a_scale.dtype != torch.float32:
+            raise PsalmHipError("causal_attention_x3_split: float32 qkv buffer, float16 split buffer, float32 scales")
+        rc = self.lib.psalm_causal_attention_x3_split(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._p(split_out),
+                                                      c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off, self._p(split_inv),
+                                                      self._p(cos), self._p(sin), self._p(key_mask), self._p(a_scale), int(a_scale.numel()),
+                                                      self._p(bound_par), self._p(self._causal_x3_ws(B, L, heads)), B, L, heads, head_dim, rot,
+                                                      self._stream())
+        self._check(rc, "psalm_causal_attention_x3_split")
         return split_out
 
     def mha_attention(self, q, k, v, B, Lq, Lk, heads, mask=None, row_all_masked=None):

@@ -132,6 +132,9 @@ class PSALM:
         # accumulators (psalm_gemm_x3_split, `paired`) -- results bit for bit those of the un-permuted layout.  A construction-time
         # choice (the weights are laid out for it): such a model cannot be switched to fuse_split = False afterwards.
         self.so_paired = self.fuse_split if paired_split_stores is None else (bool(paired_split_stores) and self.fuse_split)
+        # f16x3: the Phi attention's two contractions (Q.K^T, P.V) in the mode's own arithmetic -- three f16 matrix-core products of 22-bit
+        # operands, fp32 softmax -- instead of on the fp32 matrix instruction (r04: 64 -> ? us per layer; False = the r02 / r03 kernel)
+        self.attn_x3 = self.fuse_split
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
@@ -764,8 +767,12 @@ class PSALM:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
                                 split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True,
                                 paired=self.paired.get(f"llm{i}", False))
-                o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                         cfg.rotary_dim)
+                if self.attn_x3:                     # Q.K^T and P.V as three f16 products of 22-bit operands (csrc/attention_x3.hip)
+                    o.causal_attention_x3_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
+                                                cfg.rotary_dim, h.inv_scale, w[f"llm{i}.bnd"])
+                else:                                # ... on the fp32 matrix instruction
+                    o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
+                                             cfg.rotary_dim)
                 if last or Hd % 64 != 0 or Hd > 2048:
                     x = o.gemm(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                     h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \
@@ -973,7 +980,10 @@ class PSALM:
         extra = tuple((info.get("height"), info.get("width")) if isinstance(info, dict) else None for info in (seg_info or []))
         ikey = (tuple(images.shape), video, class_name_embedding_indices is not None, refer_embedding_indices is not None, extra) + tuple(
             ident(t) for t in [input_ids, attention_mask, class_name_ids, cls_indices] + list(token_refer_id or []) + pms)
-        cacheable = all(pm is None or torch.is_tensor(pm) for pm in pms)        # (an ndarray has no version counter: in-place edits would go unseen)
+        # (only torch tensors carry a version counter: a list / ndarray prompt edited in place would go unseen -> no fast path for those.
+        #  Edits that bypass the counter -- `.data`, storage shared with numpy through torch.from_numpy -- are the caller's to avoid.)
+        cacheable = all(t is None or torch.is_tensor(t) for t in
+                        [input_ids, attention_mask, class_name_ids, cls_indices] + list(token_refer_id or []) + pms)
         hit = self._prep_cache.get(ikey) if cacheable else None
         if hit is not None:
             return hit[0]

@@ -30,7 +30,7 @@ if ASAN:
 def build(force=False, verbose=True):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "hip", "hip_runtime.h")]
+    deps = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) + [os.path.join(HERE, "hip", "hip_runtime.h")]
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(OUT, os.path.basename(s)[:-4] + ".o")
