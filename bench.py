@@ -129,7 +129,7 @@ def main():
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
     if args.attn_fp32:
-        model.attn_x3 = False
+        model.attn_x3 = model.win_x3 = False
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"

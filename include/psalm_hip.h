@@ -26,7 +26,7 @@ const char* psalm_last_error(void);
 /* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
- * 5: psalm_causal_attention_x3[_split]. */
+ * 5: psalm_causal_attention_x3[_split], psalm_window_attention_x3_split. */
 #define PSALM_ABI_VERSION 5
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -280,6 +280,10 @@ int psalm_window_attention(const void* qkv, const float* bias_table, void* out, 
  * {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}; the output is a convex combination of the window's v rows. */
 int psalm_window_attention_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par, void* split_out,
                                  int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads, int ws, int shift, void* stream);
+/* ... with S = Q.K^T and O = P.V in split-f16 arithmetic (three f16 matrix-core products of 22-bit operands, fp32 softmax; csrc/attention_x3.hip):
+ * same operands, same output contract. */
+int psalm_window_attention_x3_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par, void* split_out,
+                                    int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads, int ws, int shift, void* stream);
 /* The same on the matrix cores for bf16 buffers and 12x12 windows (one block per (window, head), K / V^T / bias column
  * staged in LDS, scores of a whole 144-key row kept in MFMA accumulators). */
 int psalm_window_attention_mfma(const void* qkv, const float* bias_table, void* out, int B, int nWh, int nWw, int C, int heads,

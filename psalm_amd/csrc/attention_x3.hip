@@ -1,16 +1,22 @@
 // Phi prefill attention in SPLIT-f16 arithmetic (precision "f16x3"; modeling_phi.py:189-245 attention core, :137-160 / :92-122 partial RoPE):
-// the two contractions of the attention -- S = Q.K^T over the 64 head dims and O = P.V over the keys -- run on the f16 matrix cores as
-// three products of 22-bit operands (hi.hi + lo.hi + hi.lo, fp32 accumulate: the arithmetic of every GEMM of this mode, csrc/gemm.hip)
-// instead of on the fp32 matrix instruction; softmax statistics, the online rescale and the merge stay fp32.
+// the two contractions of the attention -- S = Q.K^T over the 64 head dims and O = P.V over the keys -- run on the f16 matrix cores instead of
+// on the fp32 matrix instruction; softmax statistics, the online rescale and the merge stay fp32.
+//   O = P.V: three products of 22-bit operands (hi.hi + lo.hi + hi.lo, fp32 accumulate) -- the arithmetic of every GEMM of this mode
+//            (csrc/gemm.hip): the error is relative to the output, like a GEMM's.
+//   S = Q.K^T: SIX products of 33-bit operands (hi + mid + lo f16 triples: hh | hm + mh + mm + hl + lh, the five small ones in their own
+//            accumulator) = fp32-class logits.  The logit is the one place of the network where an ABSOLUTE error of the size 2^-22 |q| |k|
+//            enters an exponential: with 22-bit Q / K (first form of this kernel, r04c) one of 78 wide-parity inputs -- panoptic seed 8, which the
+//            float64 control of tools/exp_noise_floor_cpu.py leaves in place -- moved by 6e-2 of the logit range
+//            (profiles/r04c_parity_wide_attention_3products_S.jsonl).
 //
 // Why: r04a kernel trace -- causal_attention_f32_splitk_kernel 64.1 us per Phi layer, 1.54 ms per image.  A 32-key tile costs 64
-// v_mfma_f32_32x32x2_f32 = 4096 matrix cycles per wave; here it costs 24 v_mfma_f32_32x32x16_f16 = 768, and the kernel's bound moves from
-// the matrix pipe (37 % busy behind 430 VALU instructions per tile, r02n SQ counters) to that VALU work alone.
+// v_mfma_f32_32x32x2_f32 = 4096 matrix cycles per wave; here it costs 24 + 12 v_mfma_f32_32x32x16_f16 = 1152, and the kernel's bound moves
+// from the matrix pipe (37 % busy behind 430 VALU instructions per tile, r02n SQ counters) to that VALU work alone.
 //
 // Structure = the fp32 kernel's (csrc/attention.hip causal_attention_f32_splitk_kernel): a block owns a balanced PAIR of 32-query tiles, its
 // 4 wavefronts take every 4th key tile, swapped products (S^T = K.Q^T, O^T += V^T.P^T: P goes from the accumulators straight into the
 // B operand), private online-softmax state per wave, merge through LDS.  What differs is the operand form, made by the pre-pass:
-//   Qs / Ks (b, h, Lp, 128) f16 = [hi (64) | lo (64)] rows of the RoPE'd (and, Q, pre-scaled) vectors under a per-ROW power-of-two scale
+//   Qs / Ks (b, h, Lp, 192) f16 = [hi (64) | mid (64) | lo (64)] rows of the RoPE'd (and, Q, pre-scaled) vectors under a per-ROW power-of-two scale
 //           (row maximum in [2^13, 2^14), as psalm_split_f16), 1 / scale in qinv / kinv (b, h, Lp); kinv = 0 marks a masked / padded key;
 //   Vth / Vtl (b, h, 64, Lp) f16 = V TRANSPOSED (rows = head dims, columns = keys) as hi / lo under ONE power-of-two scale for the whole
 //           tensor, derived from a bound of |v| the caller knows before the kernel runs (GemmFastArgs::so bound: max_r a_scale[r] * par[2] +
@@ -42,6 +48,32 @@ __device__ __forceinline__ void ax3_emit8(const float* v, float sc, unsigned sho
         lw[k] = l0 | (l1 << 16);
     }
     *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
+}
+
+// x s = hi + mid + lo as three f16 (33 bits): 8 consecutive elements to the three parts of an operand row
+__device__ __forceinline__ void ax3_emit8_triple(const float* v, float sc, unsigned short* hi_dst, unsigned short* mid_dst, unsigned short* lo_dst) {
+    unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned w[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float y = v[2 * k + e] * sc;
+            const _Float16 h = (_Float16)y;
+            const float r1 = y - (float)h;                                // exact
+            const _Float16 m = (_Float16)r1;
+            const _Float16 l = (_Float16)(r1 - (float)m);                 // exact difference, rounded once
+            w[e][0] = __builtin_bit_cast(unsigned short, h);
+            w[e][1] = __builtin_bit_cast(unsigned short, m);
+            w[e][2] = __builtin_bit_cast(unsigned short, l);
+        }
+        hw[k] = w[0][0] | (w[1][0] << 16);
+        mw[k] = w[0][1] | (w[1][1] << 16);
+        lw[k] = w[0][2] | (w[1][2] << 16);
+    }
+    *reinterpret_cast<psalm_u32x4*>(hi_dst) = psalm_u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<psalm_u32x4*>(mid_dst) = psalm_u32x4{mw[0], mw[1], mw[2], mw[3]};
     *reinterpret_cast<psalm_u32x4*>(lo_dst) = psalm_u32x4{lw[0], lw[1], lw[2], lw[3]};
 }
 
@@ -107,10 +139,10 @@ __global__ void __launch_bounds__(256) phi_rope_prep_x3_kernel(const float* __re
     ax3_row_scale(aq, sq, iq);
     ax3_row_scale(ak, sk, ik);
     if (t < Lp) {
-        unsigned short* qd = Qs + (bh * Lp + t) * 128 + c0;
-        unsigned short* kd = Ks + (bh * Lp + t) * 128 + c0;
-        ax3_emit8(q, sq, qd, qd + 64);
-        ax3_emit8(k, sk, kd, kd + 64);
+        unsigned short* qd = Qs + (bh * Lp + t) * 192 + c0;
+        unsigned short* kd = Ks + (bh * Lp + t) * 192 + c0;
+        ax3_emit8_triple(q, sq, qd, qd + 64, qd + 128);
+        ax3_emit8_triple(k, sk, kd, kd + 64, kd + 128);
         if (c0 == 0) {
             qinv[bh * Lp + t] = iq;
             kinv[bh * Lp + t] = (live && key_mask[(long)b * L + t]) ? ik : 0.f;       // 0: masked / padded key
@@ -158,13 +190,14 @@ causal_attention_x3_kernel(const unsigned short* __restrict__ Qs, const unsigned
     const int w0 = pass ? 3 - wave : wave;                                // second tile: key tiles dealt in the opposite wave order
     if (pass) __syncthreads();                                            // the first tile's merge has been read out of Os / Ml
     const int qi = qt * 32 + n32;                                         // this lane's query column
-    psalm_u32x4 qh[4], ql[4];
+    psalm_u32x4 qh[4], qm[4], ql[4];
     {
-        const unsigned short* p = Qs + (bh * Lp + qi) * 128 + 8 * hi;
+        const unsigned short* p = Qs + (bh * Lp + qi) * 192 + 8 * hi;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             qh[c] = *reinterpret_cast<const psalm_u32x4*>(p + 16 * c);
-            ql[c] = *reinterpret_cast<const psalm_u32x4*>(p + 64 + 16 * c);
+            qm[c] = *reinterpret_cast<const psalm_u32x4*>(p + 64 + 16 * c);
+            ql[c] = *reinterpret_cast<const psalm_u32x4*>(p + 128 + 16 * c);
         }
     }
     const float qi_inv = qinv[bh * Lp + qi];
@@ -174,13 +207,14 @@ causal_attention_x3_kernel(const unsigned short* __restrict__ Qs, const unsigned
     float m = -3.0e38f, l = 0.f;
     for (int kt = w0; kt <= qt; kt += 4) {                                // key tiles 0..qt (the diagonal tile is qt)
         // ---- fragments of this tile, all loads issued up front
-        psalm_u32x4 kh[4], kl[4], vh[2][2], vl[2][2];
+        psalm_u32x4 kh[4], km[4], kl[4], vh[2][2], vl[2][2];
         {
-            const unsigned short* kp = Ks + (bh * Lp + kt * 32 + n32) * 128 + 8 * hi;
+            const unsigned short* kp = Ks + (bh * Lp + kt * 32 + n32) * 192 + 8 * hi;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 kh[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 16 * c);
-                kl[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 64 + 16 * c);
+                km[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 64 + 16 * c);
+                kl[c] = *reinterpret_cast<const psalm_u32x4*>(kp + 128 + 16 * c);
             }
         }
 #pragma unroll
@@ -198,22 +232,21 @@ causal_attention_x3_kernel(const unsigned short* __restrict__ Qs, const unsigned
             const psalm_f32x4 t4 = *reinterpret_cast<const psalm_f32x4*>(kinv + bh * Lp + kt * 32 + 8 * g + 4 * hi);
             ksc[4 * g] = t4.x; ksc[4 * g + 1] = t4.y; ksc[4 * g + 2] = t4.z; ksc[4 * g + 3] = t4.w;
         }
-        // ---- S^T = K . Q^T: three products, two accumulators (even / odd head-dim chunks) to halve the dependent chain
+        // ---- S^T = K . Q^T: six products of the (hi, mid, lo) triples; sa takes hi.hi, sb the five small ones (<= 2^-10 of the sum: their own
+        // rounding does not reach the result), so S = sa + sb carries the fp32 matrix instruction's accumulation error and no operand error
         ax3_f32x16 sa, sb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
 #pragma unroll
-        for (int c = 0; c < 4; c += 2) {
-            const ax3_f16x8 k0h = __builtin_bit_cast(ax3_f16x8, kh[c]), k0l = __builtin_bit_cast(ax3_f16x8, kl[c]);
-            const ax3_f16x8 k1h = __builtin_bit_cast(ax3_f16x8, kh[c + 1]), k1l = __builtin_bit_cast(ax3_f16x8, kl[c + 1]);
-            const ax3_f16x8 q0h = __builtin_bit_cast(ax3_f16x8, qh[c]), q0l = __builtin_bit_cast(ax3_f16x8, ql[c]);
-            const ax3_f16x8 q1h = __builtin_bit_cast(ax3_f16x8, qh[c + 1]), q1l = __builtin_bit_cast(ax3_f16x8, ql[c + 1]);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, q0h, sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, q1h, sb, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0l, q0h, sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1l, q1h, sb, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0h, q0l, sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1h, q1l, sb, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+            const ax3_f16x8 kH = __builtin_bit_cast(ax3_f16x8, kh[c]), kM = __builtin_bit_cast(ax3_f16x8, km[c]), kL = __builtin_bit_cast(ax3_f16x8, kl[c]);
+            const ax3_f16x8 qH = __builtin_bit_cast(ax3_f16x8, qh[c]), qM = __builtin_bit_cast(ax3_f16x8, qm[c]), qL = __builtin_bit_cast(ax3_f16x8, ql[c]);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kH, qH, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kL, qH, sb, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kH, qL, sb, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kM, qM, sb, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kM, qH, sb, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kH, qM, sb, 0, 0, 0);
         }
         float sv[16];
         float mc = -3.0e38f;
@@ -305,10 +338,10 @@ causal_attention_x3_kernel(const unsigned short* __restrict__ Qs, const unsigned
     }
 }
 
-// workspace: Qs, Ks (B heads Lp 128 f16 each) | Vth, Vtl (B heads 64 Lp f16 each) | qinv, kinv (B heads Lp f32) | vinv (B heads f32)
+// workspace: Qs, Ks (B heads Lp 192 f16 each) | Vth, Vtl (B heads 64 Lp f16 each) | qinv, kinv (B heads Lp f32) | vinv (B heads f32)
 extern "C" long psalm_causal_attention_x3_workspace(int B, int L, int heads) {
     const long Lp = (L + 31) / 32 * 32, bh = (long)B * heads;
-    return 2 * bh * Lp * 128 * 2 + 2 * bh * 64 * Lp * 2 + 2 * bh * Lp * 4 + bh * 4 + 64;
+    return 2 * bh * Lp * 192 * 2 + 2 * bh * 64 * Lp * 2 + 2 * bh * Lp * 4 + bh * 4 + 64;
 }
 
 // Phi prefill attention on fp32 q | k | v columns in split-f16 arithmetic.  Operands as psalm_causal_attention_f32[_split]; in addition the
@@ -328,8 +361,8 @@ static int causal_attention_x3_impl(const float* qkv, long ld, int q_off, int k_
     if (B == 0 || L == 0) return 0;
     const long Lp = (L + 31) / 32 * 32, bh = (long)B * heads;
     unsigned short* Qs = (unsigned short*)workspace;
-    unsigned short* Ks = Qs + bh * Lp * 128;
-    unsigned short* Vth = Ks + bh * Lp * 128;
+    unsigned short* Ks = Qs + bh * Lp * 192;
+    unsigned short* Vth = Ks + bh * Lp * 192;
     unsigned short* Vtl = Vth + bh * 64 * Lp;
     float* qinv = (float*)(Vtl + bh * 64 * Lp);
     float* kinv = qinv + bh * Lp;
@@ -367,4 +400,217 @@ extern "C" int psalm_causal_attention_x3_split(const float* qkv, long ld, int q_
     return causal_attention_x3_impl(qkv, ld, q_off, k_off, v_off, split_out, ld_split, split_col_off, cos_table, sin_table, key_mask, a_scale,
                                     n_scale, bound_par, workspace, B, L, heads, head_dim, rot, stream, split_inv, split_kp,
                                     "psalm_causal_attention_x3_split");
+}
+
+// ============================================================================================ Swin window attention, split-f16 arithmetic
+// psalm_window_attention_split (swin_trans.py:117-149 + the shift mask of :369-387) with S = Q.K^T + bias (six products of 33-bit operands) and
+// O = P.V (three products of 22-bit operands) on the f16 matrix cores, like the Phi kernel above -- the fp32 form (csrc/attention.hip window_attention_f32_mfma_kernel) spends
+// 1296 v_mfma_f32_16x16x4_f32 = 41 K matrix cycles per (window, head), a 17 us serial chain when a stage has fewer (window, head) pairs than the
+// chip has SIMDs (Swin-B stage 3 at 1024^2: 576 pairs, 18 of the 24 launches).  Here: 9 x 9 x 6 + 9 x 30 = 756 v_mfma_f32_16x16x32_f16 = 12 K.
+// One block of NWV wavefronts per (window, head), every wavefront takes every NWV-th 16-query tile; 144 tokens, head dim 32.  In LDS:
+//   Kh / Km / Kl [144][32] f16: the K rows as (hi, mid, lo) triples under per-row power-of-two scales (1 / scale in kinv): an A fragment = 16
+//             contiguous bytes, a tile = 1 KB;
+//   Vth / Vtl [32][160 (+8)] f16: V TRANSPOSED under the window's output scale (the bound the split output is scaled with), keys padded to 160
+//             = 5 contraction steps of 32, inside a step in the order  position 8 kk + 4 t + r <-> key 16 t + 4 kk + r  (t = 0, 1): the keys
+//             lane (q, kk) holds in its S^T registers of the key tiles 2 u + t, so that P goes from the accumulators into the B operand;
+//   the head's relative-position-bias column.
+// Exact two-pass softmax over the whole 144-key score block in registers, as in the fp32 form.
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV) window_attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
+                                                                     unsigned short* __restrict__ out, int nWh, int nWw, int C, int heads,
+                                                                     int shift, const float* __restrict__ a_inv, const float* __restrict__ so_par,
+                                                                     float* __restrict__ so_inv, int so_kp) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int HD = 32, WS = 12, N = WS * WS, NT = N / 16, NB = (2 * WS - 1) * (2 * WS - 1), NU = 5, VP = 168;
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[N * HD], Km[N * HD], Kl[N * HD], Vth[HD * VP], Vtl[HD * VP];
+    __shared__ float kinv[N], Bs[NB];
+    const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, kk = lane >> 4;
+    const long row0 = (long)win * N;
+    // ---- the window's output / V scale from the magnitude bound (as the fp32 form)
+    float gmax = 0.f;
+    for (int r = lane; r < N; r += 64) gmax = fmaxf(gmax, a_inv[row0 + r]);
+    gmax = wave_max(gmax);
+    const float bound = fminf(fmaxf(fmaf(gmax, so_par[0], so_par[1]), 7.888609e-31f), 1.2676506e30f);  // [2^-100, 2^100]
+    const unsigned eb = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;                               // bound * scale in [2^12, 2^13)
+    const float so_sc = __builtin_bit_cast(float, (266u - eb) << 23);
+    if (h == 0 && wave == 0) {
+        const float inv = __builtin_bit_cast(float, (eb - 12u) << 23);
+        for (int r = lane; r < N; r += 64) so_inv[row0 + r] = inv;
+    }
+    // ---- stage K (rows, per-row scale) and V (transposed, window scale): item = (row, 8 head dims); the 4 items of a row are 4 adjacent lanes
+    for (int e = tid; e < N * 4; e += 64 * NWV) {
+        const int r = e >> 2, c8 = (e & 3) * 8;
+        const float* p = qkv + (row0 + r) * 3 * C + h * HD + c8;
+        float kf[8], vf[8];
+        ld8(p + C, kf);
+        ld8(p + 2 * C, vf);
+        float ak = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ak = fmaxf(ak, fabsf(kf[i]));
+        ak = fmaxf(ak, __shfl_xor(ak, 1));
+        ak = fmaxf(ak, __shfl_xor(ak, 2));
+        float sk, ik;
+        ax3_row_scale(ak, sk, ik);
+        ax3_emit8_triple(kf, sk, &Kh[r * HD + c8], &Km[r * HD + c8], &Kl[r * HD + c8]);
+        if (c8 == 0) kinv[r] = ik;
+        const int jj = r & 31, pos = 32 * (r >> 5) + 8 * ((jj & 15) >> 2) + 4 * (jj >> 4) + (jj & 3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned hw, lw;
+            psalm_split_words(vf[i] * so_sc, hw, lw);
+            Vth[(c8 + i) * VP + pos] = (unsigned short)hw;
+            Vtl[(c8 + i) * VP + pos] = (unsigned short)lw;
+        }
+    }
+    for (int e = tid; e < HD * 16; e += 64 * NWV) {                      // keys 144 .. 159 of the last step: zero columns (positions 128 + 8 kk + 4 + r)
+        const int d = e >> 4, i = e & 15, pos = 128 + 8 * (i >> 2) + 4 + (i & 3);
+        Vth[d * VP + pos] = 0;
+        Vtl[d * VP + pos] = 0;
+    }
+    for (int e = tid; e < NB; e += 64 * NWV) Bs[e] = bias_table[(long)e * heads + h];
+    __syncthreads();
+    const float scale = rsqrtf((float)HD);
+    const int wwin = win % (nWh * nWw);
+    const int wh = wwin / nWw, ww = wwin % nWw;
+    const int Hp = nWh * WS, Wp = nWw * WS;
+    auto label = [&](int t) -> int {                                     // shift-mask region of a token (swin_trans.py:371-387)
+        const int gy = wh * WS + t / WS, gx = ww * WS + t % WS;
+        const int ly = gy < Hp - WS ? 0 : (gy < Hp - shift ? 1 : 2);
+        const int lx = gx < Wp - WS ? 0 : (gx < Wp - shift ? 1 : 2);
+        return ly * 3 + lx;
+    };
+    int klab[NT][4];                                                     // labels of the keys this lane holds (16 tk + 4 kk + r)
+    if (shift > 0) {
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) klab[tk][r] = label(16 * tk + 4 * kk + r);
+    }
+#pragma unroll 1
+    for (int tq = wave; tq < NT; tq += NWV) {
+        const int qi = 16 * tq + n16;                                    // this lane's query (column of S^T / O^T)
+        ax3_f16x8 qh, qm, ql;
+        float qinv_;
+        {
+            float qf[8];
+            ld8(qkv + (row0 + qi) * 3 * C + h * HD + 8 * kk, qf);
+            float aq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qf[i] *= scale; aq = fmaxf(aq, fabsf(qf[i])); }
+            aq = fmaxf(aq, __shfl_xor(aq, 16));
+            aq = fmaxf(aq, __shfl_xor(aq, 32));
+            float sq;
+            ax3_row_scale(aq, sq, qinv_);
+            psalm_u32x4 t3[3];
+            ax3_emit8_triple(qf, sq, reinterpret_cast<unsigned short*>(&t3[0]), reinterpret_cast<unsigned short*>(&t3[1]),
+                             reinterpret_cast<unsigned short*>(&t3[2]));
+            qh = __builtin_bit_cast(ax3_f16x8, t3[0]);
+            qm = __builtin_bit_cast(ax3_f16x8, t3[1]);
+            ql = __builtin_bit_cast(ax3_f16x8, t3[2]);
+        }
+        const int yi = qi / WS, xi = qi % WS;
+        const int qlab = shift > 0 ? label(qi) : 0;
+        f32x4 sc[NT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, small = {0.f, 0.f, 0.f, 0.f};    // hi.hi | the five small products (see the Phi kernel)
+            const ax3_f16x8 kh = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Kh[(16 * tk + n16) * HD + 8 * kk]));
+            const ax3_f16x8 km = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Km[(16 * tk + n16) * HD + 8 * kk]));
+            const ax3_f16x8 kl = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Kl[(16 * tk + n16) * HD + 8 * kk]));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
+            small = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, small, 0, 0, 0);
+            small = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, small, 0, 0, 0);
+            small = __builtin_amdgcn_mfma_f32_16x16x32_f16(km, qm, small, 0, 0, 0);
+            small = __builtin_amdgcn_mfma_f32_16x16x32_f16(km, qh, small, 0, 0, 0);
+            small = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qm, small, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += small[r];
+            const psalm_f32x4 ki = *reinterpret_cast<const psalm_f32x4*>(&kinv[16 * tk + 4 * kk]);
+            const float kis[4] = {ki.x, ki.y, ki.z, ki.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * tk + 4 * kk + r;
+                const int yj = j / WS, xj = j % WS;
+                float v = fmaf(acc[r], kis[r] * qinv_, Bs[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)]);
+                if (shift > 0 && klab[tk][r] != qlab) v += -100.0f;
+                acc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            sc[tk] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+        unsigned ph[NU][4], pl[NU][4];                                    // P of contraction step u: words (e / 2): slots e < 4 key tile 2u, e >= 4 key tile 2u + 1
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __expf(sc[tk][r] - mx); l += p[r]; }
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            psalm_split_words(p[0], h0, l0);
+            psalm_split_words(p[1], h1, l1);
+            psalm_split_words(p[2], h2, l2);
+            psalm_split_words(p[3], h3, l3);
+            ph[tk >> 1][2 * (tk & 1)] = h0 | (h1 << 16);
+            ph[tk >> 1][2 * (tk & 1) + 1] = h2 | (h3 << 16);
+            pl[tk >> 1][2 * (tk & 1)] = l0 | (l1 << 16);
+            pl[tk >> 1][2 * (tk & 1) + 1] = l2 | (l3 << 16);
+        }
+        ph[NU - 1][2] = ph[NU - 1][3] = pl[NU - 1][2] = pl[NU - 1][3] = 0u;   // keys 144 .. 159
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};       // O^T d-tiles: rows d = 16 t + 4 kk + r, column q
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const ax3_f16x8 pH = __builtin_bit_cast(ax3_f16x8, psalm_u32x4{ph[u][0], ph[u][1], ph[u][2], ph[u][3]});
+            const ax3_f16x8 pL = __builtin_bit_cast(ax3_f16x8, psalm_u32x4{pl[u][0], pl[u][1], pl[u][2], pl[u][3]});
+            const ax3_f16x8 v0h = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Vth[n16 * VP + 32 * u + 8 * kk]));
+            const ax3_f16x8 v0l = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Vtl[n16 * VP + 32 * u + 8 * kk]));
+            const ax3_f16x8 v1h = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Vth[(16 + n16) * VP + 32 * u + 8 * kk]));
+            const ax3_f16x8 v1l = __builtin_bit_cast(ax3_f16x8, *reinterpret_cast<const psalm_u32x4*>(&Vtl[(16 + n16) * VP + 32 * u + 8 * kk]));
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, pH, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, pH, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0l, pH, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1l, pH, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, pL, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, pL, o1, 0, 0, 0);
+        }
+        // O carries the window scale already (V was scaled with it): the operand words are split(o / l)
+        const float inv = 1.f / l;
+        unsigned short* op = out + (row0 + qi) * 2L * so_kp + h * HD + 4 * kk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned hw[2], lw[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned h0, h1, l0, l1;
+                psalm_split_words((t ? o1[2 * k] : o0[2 * k]) * inv, h0, l0);
+                psalm_split_words((t ? o1[2 * k + 1] : o0[2 * k + 1]) * inv, h1, l1);
+                hw[k] = h0 | (h1 << 16);
+                lw[k] = l0 | (l1 << 16);
+            }
+            *reinterpret_cast<psalm_u32x2*>(op + 16 * t) = psalm_u32x2{hw[0], hw[1]};
+            *reinterpret_cast<psalm_u32x2*>(op + 16 * t + so_kp) = psalm_u32x2{lw[0], lw[1]};
+        }
+    }
+}
+
+// Same contract as psalm_window_attention_split (csrc/attention.hip); arithmetic: split-f16 (this file's header).
+extern "C" int psalm_window_attention_x3_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par,
+                                               void* split_out, int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads,
+                                               int ws, int shift, void* stream) {
+    PSALM_CHECK_ARG(C == heads * 32 && ws == 12, "psalm_window_attention_x3_split: head_dim 32, 12 x 12 windows");
+    PSALM_CHECK_ARG(a_inv && bound_par && split_out && split_inv && split_kp >= C && split_kp % 8 == 0 && (uintptr_t)qkv % 16 == 0 &&
+                        (uintptr_t)split_out % 16 == 0 && C % 4 == 0, "psalm_window_attention_x3_split: operand scales, bound parameters, aligned buffers");
+    const int nwin = B * nWh * nWw;
+    if (nwin == 0) return 0;
+    if ((long)nwin * heads <= 640)                                        // fewer (window, head) pairs than SIMDs: three wavefronts share one
+        hipLaunchKernelGGL((window_attention_x3_kernel<3>), dim3(nwin, heads), dim3(192), 0, (hipStream_t)stream, qkv, bias_table,
+                           (unsigned short*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    else
+        hipLaunchKernelGGL((window_attention_x3_kernel<1>), dim3(nwin, heads), dim3(64), 0, (hipStream_t)stream, qkv, bias_table,
+                           (unsigned short*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    PSALM_LAUNCH_END("psalm_window_attention_x3_split");
 }

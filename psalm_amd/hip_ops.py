@@ -561,18 +561,20 @@ class Ops:
         self._check(rc, "psalm_window_attention")
         return out
 
-    def window_attention_split(self, qkv, bias_table, a_inv, bound_par, B, nWh, nWw, heads, ws, shift):
+    def window_attention_split(self, qkv, bias_table, a_inv, bound_par, B, nWh, nWw, heads, ws, shift, x3=False):
         """window_attention on a float32 qkv buffer (12 x 12 windows) -> SplitF16 (rows, C): the projection GEMM's A operand, see
-        psalm_window_attention_split.  a_inv: row scales of the qkv GEMM's A operand; bound_par: >= 2 device floats."""
+        psalm_window_attention_split.  a_inv: row scales of the qkv GEMM's A operand; bound_par: >= 2 device floats.
+        x3: Q.K^T and P.V in split-f16 arithmetic (psalm_window_attention_x3_split) instead of on the fp32 matrix instruction."""
         C = qkv.shape[-1] // 3
         if qkv.dtype != torch.float32 or ws != 12 or a_inv.numel() != qkv.shape[0]:
             raise PsalmHipError("window_attention_split: float32 qkv, 12 x 12 windows, one operand scale per row")
         Kp = (C + 63) // 64 * 64
         so = (self.empty if Kp == C else self.zeros)(qkv.shape[0], 2 * Kp, dtype=torch.float16)
         inv = self.empty(qkv.shape[0], dtype=torch.float32)
-        rc = self.lib.psalm_window_attention_split(self._p(qkv), self._p(bias_table), self._p(a_inv), self._p(bound_par), self._p(so), Kp,
-                                                   self._p(inv), B, nWh, nWw, C, heads, ws, shift, self._stream())
-        self._check(rc, "psalm_window_attention_split")
+        fn = self.lib.psalm_window_attention_x3_split if x3 else self.lib.psalm_window_attention_split
+        rc = fn(self._p(qkv), self._p(bias_table), self._p(a_inv), self._p(bound_par), self._p(so), Kp,
+                self._p(inv), B, nWh, nWw, C, heads, ws, shift, self._stream())
+        self._check(rc, "psalm_window_attention_x3_split" if x3 else "psalm_window_attention_split")
         return SplitF16(so, inv, C)
 
     def causal_attention(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot):

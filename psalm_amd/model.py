@@ -135,6 +135,7 @@ class PSALM:
         # f16x3: the Phi attention's two contractions (Q.K^T, P.V) in the mode's own arithmetic -- three f16 matrix-core products of 22-bit
         # operands, fp32 softmax -- instead of on the fp32 matrix instruction (r04: 64 -> ? us per layer; False = the r02 / r03 kernel)
         self.attn_x3 = self.fuse_split
+        self.win_x3 = self.fuse_split                 # ... and the Swin window attention's (psalm_window_attention_x3_split)
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
@@ -490,7 +491,7 @@ class PSALM:
                     xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
                 if x3f and self.fuse_split and ws == 12 and isinstance(xw, H.SplitF16):      # f16x3: the output leaves as the projection GEMM's split operand
-                    aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift)
+                    aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift, x3=self.win_x3)
                 else:
                     aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
                 pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)

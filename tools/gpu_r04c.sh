@@ -3,7 +3,7 @@ TAG=${1:-r04c}
 set -x
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_1_ops.py tests/test_2_gemm.py -m gpu -q -x -p no:cacheprovider -k "causal or paired or split_output" > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log
+timeout 600 python -m pytest tests/test_1_ops.py tests/test_2_gemm.py -m gpu -q -x -p no:cacheprovider -k "causal or paired or split_output or window" > gpurun_out/${TAG}_pytest.log 2>&1; tail -3 gpurun_out/${TAG}_pytest.log
 for flag in "" "--attn-fp32" "" "--attn-fp32"; do
 timeout 300 python bench.py --steps 20 --no-cpu-baseline --no-side-modes $flag 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_quick.json
 python -c "import sys,json; d=json.load(open('gpurun_out/${TAG}_bench_quick.json')); r=d['roofline']; print('attn[$flag]', d['value'], d['ms_per_step'], r['kernel'][:90], r['avg_launch_us'], r['achieved'], r['all_mfma_gemms'])"

@@ -162,7 +162,7 @@ def main():
             cur_task = task
             for model in models.values():
                 if args.attn_fp32:
-                    model.attn_x3 = False
+                    model.attn_x3 = model.win_x3 = False
                 for code in [int(c) for c in args.gemm_policy.split(",") if c]:
                     model.ops.gemm_tile_policy(code)
         for s in seeds:
