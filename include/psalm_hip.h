@@ -26,7 +26,7 @@ const char* psalm_last_error(void);
 /* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
- * 5: psalm_causal_attention_x3[_split], psalm_window_attention_x3_split. */
+ * 5: psalm_msda_set_policy, psalm_msda_lds_applicable (the LDS-staged MSDA kernel). */
 #define PSALM_ABI_VERSION 5
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -55,6 +55,11 @@ int psalm_msda_forward_dev(const void* value, int value_dtype, const int64_t* sp
 int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
                      const int64_t* level_start_host, const float* offsets_logits, void* out, int out_dtype, int B, int S,
                      int M, int D, int L, int P, void* stream);
+/* Tuning / test knob of psalm_msda_fused: 1 (default) = the LDS-staged kernel (block = (tile of the normalised image, head): the three level
+ * windows copied once into LDS) wherever its geometry holds -- fp32 value, head dim 32, one image, a 4 : 2 : 1 pyramid with an even coarsest
+ * level --, 0 = the L2-gather kernel everywhere; 2 / 3 = the gather kernel's query order (XCD bands / linear). */
+int psalm_msda_set_policy(int v);
+int psalm_msda_lds_applicable(const int64_t* spatial_shapes_host, const int64_t* level_start_host, int L, int S, int B, int D, int value_dtype);
 
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -194,21 +199,6 @@ int psalm_causal_attention_f32_split(const float* qkv, long ld, int q_off, int k
                                      const unsigned char* key_mask, void* workspace, int B, int L, int heads, int head_dim, int rot,
                                      void* stream);
 
-/* Phi prefill attention in SPLIT-f16 arithmetic (precision "f16x3"; modeling_phi.py:189-245, :137-160, :92-122): S = Q.K^T and O = P.V as three
- * f16 matrix-core products of 22-bit operands each (the arithmetic of psalm_gemm_x3), fp32 softmax statistics -- csrc/attention_x3.hip.
- * Operands as psalm_causal_attention_f32 / _f32_split plus the bound of |v| the V operand is scaled under:
- *   max over a_scale[0 .. n_scale) * bound_par[2] + bound_par[3]   (device pointers: the per-row inverse scales of the A operand of the GEMM
- *   that produced q | k | v, and that GEMM's 4 bound parameters as psalm_gemm_x3_split takes them -- terms 2 / 3 bound the v rows).
- * workspace: psalm_causal_attention_x3_workspace(B, L, heads) bytes, 16-byte aligned. */
-long psalm_causal_attention_x3_workspace(int B, int L, int heads);
-int psalm_causal_attention_x3(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off, const float* cos_table,
-                              const float* sin_table, const unsigned char* key_mask, const float* a_scale, int n_scale, const float* bound_par,
-                              void* workspace, int B, int L, int heads, int head_dim, int rot, void* stream);
-int psalm_causal_attention_x3_split(const float* qkv, long ld, int q_off, int k_off, int v_off, void* split_out, long ld_split, int split_kp,
-                                    int split_col_off, const float* split_inv, const float* cos_table, const float* sin_table,
-                                    const unsigned char* key_mask, const float* a_scale, int n_scale, const float* bound_par, void* workspace,
-                                    int B, int L, int heads, int head_dim, int rot, void* stream);
-
 /* zero `bytes` bytes / copy `bytes` bytes device-to-device, as stream operations (hipMemsetAsync / hipMemcpyAsync; graph-capturable) */
 int psalm_memset_zero(void* p, long bytes, void* stream);
 int psalm_copy_d2d(void* dst, const void* src, long bytes, void* stream);
@@ -280,10 +270,6 @@ int psalm_window_attention(const void* qkv, const float* bias_table, void* out, 
  * {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}; the output is a convex combination of the window's v rows. */
 int psalm_window_attention_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par, void* split_out,
                                  int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads, int ws, int shift, void* stream);
-/* ... with S = Q.K^T and O = P.V in split-f16 arithmetic (three f16 matrix-core products of 22-bit operands, fp32 softmax; csrc/attention_x3.hip):
- * same operands, same output contract. */
-int psalm_window_attention_x3_split(const float* qkv, const float* bias_table, const float* a_inv, const float* bound_par, void* split_out,
-                                    int split_kp, float* split_inv, int B, int nWh, int nWw, int C, int heads, int ws, int shift, void* stream);
 /* The same on the matrix cores for bf16 buffers and 12x12 windows (one block per (window, head), K / V^T / bias column
  * staged in LDS, scores of a whole 144-key row kept in MFMA accumulators). */
 int psalm_window_attention_mfma(const void* qkv, const float* bias_table, void* out, int B, int nWh, int nWw, int C, int heads,

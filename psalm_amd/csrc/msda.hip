@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
 #define MSDA_R 3
 struct MsdaTiles { int tgy, tgx, n[3], ww[3], wbase[3], qoff[3], npos; };
 template <typename TO>
-__global__ void __launch_bounds__(384) msda_fused_lds_kernel(const float* __restrict__ value, MsdaLevels lv, MsdaTiles tl,
+__global__ void __launch_bounds__(384) PSALM_WAVES_PER_EU(3) msda_fused_lds_kernel(const float* __restrict__ value, MsdaLevels lv, MsdaTiles tl,
                                                              const float* __restrict__ ow, TO* __restrict__ out, int S, int M) {
     constexpr int L = 3, P = 4, LP = 12, D = 32;
     __shared__ __attribute__((aligned(16))) float win[504 * D];          // positions x 32 channels (chunk-swizzled), 63 copy instructions
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(384) msda_fused_lds_kernel(const float* __rest
             if (l == j) { Hl = lv.H[j]; Wl = lv.W[j]; sl = lv.start[j]; nl = tl.n[j]; wwl = tl.ww[j]; wb = tl.wbase[j]; }
         const int oy = ty * nl - MSDA_R - 1, ox = tx * nl - MSDA_R - 1;   // level pixel of window position (0, 0)
         const float* vl = vb + (long)sl * row_stride;
-#pragma unroll
+#pragma unroll 2
         for (int p = 0; p < P; ++p) {
             const int i = l * P + p;
             // bilinear taps: the expression of msda_taps8 (ms_deform_im2col_cuda.cuh:38-89; corners clamped into the level, validity in the weights)
@@ -435,6 +435,34 @@ static int fill_levels(MsdaLevels& lv, const int64_t* shapes, const int64_t* sta
     return tot == S ? 0 : -2;
 }
 
+// Geometry of the LDS-staged fused kernel: fp32 value, head dim 32, one image, a 4 : 2 : 1 pyramid (any level order) whose coarsest level has
+// even sides -> tile grid (hmin / 2) x (wmin / 2), n_l = 2 / 4 / 8 pixels of level l per tile side.
+static bool msda_tiles(const MsdaLevels& lv, int L, int B, int S, int D, int value_dtype, MsdaTiles& tl) {
+    if (!(L == 3 && B == 1 && D == 32 && value_dtype == PSALM_F32 && S > 0)) return false;
+    int hmin = lv.H[0], wmin = lv.W[0];
+    for (int l = 1; l < L; ++l) { hmin = lv.H[l] < hmin ? lv.H[l] : hmin; wmin = lv.W[l] < wmin ? lv.W[l] : wmin; }
+    if (hmin % 2 || wmin % 2 || hmin < 2 || wmin < 2) return false;
+    tl.tgy = hmin / 2; tl.tgx = wmin / 2;
+    int seen = 0, pos = 0, qo = 0;
+    for (int l = 0; l < L; ++l) {
+        const int ny = lv.H[l] / tl.tgy, nx = lv.W[l] / tl.tgx;
+        if (lv.H[l] % tl.tgy || lv.W[l] % tl.tgx || ny != nx || !(ny == 2 || ny == 4 || ny == 8) || (seen & ny)) return false;
+        seen |= ny;
+        tl.n[l] = ny; tl.ww[l] = ny + 2 * MSDA_R + 2; tl.wbase[l] = pos; tl.qoff[l] = qo;
+        pos += tl.ww[l] * tl.ww[l];
+        qo += ny * ny;
+    }
+    tl.npos = pos;
+    return pos <= 504 && qo == 84;
+}
+// 1 if psalm_msda_fused takes the LDS-staged kernel for this level table (tests / bench attribution)
+extern "C" int psalm_msda_lds_applicable(const int64_t* spatial_shapes_host, const int64_t* level_start_host, int L, int S, int B, int D,
+                                         int value_dtype) {
+    MsdaLevels lv = {};
+    MsdaTiles tl = {};
+    return g_msda_lds && fill_levels(lv, spatial_shapes_host, level_start_host, L, S) == 0 && msda_tiles(lv, L, B, S, D, value_dtype, tl) ? 1 : 0;
+}
+
 extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
                                   const int64_t* level_start_host, const float* sampling_loc, const float* attn_weight,
                                   void* out, int out_dtype, int B, int S, int M, int D, int L, int Lq, int P, void* stream) {
@@ -485,31 +513,14 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
     int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
     PSALM_CHECK_ARG(rc == 0, "psalm_msda_fused: bad level table");
     const int block = 256;
-    // LDS-staged form: fp32 value, head dim 32, one image, a 4 : 2 : 1 pyramid (any level order) whose coarsest level has even sides
-    if (g_msda_lds && B == 1 && D == 32 && value_dtype == PSALM_F32 && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0 && S > 0) {
-        int hmin = lv.H[0], wmin = lv.W[0];
-        for (int l = 1; l < L; ++l) { hmin = lv.H[l] < hmin ? lv.H[l] : hmin; wmin = lv.W[l] < wmin ? lv.W[l] : wmin; }
-        MsdaTiles tl = {};
-        bool ok = hmin % 2 == 0 && wmin % 2 == 0 && hmin >= 2 && wmin >= 2;
-        tl.tgy = hmin / 2; tl.tgx = wmin / 2;
-        int seen = 0, pos = 0, qo = 0;
-        for (int l = 0; l < L && ok; ++l) {
-            const int ny = lv.H[l] / tl.tgy, nx = lv.W[l] / tl.tgx;
-            ok = ok && lv.H[l] % tl.tgy == 0 && lv.W[l] % tl.tgx == 0 && ny == nx && (ny == 2 || ny == 4 || ny == 8) && !(seen & ny);
-            seen |= ny;
-            tl.n[l] = ny; tl.ww[l] = ny + 2 * MSDA_R + 2; tl.wbase[l] = pos; tl.qoff[l] = qo;
-            pos += tl.ww[l] * tl.ww[l];
-            qo += ny * ny;
-        }
-        tl.npos = pos;
-        if (ok && pos <= 504 && qo == 84) {
-            const unsigned nblk = (unsigned)(tl.tgy * tl.tgx * M);
-            PSALM_DISPATCH(out_dtype, TO, {
-                hipLaunchKernelGGL((msda_fused_lds_kernel<TO>), dim3(nblk), dim3(384), 0, (hipStream_t)stream, (const float*)value, lv, tl,
-                                   offsets_logits, (TO*)out, S, M);
-            });
-            PSALM_LAUNCH_END("psalm_msda_fused");
-        }
+    MsdaTiles tl = {};
+    if (g_msda_lds && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0 && msda_tiles(lv, L, B, S, D, value_dtype, tl)) {
+        const unsigned nblk = (unsigned)(tl.tgy * tl.tgx * M);
+        PSALM_DISPATCH(out_dtype, TO, {
+            hipLaunchKernelGGL((msda_fused_lds_kernel<TO>), dim3(nblk), dim3(384), 0, (hipStream_t)stream, (const float*)value, lv, tl,
+                               offsets_logits, (TO*)out, S, M);
+        });
+        PSALM_LAUNCH_END("psalm_msda_fused");
     }
     if (D % 8 == 0 && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0) {       // 8 channels per lane
         const long total8 = (long)B * S * M * (D / 8);

@@ -62,7 +62,7 @@ class _ProfiledLib:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
         if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version", "psalm_gemm_last_kernel",
-                                                         "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
+                                                         "psalm_gemm_set_tile_policy", "psalm_msda_set_policy") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -561,20 +561,18 @@ class Ops:
         self._check(rc, "psalm_window_attention")
         return out
 
-    def window_attention_split(self, qkv, bias_table, a_inv, bound_par, B, nWh, nWw, heads, ws, shift, x3=False):
+    def window_attention_split(self, qkv, bias_table, a_inv, bound_par, B, nWh, nWw, heads, ws, shift):
         """window_attention on a float32 qkv buffer (12 x 12 windows) -> SplitF16 (rows, C): the projection GEMM's A operand, see
-        psalm_window_attention_split.  a_inv: row scales of the qkv GEMM's A operand; bound_par: >= 2 device floats.
-        x3: Q.K^T and P.V in split-f16 arithmetic (psalm_window_attention_x3_split) instead of on the fp32 matrix instruction."""
+        psalm_window_attention_split.  a_inv: row scales of the qkv GEMM's A operand; bound_par: >= 2 device floats."""
         C = qkv.shape[-1] // 3
         if qkv.dtype != torch.float32 or ws != 12 or a_inv.numel() != qkv.shape[0]:
             raise PsalmHipError("window_attention_split: float32 qkv, 12 x 12 windows, one operand scale per row")
         Kp = (C + 63) // 64 * 64
         so = (self.empty if Kp == C else self.zeros)(qkv.shape[0], 2 * Kp, dtype=torch.float16)
         inv = self.empty(qkv.shape[0], dtype=torch.float32)
-        fn = self.lib.psalm_window_attention_x3_split if x3 else self.lib.psalm_window_attention_split
-        rc = fn(self._p(qkv), self._p(bias_table), self._p(a_inv), self._p(bound_par), self._p(so), Kp,
-                self._p(inv), B, nWh, nWw, C, heads, ws, shift, self._stream())
-        self._check(rc, "psalm_window_attention_x3_split" if x3 else "psalm_window_attention_split")
+        rc = self.lib.psalm_window_attention_split(self._p(qkv), self._p(bias_table), self._p(a_inv), self._p(bound_par), self._p(so), Kp,
+                                                   self._p(inv), B, nWh, nWw, C, heads, ws, shift, self._stream())
+        self._check(rc, "psalm_window_attention_split")
         return SplitF16(so, inv, C)
 
     def causal_attention(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot):
@@ -630,42 +628,6 @@ class Ops:
                                                        self._p(split_inv), self._p(cos), self._p(sin), self._p(key_mask), self._p(ws),
                                                        B, L, heads, head_dim, rot, self._stream())
         self._check(rc, "psalm_causal_attention_f32_split")
-        return split_out
-
-    def _causal_x3_ws(self, B, L, heads):
-        self.lib.psalm_causal_attention_x3_workspace.restype = c_long
-        nbytes = self.lib.psalm_causal_attention_x3_workspace(B, L, heads)
-        key = ("causal_x3_ws", nbytes)
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return ws
-
-    def causal_attention_x3(self, buf, q_off, k_off, v_off, out, o_off, cos, sin, key_mask, B, L, heads, head_dim, rot, a_scale, bound_par):
-        """causal_attention on fp32 q | k | v columns in split-f16 arithmetic (psalm_causal_attention_x3): Q.K^T and P.V as three f16
-        matrix-core products of 22-bit operands.  a_scale (n,) / bound_par (4,) float32: the bound of |v|, max(a_scale) * bound_par[2] +
-        bound_par[3] (see psalm_gemm_x3_split)."""
-        if buf.dtype != torch.float32 or out.dtype != torch.float32 or a_scale.dtype != torch.float32 or bound_par.numel() != 4:
-            raise PsalmHipError("causal_attention_x3: float32 buffers, float32 a_scale, 4 bound parameters")
-        rc = self.lib.psalm_causal_attention_x3(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._pv(out), c_long(out.stride(0)),
-                                                o_off, self._p(cos), self._p(sin), self._p(key_mask), self._p(a_scale), int(a_scale.numel()),
-                                                self._p(bound_par), self._p(self._causal_x3_ws(B, L, heads)), B, L, heads, head_dim, rot,
-                                                self._stream())
-        self._check(rc, "psalm_causal_attention_x3")
-        return out
-
-    def causal_attention_x3_split(self, buf, q_off, k_off, v_off, split_out, split_inv, split_col_off, cos, sin, key_mask, B, L, heads,
-                                  head_dim, rot, a_scale, bound_par):
-        """... whose output goes, in split-f16 form under the row scales 1/split_inv, into columns split_col_off.. of `split_out`
-        (as causal_attention_split)."""
-        if buf.dtype != torch.float32 or split_out.dtype != torch.float16 or split_inv.dtype != torch.float32 or a_scale.dtype != torch.float32:
-            raise PsalmHipError("causal_attention_x3_split: float32 qkv buffer, float16 split buffer, float32 scales")
-        rc = self.lib.psalm_causal_attention_x3_split(self._pv(buf), c_long(buf.stride(0)), q_off, k_off, v_off, self._p(split_out),
-                                                      c_long(split_out.stride(0)), split_out.shape[1] // 2, split_col_off, self._p(split_inv),
-                                                      self._p(cos), self._p(sin), self._p(key_mask), self._p(a_scale), int(a_scale.numel()),
-                                                      self._p(bound_par), self._p(self._causal_x3_ws(B, L, heads)), B, L, heads, head_dim, rot,
-                                                      self._stream())
-        self._check(rc, "psalm_causal_attention_x3_split")
         return split_out
 
     def mha_attention(self, q, k, v, B, Lq, Lk, heads, mask=None, row_all_masked=None):
@@ -948,6 +910,18 @@ class Ops:
                                              self._p(loc), self._p(attw), self._p(out), _dt(out), B, S, M, D, L, Lq, P, self._stream())
         self._check(rc, "psalm_msda_forward_dev")
         return out
+
+    def msda_policy(self, v: int):
+        """psalm_msda_set_policy: 1 / 0 = LDS-staged kernel on (default) / off; 2 / 3 = gather kernel in XCD-band / linear query order"""
+        self._check(self._cdll_raw.psalm_msda_set_policy(int(v)), "psalm_msda_set_policy")
+
+    def msda_lds_applicable(self, spatial_shapes, level_start, B, D, dtype=torch.float32) -> bool:
+        """does msda_fused take the LDS-staged kernel for this level table?"""
+        L = len(spatial_shapes)
+        sh = (ctypes.c_int64 * (2 * L))(*[int(x) for hw in spatial_shapes for x in hw])
+        st = (ctypes.c_int64 * L)(*[int(x) for x in level_start])
+        S = sum(int(h) * int(w) for h, w in spatial_shapes)
+        return bool(self._cdll_raw.psalm_msda_lds_applicable(sh, st, L, S, B, D, F32 if dtype == torch.float32 else BF16))
 
     def msda_fused(self, value, spatial_shapes, level_start, offsets_logits, M, out_dtype=None):
         """value (B,S,M*D); offsets_logits (B,S,M*L*P*3) f32 = [offsets | logits] -> (B,S,M*D)."""

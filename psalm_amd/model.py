@@ -132,10 +132,6 @@ class PSALM:
         # accumulators (psalm_gemm_x3_split, `paired`) -- results bit for bit those of the un-permuted layout.  A construction-time
         # choice (the weights are laid out for it): such a model cannot be switched to fuse_split = False afterwards.
         self.so_paired = self.fuse_split if paired_split_stores is None else (bool(paired_split_stores) and self.fuse_split)
-        # f16x3: the Phi attention's two contractions (Q.K^T, P.V) in the mode's own arithmetic -- three f16 matrix-core products of 22-bit
-        # operands, fp32 softmax -- instead of on the fp32 matrix instruction (r04: 64 -> ? us per layer; False = the r02 / r03 kernel)
-        self.attn_x3 = self.fuse_split
-        self.win_x3 = self.fuse_split                 # ... and the Swin window attention's (psalm_window_attention_x3_split)
         self._side = None
         self.w: Dict[str, torch.Tensor] = {}
         self.paired: Dict[str, bool] = {}            # linear name -> its weight rows are permuted for paired split-f16 stores
@@ -491,7 +487,7 @@ class PSALM:
                     xw = o.swin_window_gather(x, w[q + "n1.g"], w[q + "n1.b"], B, Hc, Wc, ws, shift, out_dtype=self.adt)
                 qkv = o.gemm(xw, w[q + "qkv.w"], w[q + "qkv.b"], out_dtype=self.adt)
                 if x3f and self.fuse_split and ws == 12 and isinstance(xw, H.SplitF16):      # f16x3: the output leaves as the projection GEMM's split operand
-                    aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift, x3=self.win_x3)
+                    aw = o.window_attention_split(qkv, w[q + "rpb"], xw.inv_scale, w[q + "qkv.bnd"], B, nWh, nWw, heads, ws, shift)
                 else:
                     aw = o.window_attention(qkv, w[q + "rpb"], B, nWh, nWw, heads, ws, shift)
                 pw = o.gemm(aw, w[q + "proj.w"], w[q + "proj.b"], out_dtype=self.adt)
@@ -768,12 +764,8 @@ class PSALM:
                 o.gemm_x3_split(h, w[f"llm{i}.w1"], w[f"llm{i}.b1"], H.ACT_GELU_NEW, a2, inv2, w[f"llm{i}.bnd"], split_col_off=Hd,
                                 split_col_start=3 * Hd, act_col_start=3 * Hd, out=big, global_rows=True,
                                 paired=self.paired.get(f"llm{i}", False))
-                if self.attn_x3:                     # Q.K^T and P.V as three f16 products of 22-bit operands (csrc/attention_x3.hip)
-                    o.causal_attention_x3_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                                cfg.rotary_dim, h.inv_scale, w[f"llm{i}.bnd"])
-                else:                                # ... on the fp32 matrix instruction
-                    o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
-                                             cfg.rotary_dim)
+                o.causal_attention_split(big, 2 * Hd, 0, Hd, a2, inv2, 0, cos, sin, key_mask, B, L, cfg.num_heads, cfg.head_dim,
+                                         cfg.rotary_dim)
                 if last or Hd % 64 != 0 or Hd > 2048:
                     x = o.gemm(H.SplitF16(a2, inv2, Hd + I), w[f"llm{i}.w2"], w[f"llm{i}.b2"], residual=x, out_dtype=torch.float32)
                     h = o.layernorm(x, ng, nb, cfg.layer_norm_eps, out_dtype=torch.float32) if last else \

@@ -402,11 +402,6 @@ inline emu::f32x16_t emu_mfma_32x32x16_f16(emu::f16x8_t a, emu::f16x8_t b, emu::
     emu::AB8H m{a, b};
     return emu::mfma<32, 8, emu::AB8H, emu::f32x16_t, 16>(m, c, emu::ga8h, emu::gb8h);
 }
-inline emu::f32x4_t emu_mfma_16x16x32_f16(emu::f16x8_t a, emu::f16x8_t b, emu::f32x4_t c, int, int, int) {
-    emu::AB8H m{a, b};
-    return emu::mfma<16, 8, emu::AB8H, emu::f32x4_t, 4>(m, c, emu::ga8h, emu::gb8h);
-}
-#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_mfma_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16

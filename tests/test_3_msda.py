@@ -134,6 +134,40 @@ def test_fused_matches_explicit(ops, B, shapes):
     assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
 
 
+@pytest.mark.parametrize("shapes,off_scale", [([(8, 8), (16, 16), (32, 32)], 1.5), ([(32, 32), (16, 16), (8, 8)], 6.0), ([(16, 24), (32, 48), (64, 96)], 3.0)])
+def test_fused_lds_staged_matches_gather_and_reference(ops, shapes, off_scale):
+    """r04: the LDS-staged fused kernel (block = (tile, head), the level windows copied once into LDS) against the L2-gather kernel and the
+    torch restatement: border tiles, both level orders, a non-square pyramid, and sampling offsets far beyond the 3-pixel halo (those
+    samples take their corner patch from global memory).  Same per-sample arithmetic as the gather kernel: bit-identical results."""
+    B, M, D, P, L = 1, 8, 32, 4, 3
+    S = sum(h * w for h, w in shapes)
+    st = _starts(shapes)
+    g = torch.Generator().manual_seed(9)
+    value = torch.randn(B, S, M * D, generator=g)
+    ow = torch.randn(B, S, M * L * P * 3, generator=g)
+    ow[..., : M * L * P * 2] *= off_scale
+    off = ow[..., : M * L * P * 2].reshape(B, S, M, L, P, 2)
+    aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, S, M, L * P), -1).view(B, S, M, L, P)
+    refs = []
+    for (H_, W_) in shapes:
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing="ij")
+        refs.append(torch.stack((rx.reshape(-1) / W_, ry.reshape(-1) / H_), -1))
+    ref_pts = torch.cat(refs, 0)[None, :, None, None, None, :]
+    norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)[None, None, None, :, None, :]
+    want = O.msda_core(value.view(B, S, M, D), shapes, st, ref_pts + off / norm, aw)
+    d = ops.device
+    ops.msda_policy(1)
+    assert ops.msda_lds_applicable(shapes, st, B, D) and not ops.msda_lds_applicable([(8, 4), (16, 8), (24, 16)], [0, 32, 160], B, D)
+    got = ops.msda_fused(value.to(d), shapes, st, ow.to(d), M).cpu()
+    ops.msda_policy(0)
+    try:
+        gather = ops.msda_fused(value.to(d), shapes, st, ow.to(d), M).cpu()
+    finally:
+        ops.msda_policy(1)
+    assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
+    assert torch.equal(got, gather)
+
+
 def test_plugin_module_by_name_device_side_level_table(ops, monkeypatch):
     """Seam B1: import the extension module by the reference's name and call it the way MSDeformAttnFunction.forward does
     (ops/functions/ms_deform_attn_func.py:34-39): `spatial_shapes` / `level_start_index` are int64 TENSORS on the op's device and stay

@@ -1,3 +1,15 @@
+// EXPERIMENT, NOT PART OF THE PRODUCT LIBRARY (r04; not compiled by psalm_amd/build.py).  Phi prefill attention and Swin window attention with their
+// contractions on the f16 matrix cores in split-f16 arithmetic instead of on the fp32 matrix instruction -- built, unit-tested (emulator + MI355X),
+// measured in the model and TAKEN OUT again (VERDICT r03 "Next" #7 asked for a result or a committed refutation; this is the refutation):
+//   form                                              Phi kernel + pre-pass     images/s (same box A/B)      wide parity, 78 inputs vs the fp32 oracle
+//   fp32 matrix instruction (the product, r02 ..)     64.1 + 7.8 us / layer     48.7 - 48.9                  panoptic {11}, referring {(11,1)} moved > 1e-4
+//   S and O as 3 products of 22-bit operands          42.1 + 11.9               49.7 (+1.9 %)                panoptic {8 (5.9e-2), 11}, referring {(11,1)}
+//   S as 6 products of 33-bit operands (fp32-class    57.9 + 12.5               48.1 - 48.2 (-0.6 %)         panoptic {8 (5.9e-2)}, referring {(8,1), (8,2), (11,1)}
+//     logits), O as 3; window attention likewise      (window: 1.45 vs 1.38 ms per image)
+// (profiles/r04c_*, r04d_*).  The fast form is VALU-bound after the matrix work shrinks 5x (42 us, not the 23 the matrix pipe would allow) and
+// re-rolls which knife-edge inputs tip (seed 8, which the float64 control of tools/exp_noise_floor_cpu.py leaves in place); the fp32-class form
+// gives the time back.  To build it again: copy into psalm_amd/csrc/, declare the entry points in include/psalm_hip.h, see git history of r04.
+//
 // Phi prefill attention in SPLIT-f16 arithmetic (precision "f16x3"; modeling_phi.py:189-245 attention core, :137-160 / :92-122 partial RoPE):
 // the two contractions of the attention -- S = Q.K^T over the 64 head dims and O = P.V over the keys -- run on the f16 matrix cores instead of
 // on the fp32 matrix instruction; softmax statistics, the online rescale and the merge stay fp32.

@@ -121,7 +121,6 @@ def main():
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--weights-seed", type=int, default=0)
-    ap.add_argument("--attn-fp32", action="store_true", help="f16x3: Phi attention on the fp32 matrix instruction (A/B runs)")
     ap.add_argument("--gemm-policy", default="", help="comma-separated psalm_gemm_set_tile_policy codes (kernel A/B runs)")
     args = ap.parse_args()
     ncpu = os.cpu_count() or 8
@@ -161,8 +160,6 @@ def main():
                 models = {m: PSALM(cfg, sd, precision=m, use_graphs=False) for m in modes}
             cur_task = task
             for model in models.values():
-                if args.attn_fp32:
-                    model.attn_x3 = model.win_x3 = False
                 for code in [int(c) for c in args.gemm_policy.split(",") if c]:
                     model.ops.gemm_tile_policy(code)
         for s in seeds:
