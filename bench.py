@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     ap.add_argument("--gemm-policy", default="", help="comma-separated psalm_gemm_set_tile_policy codes applied before the first call (kernel A/B runs)")
-    ap.add_argument("--msda-gather", action="store_true", help="pixel decoder: the L2-gather MSDeformAttn kernel instead of the LDS-staged one (A/B runs)")
+    ap.add_argument("--msda-per-lane", action="store_true", help="MSDeformAttn: every lane computes all bilinear taps (the r01 - r03 kernel) instead of sharing them in the quad (A/B runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still run init_process_group('nccl'), the weight broadcast, the checksum all-reduce and the barriers (RCCL dry run on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
@@ -128,7 +128,7 @@ def main():
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
-    if args.msda_gather:
+    if args.msda_per_lane:
         model.ops.msda_policy(0)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
@@ -325,7 +325,7 @@ def main():
             elif name == "psalm_msda_fused":
                 esz_v, esz_o = (2 if a[1] == 1 else 4), (2 if a[6] == 1 else 4)
                 B_, S_, M_, D_, L_, P_ = a[7], a[8], a[9], a[10], a[11], a[12]
-                nbytes, kn = B_ * S_ * (M_ * D_ * esz_v + M_ * L_ * P_ * 3 * 4 + M_ * D_ * esz_o), ("msda_fused8_kernel" if args.msda_gather else "msda_fused_lds_kernel")
+                nbytes, kn = B_ * S_ * (M_ * D_ * esz_v + M_ * L_ * P_ * 3 * 4 + M_ * D_ * esz_o), "msda_fused8_kernel"
             elif name == "psalm_resize_planes":                                   # (x, x_dtype, out, out_dtype, N, h, w, hc, wc, H, W, stream): read the crop, write the planes
                 nbytes = a[4] * (a[7] * a[8] * (2 if a[1] == 1 else 4) + a[9] * a[10] * (2 if a[3] == 1 else 4))
                 if nbytes < (64 << 20):

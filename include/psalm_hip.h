@@ -26,7 +26,7 @@ const char* psalm_last_error(void);
 /* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
- * 5: psalm_msda_set_policy, psalm_msda_lds_applicable (the LDS-staged MSDA kernel). */
+ * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone). */
 #define PSALM_ABI_VERSION 5
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -55,11 +55,9 @@ int psalm_msda_forward_dev(const void* value, int value_dtype, const int64_t* sp
 int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
                      const int64_t* level_start_host, const float* offsets_logits, void* out, int out_dtype, int B, int S,
                      int M, int D, int L, int P, void* stream);
-/* Tuning / test knob of psalm_msda_fused: 1 (default) = the LDS-staged kernel (block = (tile of the normalised image, head): the three level
- * windows copied once into LDS) wherever its geometry holds -- fp32 value, head dim 32, one image, a 4 : 2 : 1 pyramid with an even coarsest
- * level --, 0 = the L2-gather kernel everywhere; 2 / 3 = the gather kernel's query order (XCD bands / linear). */
+/* Tuning / test knob of psalm_msda_fused (head dim 32): 1 (default) = the bilinear taps of a sample are computed once per (query, head) and
+ * shared by its 4 channel-group lanes, 0 = every lane computes all samples (the r01 - r03 kernel).  Same values either way. */
 int psalm_msda_set_policy(int v);
-int psalm_msda_lds_applicable(const int64_t* spatial_shapes_host, const int64_t* level_start_host, int L, int S, int B, int D, int value_dtype);
 
 
 /* ------------------------------------------------------------------------------------------------------------------

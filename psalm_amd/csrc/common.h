@@ -119,16 +119,27 @@ __device__ __forceinline__ void psalm_split_words(float y, unsigned& hw, unsigne
 #define PSALM_BUF_OOB 0x80000000u
 #ifdef PSALM_EMU_BUILD
 __device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) { return __shfl_xor(v, 1); }   // value of lane ^ 1
+__device__ __forceinline__ unsigned psalm_quad_swap2(unsigned v) { return __shfl_xor(v, 2); }      // value of lane ^ 2
+template <int P> __device__ __forceinline__ unsigned psalm_quad_bcast(unsigned v) { return __shfl(v, ((threadIdx.x & 63) & ~3) | P); }   // lane P of this lane's group of 4
 struct psalm_rsrc { char* base; unsigned bytes; };
 __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) { return psalm_rsrc{(char*)p, bytes}; }
 __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<float*>(r.base + off) = v; }
 __device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { if (off < r.bytes && r.bytes - off >= 4u) *reinterpret_cast<unsigned*>(r.base + off) = v; }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) { return (off < r.bytes && r.bytes - off >= 4u) ? *reinterpret_cast<const float*>(r.base + off) : 0.f; }
+__device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128(psalm_rsrc r, unsigned off) {
+    return (off < r.bytes && r.bytes - off >= 16u) ? *reinterpret_cast<const psalm_u32x4*>(r.base + off) : psalm_u32x4{0u, 0u, 0u, 0u};
+}
 __device__ __forceinline__ void psalm_buf_store_f32_s(float v, psalm_rsrc r, unsigned voff, unsigned soff) { if (voff < PSALM_BUF_OOB) psalm_buf_store_f32(v, r, voff + soff); }
 __device__ __forceinline__ float psalm_buf_load_f32_s(psalm_rsrc r, unsigned voff, unsigned soff) { return voff < PSALM_BUF_OOB ? psalm_buf_load_f32(r, voff + soff) : 0.f; }
 #else
 __device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) {                              // DPP quad_perm [1,0,3,2]: no LDS crossbar
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned psalm_quad_swap2(unsigned v) {                                 // DPP quad_perm [2,3,0,1]
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+}
+template <int P> __device__ __forceinline__ unsigned psalm_quad_bcast(unsigned v) {                // DPP quad_perm [P,P,P,P]: lane P of the group of 4
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, P * 0x55, 0xF, 0xF, true);
 }
 typedef __amdgpu_buffer_rsrc_t psalm_rsrc;
 __device__ __forceinline__ psalm_rsrc psalm_make_rsrc(const void* p, unsigned bytes) {
@@ -140,6 +151,11 @@ __device__ __forceinline__ void psalm_buf_store_f32(float v, psalm_rsrc r, unsig
 __device__ __forceinline__ void psalm_buf_store_u32(unsigned v, psalm_rsrc r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
 __device__ __forceinline__ float psalm_buf_load_f32(psalm_rsrc r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+typedef unsigned psalm_u32x4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128(psalm_rsrc r, unsigned off) {          // buffer_load_dwordx4 ... offen: one VGPR of address
+    const psalm_u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return psalm_u32x4{v.x, v.y, v.z, v.w};
 }
 // ... with a wave-uniform part of the offset in an SGPR (soff; buffers < 2^31 bytes, a per-lane voff >= PSALM_BUF_OOB still drops the access):
 // one VGPR of address per access instead of a 64-bit pointer

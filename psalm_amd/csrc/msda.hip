@@ -35,6 +35,7 @@ __device__ __forceinline__ void st4(bf16_t* p, f32x4_s v) {
     *reinterpret_cast<bf16x4_s*>(p) = bf16x4_s{f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
 }
 
+template <int V> struct msda_ic { static constexpr int value = V; };
 #define MSDA_MAX_LEVELS 8
 struct MsdaLevels {
     int H[MSDA_MAX_LEVELS], W[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
@@ -106,7 +107,12 @@ __device__ __forceinline__ MsdaTaps8<TV> msda_taps8(const TV* __restrict__ vbase
 // samples every level around its own normalised position, so the corner rows an XCD touches are its band of each level (+ a halo):
 // 1/8 of the 22 MB fp32 value tensor = 2.75 MB, resident in that XCD's 4 MB L2 -- with the linear order every XCD streamed the whole
 // tensor through its L2 (r01 PMC: 1.9x the compulsory bytes from the fabric).
-template <typename TV, typename TO, int L, int P, bool XCD_BANDS = false>
+// QUAD = true (D == 32: the 4 lanes of a (query, head) are one DPP quad): lane g owns sampling point p = g of every level -- its softmax
+// term, sampling location, clamped corner offsets and the four corner weights (times the attention weight) are computed ONCE and handed to
+// the other three lanes with quad broadcasts, instead of every lane computing all L * P samples for itself.  r04e: the LDS-staged form of this
+// kernel (tools/experiments/msda_lds_staged.hip) removed the L2 fetches and got SLOWER (108 vs 57 us): what the kernel spends its time on is
+// this per-sample arithmetic, ~60 instructions per sample, 4 x redundant.
+template <typename TV, typename TO, int L, int P, bool XCD_BANDS = false, bool QUAD = false>
 __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__ value, MsdaLevels lv,
                                                           const float* __restrict__ ow, TO* __restrict__ out, int B, int S,
                                                           int M, int D) {
@@ -147,6 +153,87 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
         const float* row = ow + ((long)b * Lq + q) * (M * LP * 3);
         const float* offp = row + m * LP * 2;
         const float* lgp = row + M * LP * 2 + m * LP;
+        const int row_stride = M * D;
+        const TV* vb = value + (long)b * S * row_stride + m * D + g * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        if constexpr (QUAD) {
+            static_assert(P == 4, "one sampling point per lane of the quad");
+            // ---- this lane's share: point p = g of every level
+            float lgq[L];
+            float mx = -3.4e38f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) { lgq[l] = lgp[l * P + g]; mx = fmaxf(mx, lgq[l]); }
+            mx = fmaxf(mx, __builtin_bit_cast(float, psalm_swap_adjacent(__builtin_bit_cast(unsigned, mx))));
+            mx = fmaxf(mx, __builtin_bit_cast(float, psalm_quad_swap2(__builtin_bit_cast(unsigned, mx))));
+            float den = 0.f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) { lgq[l] = __expf(lgq[l] - mx); den += lgq[l]; }
+            den += __builtin_bit_cast(float, psalm_swap_adjacent(__builtin_bit_cast(unsigned, den)));
+            den += __builtin_bit_cast(float, psalm_quad_swap2(__builtin_bit_cast(unsigned, den)));
+            const float inv = 1.f / den;
+            // corner BYTE offsets from `value` (this lane's channel offset added at the fetch): fetched through a buffer descriptor -- one address
+            // register per corner (with 64-bit pointers the compiler materialised all 48 addresses up front: 214 VGPRs and serialized fetches)
+            const psalm_rsrc vr = psalm_make_rsrc(value, (unsigned)((long)B * S * row_stride * (long)sizeof(TV)));
+            const unsigned lane_b = (unsigned)(((long)b * S * row_stride + m * D + g * 8) * (long)sizeof(TV));
+            auto fetch = [&](unsigned off, float* v8) {            // 8 channels at byte offset `off` of this lane's slice
+                if constexpr (sizeof(TV) == 4) {
+                    const psalm_u32x4 a = psalm_buf_load_b128(vr, lane_b + off), b2 = psalm_buf_load_b128(vr, lane_b + off + 16u);
+                    v8[0] = __builtin_bit_cast(float, a.x); v8[1] = __builtin_bit_cast(float, a.y); v8[2] = __builtin_bit_cast(float, a.z);
+                    v8[3] = __builtin_bit_cast(float, a.w); v8[4] = __builtin_bit_cast(float, b2.x); v8[5] = __builtin_bit_cast(float, b2.y);
+                    v8[6] = __builtin_bit_cast(float, b2.z); v8[7] = __builtin_bit_cast(float, b2.w);
+                } else {
+                    const psalm_u32x4 a = psalm_buf_load_b128(vr, lane_b + off);
+                    const unsigned w4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v8[2 * e] = __builtin_bit_cast(float, w4[e] << 16);
+                        v8[2 * e + 1] = __builtin_bit_cast(float, w4[e] & 0xffff0000u);
+                    }
+                }
+            };
+#pragma unroll 1                                                   // (unrolled, the compiler hoists the fetches of all 12 samples: 256 VGPRs + AGPRs, 1 wave per SIMD)
+            for (int l = 0; l < L; ++l) {
+                // level table: constant kernarg offsets + select on l (see the note in the generic loop below)
+                int Hl = lv.H[0], Wl = lv.W[0], sl = lv.start[0];
+                float lgl = lgq[0];
+#pragma unroll
+                for (int j = 1; j < L; ++j)
+                    if (l == j) { Hl = lv.H[j]; Wl = lv.W[j]; sl = lv.start[j]; lgl = lgq[j]; }
+                // ---- this lane's sample of the level: point p = g
+                const int i = l * P + g;
+                const float lx = ref_x + offp[2 * i] / Wl, ly = ref_y + offp[2 * i + 1] / Hl;
+                const MsdaTaps8<TV> tp = msda_taps8<TV>(vb + (long)sl * row_stride, Hl, Wl, row_stride, lx, ly);
+                const float wgt = lgl * inv;
+                unsigned toff[4];                                 // corner byte offsets from `value` + this (b, head)'s base, without the lane's channels
+                float tw[4];                                      // corner weight x attention weight
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { toff[c] = (unsigned)((tp.p[c] - vb) * (long)sizeof(TV)); tw[c] = tp.w[c] * wgt; }
+                // ---- all four samples of the level for this lane's 8 channels, taps from the owning lane; two samples' fetches in flight
+                auto pair = [&](auto PC0) {
+                    constexpr int p0 = decltype(PC0)::value;
+                    float w[2][4], v[2][4][8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        fetch(psalm_quad_bcast<p0>(toff[c]), v[0][c]);
+                        fetch(psalm_quad_bcast<p0 + 1>(toff[c]), v[1][c]);
+                        w[0][c] = __builtin_bit_cast(float, psalm_quad_bcast<p0>(__builtin_bit_cast(unsigned, tw[c])));
+                        w[1][c] = __builtin_bit_cast(float, psalm_quad_bcast<p0 + 1>(__builtin_bit_cast(unsigned, tw[c])));
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            acc[k] += w[pp][0] * v[pp][0][k] + w[pp][1] * v[pp][1][k] + w[pp][2] * v[pp][2][k] + w[pp][3] * v[pp][3][k];
+                };
+                pair(msda_ic<0>{});
+                pair(msda_ic<2>{});
+            }
+            static_assert(L <= 3, "levels of the quad form");
+            st8(out + (((long)b * Lq + q) * M + m) * D + g * 8, acc);
+            continue;
+        }
         float lg[LP];
         float mx = -3.4e38f;
 #pragma unroll
@@ -155,11 +242,6 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
 #pragma unroll
         for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
         const float inv = 1.f / den;
-        const int row_stride = M * D;
-        const TV* vb = value + (long)b * S * row_stride + m * D + g * 8;
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
         constexpr int PB = (P % 2 == 0) ? 2 : 1;                  // sampling points whose 4 * PB corner fetches are in flight together
 #pragma unroll 1                                                   // (unrolled, the tap set-up of all L*P samples is hoisted: 256 VGPRs, 1 wave/SIMD)
         for (int l = 0; l < L; ++l) {
@@ -198,125 +280,6 @@ __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__
         }
         st8(out + (((long)b * Lq + q) * M + m) * D + g * 8, acc);
     }
-}
-
-// ---- LDS-staged form of the fused kernel (r04; VERDICT r02 / r03: "LDS-staged MSDA neighbourhoods").  The fused8 kernel above fetches every
-// bilinear corner from L2: 2.06 M samples x 4 corners x 128 B = 1.05 GB of L2 requests per launch for a 22 MB value tensor (r02h counters:
-// 8.2 M requests, 89 % L2 hits, ~20 TB/s -- L2-request bound, 0.16 of the HBM roofline).  The samples of neighbouring queries cluster: a query
-// at normalised position p samples every level around p (offsets of a few level pixels), so all queries of one TILE of the normalised image
-// -- n_l x n_l pixels of level l, n_l = 2 / 4 / 8 for the 32 / 64 / 128 pyramids: 84 queries -- read the same three small windows.
-// Block = (tile, head): the windows (n_l + 2 R + 2)^2 positions x 32 channels of the head, R = MSDA_R level pixels of halo, 500 positions =
-// 64 KB at R = 3) are copied ONCE into LDS with global_load_lds (8 positions per wave instruction; the 16-byte chunk order inside a position
-// XOR-swizzled by the position so that the 16 lanes of a ds_read_b128 group spread over the banks), then every (query, 8-channel group)
-// thread takes its 48 corner values from LDS.  A sample whose 2 x 2 corner patch leaves the window (offsets beyond R) reads that patch from
-// global memory instead: any offset is handled, only slower.  L2 -> CU traffic: 2048 blocks x 64 KB = 131 MB instead of 1.05 GB.
-#define MSDA_R 3
-struct MsdaTiles { int tgy, tgx, n[3], ww[3], wbase[3], qoff[3], npos; };
-template <typename TO>
-__global__ void __launch_bounds__(384) PSALM_WAVES_PER_EU(3) msda_fused_lds_kernel(const float* __restrict__ value, MsdaLevels lv, MsdaTiles tl,
-                                                             const float* __restrict__ ow, TO* __restrict__ out, int S, int M) {
-    constexpr int L = 3, P = 4, LP = 12, D = 32;
-    __shared__ __attribute__((aligned(16))) float win[504 * D];          // positions x 32 channels (chunk-swizzled), 63 copy instructions
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // block -> (tile, head): XCD k (= block % 8) owns the k-th band of tile rows (its L2 holds that band of every level), heads innermost
-    const int ntiles = tl.tgy * tl.tgx;
-    int tile, m;
-    if (tl.tgy % 8 == 0) {
-        const int band = blockIdx.x & 7, j = blockIdx.x >> 3, per_band = ntiles / 8;
-        tile = band * per_band + j / M;
-        m = j % M;
-    } else { tile = blockIdx.x / M; m = blockIdx.x % M; }
-    const int ty = tile / tl.tgx, tx = tile % tl.tgx;
-    const int row_stride = M * D;
-    // ---- stage the three windows
-    for (int i = wave; i < 63; i += 6) {
-        int pp = min(8 * i + (lane >> 3), tl.npos - 1);
-        const int slot = lane & 7, chunk = slot ^ (pp & 7);
-        int l = 0;
-#pragma unroll
-        for (int j = 1; j < L; ++j)
-            if (pp >= tl.wbase[j]) l = j;
-        int Hl = lv.H[0], Wl = lv.W[0], sl = lv.start[0], nl = tl.n[0], wwl = tl.ww[0], wb = tl.wbase[0];
-#pragma unroll
-        for (int j = 1; j < L; ++j)
-            if (l == j) { Hl = lv.H[j]; Wl = lv.W[j]; sl = lv.start[j]; nl = tl.n[j]; wwl = tl.ww[j]; wb = tl.wbase[j]; }
-        const int wy = (pp - wb) / wwl, wx = (pp - wb) - wy * wwl;
-        const int y = min(max(ty * nl - MSDA_R - 1 + wy, 0), Hl - 1), x = min(max(tx * nl - MSDA_R - 1 + wx, 0), Wl - 1);
-        psalm_glds16(value + ((long)(sl + y * Wl + x) * M + m) * D + chunk * 4, win + (long)i * 8 * D);
-    }
-    __syncthreads();                                                     // (drains the copies: vmcnt(0) + barrier)
-    // ---- thread -> (query of the tile, 8-channel group)
-    const int item = tid;
-    if (item >= 84 * 4) return;
-    const int qidx = item >> 2, g = item & 3;
-    int lq = 0;
-#pragma unroll
-    for (int j = 1; j < L; ++j)
-        if (qidx >= tl.qoff[j]) lq = j;
-    int Hq = lv.H[0], Wq = lv.W[0], sq = lv.start[0], nq = tl.n[0], qo = tl.qoff[0];
-#pragma unroll
-    for (int j = 1; j < L; ++j)
-        if (lq == j) { Hq = lv.H[j]; Wq = lv.W[j]; sq = lv.start[j]; nq = tl.n[j]; qo = tl.qoff[j]; }
-    const int qy = ty * nq + (qidx - qo) / nq, qx = tx * nq + (qidx - qo) % nq;
-    const int q = sq + qy * Wq + qx;
-    const float ref_x = (qx + 0.5f) / Wq, ref_y = (qy + 0.5f) / Hq;
-    const float* row = ow + (long)q * (M * LP * 3);
-    const float* offp = row + m * LP * 2;
-    const float* lgp = row + M * LP * 2 + m * LP;
-    float lg[LP];
-    float mx = -3.4e38f;
-#pragma unroll
-    for (int i = 0; i < LP; ++i) { lg[i] = lgp[i]; mx = fmaxf(mx, lg[i]); }
-    float den = 0.f;
-#pragma unroll
-    for (int i = 0; i < LP; ++i) { lg[i] = __expf(lg[i] - mx); den += lg[i]; }
-    const float inv = 1.f / den;
-    const float* vb = value + m * D + g * 8;
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll 1
-    for (int l = 0; l < L; ++l) {
-        int Hl = lv.H[0], Wl = lv.W[0], sl = lv.start[0], nl = tl.n[0], wwl = tl.ww[0], wb = tl.wbase[0];
-#pragma unroll
-        for (int j = 1; j < L; ++j)
-            if (l == j) { Hl = lv.H[j]; Wl = lv.W[j]; sl = lv.start[j]; nl = tl.n[j]; wwl = tl.ww[j]; wb = tl.wbase[j]; }
-        const int oy = ty * nl - MSDA_R - 1, ox = tx * nl - MSDA_R - 1;   // level pixel of window position (0, 0)
-        const float* vl = vb + (long)sl * row_stride;
-#pragma unroll 2
-        for (int p = 0; p < P; ++p) {
-            const int i = l * P + p;
-            // bilinear taps: the expression of msda_taps8 (ms_deform_im2col_cuda.cuh:38-89; corners clamped into the level, validity in the weights)
-            const float h_im = (ref_y + offp[2 * i + 1] / Hl) * Hl - 0.5f;
-            const float w_im = (ref_x + offp[2 * i] / Wl) * Wl - 0.5f;
-            const bool inb = h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
-            const int h_low = (int)floorf(inb ? h_im : 0.f), w_low = (int)floorf(inb ? w_im : 0.f);
-            const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
-            const bool h0 = h_low >= 0, h1 = h_low + 1 <= Hl - 1, w0 = w_low >= 0, w1 = w_low + 1 <= Wl - 1;
-            const int ha = max(h_low, 0), hb = min(h_low + 1, Hl - 1), wa = max(w_low, 0), wbx = min(w_low + 1, Wl - 1);
-            const float cw[4] = {(inb && h0 && w0) ? hh * hw : 0.f, (inb && h0 && w1) ? hh * lw : 0.f,
-                                 (inb && h1 && w0) ? lh * hw : 0.f, (inb && h1 && w1) ? lh * lw : 0.f};
-            const int ys[4] = {ha, ha, hb, hb}, xs[4] = {wa, wbx, wa, wbx};
-            float v[4][8];
-            const bool in_win = !inb || (ha >= oy && hb < oy + wwl && wa >= ox && wbx < ox + wwl);
-            if (in_win) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int pos = inb ? wb + (ys[c] - oy) * wwl + (xs[c] - ox) : wb;      // (a sample outside the padded image: weights 0, any slot)
-                    const psalm_f32x4 a = *reinterpret_cast<const psalm_f32x4*>(&win[pos * D + (((2 * g) ^ (pos & 7)) << 2)]);
-                    const psalm_f32x4 b = *reinterpret_cast<const psalm_f32x4*>(&win[pos * D + (((2 * g + 1) ^ (pos & 7)) << 2)]);
-                    v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w; v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
-                }
-            } else {                                                     // offsets beyond the halo: the patch comes from global memory
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ld8(vl + ((long)ys[c] * Wl + xs[c]) * row_stride, v[c]);
-            }
-            const float wgt = inb ? lg[i] * inv : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += wgt * (cw[0] * v[0][k] + cw[1] * v[1][k] + cw[2] * v[2][k] + cw[3] * v[3][k]);
-        }
-    }
-    st8(out + ((long)q * M + m) * D + g * 8, acc);
 }
 
 // Plugin form: explicit sampling locations / attention weights (the reference op's contract).
@@ -413,14 +376,12 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const TV* __restrict__ 
     }
 }
 
-// psalm_msda_set_policy: 1 (default) = the LDS-staged kernel where its geometry conditions hold, 0 = the L2-gather kernel everywhere (A/B runs,
-// tools/bench_msda.py); 2 / 3 = the L2-gather kernel in XCD-band (default) / linear query order
-static int g_msda_lds = 1, g_msda_linear = 0;
+// A/B knob of the r04 measurement pass (tools/bench_msda.py): 1 = quad-shared taps (default), 0 = every lane computes all samples (r01 - r03)
+static int g_msda_quad = 1;
 extern "C" int psalm_msda_set_policy(int v) {
-    if (v == 0 || v == 1) { g_msda_lds = v; return 0; }
-    if (v == 2 || v == 3) { g_msda_linear = v - 2; return 0; }
-    psalm_set_error("psalm_msda_set_policy: 0 / 1 (LDS-staged kernel off / on), 2 / 3 (gather kernel: XCD bands / linear order)");
-    return -1;
+    if (v != 0 && v != 1) { psalm_set_error("psalm_msda_set_policy: 0 / 1 (quad-shared taps off / on)"); return -1; }
+    g_msda_quad = v;
+    return 0;
 }
 
 static int fill_levels(MsdaLevels& lv, const int64_t* shapes, const int64_t* starts, int L, int S) {
@@ -433,34 +394,6 @@ static int fill_levels(MsdaLevels& lv, const int64_t* shapes, const int64_t* sta
         tot += (long)lv.H[l] * lv.W[l];
     }
     return tot == S ? 0 : -2;
-}
-
-// Geometry of the LDS-staged fused kernel: fp32 value, head dim 32, one image, a 4 : 2 : 1 pyramid (any level order) whose coarsest level has
-// even sides -> tile grid (hmin / 2) x (wmin / 2), n_l = 2 / 4 / 8 pixels of level l per tile side.
-static bool msda_tiles(const MsdaLevels& lv, int L, int B, int S, int D, int value_dtype, MsdaTiles& tl) {
-    if (!(L == 3 && B == 1 && D == 32 && value_dtype == PSALM_F32 && S > 0)) return false;
-    int hmin = lv.H[0], wmin = lv.W[0];
-    for (int l = 1; l < L; ++l) { hmin = lv.H[l] < hmin ? lv.H[l] : hmin; wmin = lv.W[l] < wmin ? lv.W[l] : wmin; }
-    if (hmin % 2 || wmin % 2 || hmin < 2 || wmin < 2) return false;
-    tl.tgy = hmin / 2; tl.tgx = wmin / 2;
-    int seen = 0, pos = 0, qo = 0;
-    for (int l = 0; l < L; ++l) {
-        const int ny = lv.H[l] / tl.tgy, nx = lv.W[l] / tl.tgx;
-        if (lv.H[l] % tl.tgy || lv.W[l] % tl.tgx || ny != nx || !(ny == 2 || ny == 4 || ny == 8) || (seen & ny)) return false;
-        seen |= ny;
-        tl.n[l] = ny; tl.ww[l] = ny + 2 * MSDA_R + 2; tl.wbase[l] = pos; tl.qoff[l] = qo;
-        pos += tl.ww[l] * tl.ww[l];
-        qo += ny * ny;
-    }
-    tl.npos = pos;
-    return pos <= 504 && qo == 84;
-}
-// 1 if psalm_msda_fused takes the LDS-staged kernel for this level table (tests / bench attribution)
-extern "C" int psalm_msda_lds_applicable(const int64_t* spatial_shapes_host, const int64_t* level_start_host, int L, int S, int B, int D,
-                                         int value_dtype) {
-    MsdaLevels lv = {};
-    MsdaTiles tl = {};
-    return g_msda_lds && fill_levels(lv, spatial_shapes_host, level_start_host, L, S) == 0 && msda_tiles(lv, L, B, S, D, value_dtype, tl) ? 1 : 0;
 }
 
 extern "C" int psalm_msda_forward(const void* value, int value_dtype, const int64_t* spatial_shapes_host,
@@ -513,31 +446,24 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
     int rc = fill_levels(lv, spatial_shapes_host, level_start_host, L, S);
     PSALM_CHECK_ARG(rc == 0, "psalm_msda_fused: bad level table");
     const int block = 256;
-    MsdaTiles tl = {};
-    if (g_msda_lds && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0 && msda_tiles(lv, L, B, S, D, value_dtype, tl)) {
-        const unsigned nblk = (unsigned)(tl.tgy * tl.tgx * M);
-        PSALM_DISPATCH(out_dtype, TO, {
-            hipLaunchKernelGGL((msda_fused_lds_kernel<TO>), dim3(nblk), dim3(384), 0, (hipStream_t)stream, (const float*)value, lv, tl,
-                               offsets_logits, (TO*)out, S, M);
-        });
-        PSALM_LAUNCH_END("psalm_msda_fused");
-    }
     if (D % 8 == 0 && (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0) {       // 8 channels per lane
         const long total8 = (long)B * S * M * (D / 8);
         if (total8 == 0) return 0;
-        bool bands = !g_msda_linear && B == 1 && total8 % (block * 8) == 0;       // XCD-band order (see the kernel comment)
+        bool bands = B == 1 && total8 % (block * 8) == 0;                         // XCD-band order (see the kernel comment)
         for (int l = 0; l < L; ++l) bands = bands && lv.H[l] % 8 == 0;
+        // D == 32: the 4 channel-group lanes of a (query, head) are a DPP quad -> taps computed once per group (32-bit element offsets)
+        const bool quad = g_msda_quad && D == 32 && (long)B * S * M * D * 4 < (1L << 31);
+#define MSDA_LAUNCH8(BANDS_, QUAD_, GRID_)                                                                                              \
+        PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {                                                                 \
+            hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4, BANDS_, QUAD_>), dim3((unsigned)(GRID_)), dim3(block), 0,              \
+                               (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);                        \
+        }))
         if (bands) {
-            PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
-                hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4, true>), dim3((unsigned)(total8 / block)), dim3(block), 0,
-                                   (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);
-            }));
+            if (quad) MSDA_LAUNCH8(true, true, total8 / block); else MSDA_LAUNCH8(true, false, total8 / block);
             PSALM_LAUNCH_END("psalm_msda_fused");
         }
-        PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {
-            hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4>), dim3((unsigned)((total8 + block - 1) / block)), dim3(block), 0,
-                               (hipStream_t)stream, (const TV*)value, lv, offsets_logits, (TO*)out, B, S, M, D);
-        }));
+        if (quad) MSDA_LAUNCH8(false, true, (total8 + block - 1) / block); else MSDA_LAUNCH8(false, false, (total8 + block - 1) / block);
+#undef MSDA_LAUNCH8
         PSALM_LAUNCH_END("psalm_msda_fused");
     }
     const long total = (long)B * S * M * (D / 4);

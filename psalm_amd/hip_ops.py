@@ -62,7 +62,7 @@ class _ProfiledLib:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
         if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version", "psalm_gemm_last_kernel",
-                                                         "psalm_gemm_set_tile_policy", "psalm_msda_set_policy") or name.endswith("_workspace"):
+                                                         "psalm_gemm_set_tile_policy") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -912,16 +912,8 @@ class Ops:
         return out
 
     def msda_policy(self, v: int):
-        """psalm_msda_set_policy: 1 / 0 = LDS-staged kernel on (default) / off; 2 / 3 = gather kernel in XCD-band / linear query order"""
+        """psalm_msda_set_policy: 1 (default) / 0 = quad-shared bilinear taps on / off (A/B runs, tests)"""
         self._check(self._cdll_raw.psalm_msda_set_policy(int(v)), "psalm_msda_set_policy")
-
-    def msda_lds_applicable(self, spatial_shapes, level_start, B, D, dtype=torch.float32) -> bool:
-        """does msda_fused take the LDS-staged kernel for this level table?"""
-        L = len(spatial_shapes)
-        sh = (ctypes.c_int64 * (2 * L))(*[int(x) for hw in spatial_shapes for x in hw])
-        st = (ctypes.c_int64 * L)(*[int(x) for x in level_start])
-        S = sum(int(h) * int(w) for h, w in spatial_shapes)
-        return bool(self._cdll_raw.psalm_msda_lds_applicable(sh, st, L, S, B, D, F32 if dtype == torch.float32 else BF16))
 
     def msda_fused(self, value, spatial_shapes, level_start, offsets_logits, M, out_dtype=None):
         """value (B,S,M*D); offsets_logits (B,S,M*L*P*3) f32 = [offsets | logits] -> (B,S,M*D)."""

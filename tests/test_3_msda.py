@@ -132,40 +132,14 @@ def test_fused_matches_explicit(ops, B, shapes):
     want = O.msda_core(value.view(B, S, M, D), shapes, st, loc, aw)
     got = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
     assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
-
-
-@pytest.mark.parametrize("shapes,off_scale", [([(8, 8), (16, 16), (32, 32)], 1.5), ([(32, 32), (16, 16), (8, 8)], 6.0), ([(16, 24), (32, 48), (64, 96)], 3.0)])
-def test_fused_lds_staged_matches_gather_and_reference(ops, shapes, off_scale):
-    """r04: the LDS-staged fused kernel (block = (tile, head), the level windows copied once into LDS) against the L2-gather kernel and the
-    torch restatement: border tiles, both level orders, a non-square pyramid, and sampling offsets far beyond the 3-pixel halo (those
-    samples take their corner patch from global memory).  Same per-sample arithmetic as the gather kernel: bit-identical results."""
-    B, M, D, P, L = 1, 8, 32, 4, 3
-    S = sum(h * w for h, w in shapes)
-    st = _starts(shapes)
-    g = torch.Generator().manual_seed(9)
-    value = torch.randn(B, S, M * D, generator=g)
-    ow = torch.randn(B, S, M * L * P * 3, generator=g)
-    ow[..., : M * L * P * 2] *= off_scale
-    off = ow[..., : M * L * P * 2].reshape(B, S, M, L, P, 2)
-    aw = torch.softmax(ow[..., M * L * P * 2:].reshape(B, S, M, L * P), -1).view(B, S, M, L, P)
-    refs = []
-    for (H_, W_) in shapes:
-        ry, rx = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_), torch.linspace(0.5, W_ - 0.5, W_), indexing="ij")
-        refs.append(torch.stack((rx.reshape(-1) / W_, ry.reshape(-1) / H_), -1))
-    ref_pts = torch.cat(refs, 0)[None, :, None, None, None, :]
-    norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)[None, None, None, :, None, :]
-    want = O.msda_core(value.view(B, S, M, D), shapes, st, ref_pts + off / norm, aw)
-    d = ops.device
-    ops.msda_policy(1)
-    assert ops.msda_lds_applicable(shapes, st, B, D) and not ops.msda_lds_applicable([(8, 4), (16, 8), (24, 16)], [0, 32, 160], B, D)
-    got = ops.msda_fused(value.to(d), shapes, st, ow.to(d), M).cpu()
+    # r04: the bilinear taps of a sample are computed once per (query, head) and shared by its 4 channel-group lanes (quad broadcasts); the
+    # form in which every lane computes all samples (policy 0) differs only in where the attention weight is multiplied in
     ops.msda_policy(0)
     try:
-        gather = ops.msda_fused(value.to(d), shapes, st, ow.to(d), M).cpu()
+        per_lane = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
     finally:
         ops.msda_policy(1)
-    assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
-    assert torch.equal(got, gather)
+    assert (per_lane - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1) and (per_lane - got).abs().max() < 1e-5 * want.abs().max().clamp(min=1)
 
 
 def test_plugin_module_by_name_device_side_level_table(ops, monkeypatch):

@@ -1,6 +1,5 @@
 """MSDeformAttn fused gather micro-benchmark at the 1024^2 pixel-decoder shape (S = 21504, 8 heads x 32, 3 levels x 4 points), fp32 and
-bf16 value / output, per kernel policy: the LDS-staged kernel (fp32 only), the L2-gather kernel in XCD-band and in linear query order.
-    python tools/bench_msda.py"""
+bf16 value / output.      python tools/bench_msda.py"""
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,9 +11,8 @@ shapes = [(32, 32), (64, 64), (128, 128)]
 starts = [0, 1024, 5120]
 S, M, D = 21504, 8, 32
 g = torch.Generator().manual_seed(0)
-for name, pols in (("lds_staged", (1, 2)), ("gather_xcd_bands", (0, 2)), ("gather_linear", (0, 3))):
-  for p_ in pols:
-    ops.msda_policy(p_)
+for pol, name in ((1, "quad_shared_taps"), (0, "taps_per_lane")):
+  ops.msda_policy(pol)
   out = {"kernel": name}
   for dt in (torch.float32, torch.bfloat16):
       value = torch.randn(1, S, M * D, generator=g).to(dt).cuda()
@@ -36,4 +34,3 @@ for name, pols in (("lds_staged", (1, 2)), ("gather_xcd_bands", (0, 2)), ("gathe
   print(json.dumps(out), flush=True)
 
 ops.msda_policy(1)
-ops.msda_policy(2)
