@@ -69,7 +69,6 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     ap.add_argument("--gemm-policy", default="", help="comma-separated psalm_gemm_set_tile_policy codes applied before the first call (kernel A/B runs)")
-    ap.add_argument("--msda-per-lane", action="store_true", help="MSDeformAttn: every lane computes all bilinear taps (the r01 - r03 kernel) instead of sharing them in the quad (A/B runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still run init_process_group('nccl'), the weight broadcast, the checksum all-reduce and the barriers (RCCL dry run on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
@@ -128,8 +127,6 @@ def main():
     model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
-    if args.msda_per_lane:
-        model.ops.msda_policy(0)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"

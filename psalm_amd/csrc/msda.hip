@@ -111,7 +111,8 @@ __device__ __forceinline__ MsdaTaps8<TV> msda_taps8(const TV* __restrict__ vbase
 // term, sampling location, clamped corner offsets and the four corner weights (times the attention weight) are computed ONCE and handed to
 // the other three lanes with quad broadcasts, instead of every lane computing all L * P samples for itself.  r04e: the LDS-staged form of this
 // kernel (tools/experiments/msda_lds_staged.hip) removed the L2 fetches and got SLOWER (108 vs 57 us): what the kernel spends its time on is
-// this per-sample arithmetic, ~60 instructions per sample, 4 x redundant.
+// this per-sample arithmetic, ~60 instructions per sample, 4 x redundant -- for bf16 value (64-byte corners); with fp32 value the L2 request rate
+// is the bound and this form is slower (see the launch code): the host selects it for bf16 only.
 template <typename TV, typename TO, int L, int P, bool XCD_BANDS = false, bool QUAD = false>
 __global__ void __launch_bounds__(256) msda_fused8_kernel(const TV* __restrict__ value, MsdaLevels lv,
                                                           const float* __restrict__ ow, TO* __restrict__ out, int B, int S,
@@ -451,8 +452,11 @@ extern "C" int psalm_msda_fused(const void* value, int value_dtype, const int64_
         if (total8 == 0) return 0;
         bool bands = B == 1 && total8 % (block * 8) == 0;                         // XCD-band order (see the kernel comment)
         for (int l = 0; l < L; ++l) bands = bands && lv.H[l] % 8 == 0;
-        // D == 32: the 4 channel-group lanes of a (query, head) are a DPP quad -> taps computed once per group (32-bit element offsets)
-        const bool quad = g_msda_quad && D == 32 && (long)B * S * M * D * 4 < (1L << 31);
+        // D == 32: the 4 channel-group lanes of a (query, head) are a DPP quad -> taps computed once per group (32-bit byte offsets).  For bf16
+        // value only: r04f on MI355X (profiles/r04f_bench_msda_quad_taps.jsonl) bf16 52.6 -> 34.9 us, but fp32 57.3 -> 66.4 us -- with 128-byte
+        // corners the fp32 kernel is bound by the L2 request rate (1.05 GB per launch, ~18 TB/s), not by the tap arithmetic, and the rolled level
+        // loop keeps fewer fetches in flight.
+        const bool quad = g_msda_quad && D == 32 && value_dtype == PSALM_BF16 && (long)B * S * M * D * 2 < (1L << 31);
 #define MSDA_LAUNCH8(BANDS_, QUAD_, GRID_)                                                                                              \
         PSALM_DISPATCH(value_dtype, TV, PSALM_DISPATCH(out_dtype, TO, {                                                                 \
             hipLaunchKernelGGL((msda_fused8_kernel<TV, TO, 3, 4, BANDS_, QUAD_>), dim3((unsigned)(GRID_)), dim3(block), 0,              \

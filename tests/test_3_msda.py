@@ -132,14 +132,16 @@ def test_fused_matches_explicit(ops, B, shapes):
     want = O.msda_core(value.view(B, S, M, D), shapes, st, loc, aw)
     got = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
     assert (got - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1)
-    # r04: the bilinear taps of a sample are computed once per (query, head) and shared by its 4 channel-group lanes (quad broadcasts); the
-    # form in which every lane computes all samples (policy 0) differs only in where the attention weight is multiplied in
+    # r04, bf16 value: the bilinear taps of a sample are computed once per (query, head) and shared by its 4 channel-group lanes (quad
+    # broadcasts); the form in which every lane computes all samples (policy 0) differs only in where the attention weight is multiplied in
+    vb = value.to(torch.bfloat16).to(ops.device)
+    quad = ops.msda_fused(vb, shapes, st, ow.to(ops.device), M, out_dtype=torch.float32).cpu()
     ops.msda_policy(0)
     try:
-        per_lane = ops.msda_fused(value.to(ops.device), shapes, st, ow.to(ops.device), M).cpu()
+        per_lane = ops.msda_fused(vb, shapes, st, ow.to(ops.device), M, out_dtype=torch.float32).cpu()
     finally:
         ops.msda_policy(1)
-    assert (per_lane - want).abs().max() < 2e-5 * want.abs().max().clamp(min=1) and (per_lane - got).abs().max() < 1e-5 * want.abs().max().clamp(min=1)
+    assert (quad - per_lane).abs().max() < 1e-5 * want.abs().max().clamp(min=1) and (quad - want).abs().max() < 2e-2 * want.abs().max().clamp(min=1)
 
 
 def test_plugin_module_by_name_device_side_level_table(ops, monkeypatch):
