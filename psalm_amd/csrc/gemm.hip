@@ -1790,6 +1790,12 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         }
     }
     const bool f32out = c_dtype == PSALM_F32 || splits > 1;   // partials are fp32 regardless of the output dtype
+    // The direct fp32 epilogue addresses a tile's rows through a buffer descriptor of at most 0x7ffff000 bytes: a row stride that puts BM rows
+    // beyond it would silently drop the tail rows -- refuse instead (2 M columns at BM = 256; the path's widest output is 65536).
+    if (f32out && (long)BM * (splits > 1 ? (long)N : (g.ldc > g.ldr ? g.ldc : g.ldr)) * 4 >= 0x7ffff000L) {
+        psalm_set_error("psalm_gemm: output / residual row stride too large for the direct fp32 epilogue (BM * ld * 4 must stay below 2 GiB)");
+        return -1;
+    }
     // every launch goes through GO(): it records the exact template instantiation (psalm_gemm_last_kernel: the name a kernel trace shows,
     // so that per-kernel attributions made from launch arguments -- bench.py -- agree with rocprofv3) and launches it
 #define GO(NT_, TCN_, TC_, ...)                                                                                                              \
