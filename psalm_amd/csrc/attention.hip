@@ -286,9 +286,7 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
         const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
         // wavefronts per (window, head): 3 only when the grid cannot give every SIMD a wavefront anyway (r02n, 1024^2 image: stage 4, 288
         // pairs: 41 -> 32 us; stage 3, 576 pairs: 48.5 -> 52.4; stage 1, 1936 pairs: 100 -> 136 -- profiles/r02n_winattn_nwv.jsonl)
-        static int nwv_env = -1;                                          // PSALM_WINATTN_NWV = 1 / 3 forces it (tuning / A-B)
-        if (nwv_env < 0) { const char* e = getenv("PSALM_WINATTN_NWV"); nwv_env = e ? atoi(e) : 0; }
-        const int nwv = nwv_env == 1 || nwv_env == 3 ? nwv_env : ((long)nwin * heads <= 320 ? 3 : 1);
+        const int nwv = (long)nwin * heads <= 320 ? 3 : 1;
         if (nwv == 1)
             hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
                                (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);

@@ -69,6 +69,24 @@ class Instances:
         return int(self.pred_masks.shape[0])
 
 
+def _nonzero_2d(m: torch.Tensor) -> torch.Tensor:
+    """`m.nonzero()` of a 2-D CPU mask -- (k, 2) int64 (y, x) in row-major order -- without torch's two full passes over the bytes: a
+    1024 x 1024 region mask costs torch ~2 ms per region on the host (r04: 7 of the 37.5 ms of a region batch); here the mask is scanned
+    as 64-bit words and only the non-zero words are looked at byte by byte."""
+    if m.dim() != 2 or m.dtype != torch.bool or not m.is_contiguous() or m.numel() % 8 or m.device.type != "cpu":
+        return m.nonzero()
+    a = m.numpy().view(np.uint8).reshape(-1)
+    words = np.flatnonzero(a.view(np.uint64))
+    if words.size == 0:
+        return torch.zeros(0, 2, dtype=torch.int64)
+    if words.size * 128 > a.size:                     # not sparse (> 1/16 of the words occupied): torch's dense scan is the faster one
+        return m.nonzero()
+    cand = (words[:, None] * 8 + np.arange(8, dtype=np.int64)[None]).reshape(-1)
+    flat = cand[a[cand] != 0]
+    W = m.shape[1]
+    return torch.from_numpy(np.stack((flat // W, flat % W), 1))
+
+
 def default_region_point_sampler(nonzero: torch.Tensor, n: int) -> torch.Tensor:
     """Row indices into `nonzero` (context_cluster.py:31-40 rand_sample_repeat; global torch CPU RNG, same call order)."""
     m = nonzero.shape[0]
@@ -730,7 +748,7 @@ class PSALM:
             masks = masks.cpu()
             counts.append(int(masks.shape[0]))
             for m in masks:
-                nz = m.nonzero()
+                nz = _nonzero_2d(m)
                 wh = torch.tensor([m.shape[0], m.shape[1]])[None]
                 pts.append((nz / wh)[sampler(nz, n)].float())
         return (torch.stack(pts) if pts else torch.zeros(0, n, 2)), counts

@@ -65,3 +65,22 @@ def test_vectorised_splice_plan_equals_per_token_form():
             assert (a[k] is None) == (b[k] is None)
             if a[k] is not None:
                 assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]), (task, k)
+
+
+def test_region_mask_nonzero_fast_path_equals_torch_nonzero():
+    """context_cluster.py:345-356 takes `mask.nonzero()` of every region mask on the host; the word-scanning form of it that
+    PSALM.region_points uses returns the same (k, 2) int64 rows in the same (row-major) order on sparse blobs, scattered pixels, dense
+    masks (falls back), empty masks, widths that are not a multiple of 8 (falls back), transposed views (falls back)."""
+    from psalm_amd.model import _nonzero_2d
+    g = torch.Generator().manual_seed(3)
+    blob = torch.zeros(1024, 1024, dtype=torch.bool)
+    blob[400:431, 299:316] = True
+    blob[1023, 1023] = True
+    blob[0, 0] = True
+    cases = [blob, torch.zeros(64, 64, dtype=torch.bool), torch.ones(64, 64, dtype=torch.bool), torch.zeros(64, 64, dtype=torch.bool).t(),
+             torch.ones(48, 40, dtype=torch.bool).t()]
+    for shape, p in (((1024, 1024), 3e-4), ((640, 640), 0.01), ((640, 640), 0.2), ((37, 24), 0.5), ((5, 7), 0.4), ((3, 8), 0.1)):
+        cases.append(torch.rand(shape, generator=g) < p)
+    for m in cases:
+        got, want = _nonzero_2d(m), m.nonzero()
+        assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want)

@@ -1,5 +1,6 @@
 """Micro-benchmark of the fp32 window attention at the four Swin-B stages of a 1024^2 image (12 x 12 windows, head dim 32).
-PSALM_WINATTN_NWV = 1 / 3: wavefronts per (window, head);  one run per value."""
+(The wavefronts-per-(window, head) choice it was written to A/B -- 3 when <= 320 pairs, else 1, profiles/r02n_winattn_nwv.jsonl -- is now
+fixed in psalm_window_attention; the environment knob is gone.)"""
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +29,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out[f"stage{stage}_shift{shift}"] = {"us": round(e0.elapsed_time(e1) * 1e3 / 30, 2), "checksum": float(o.double().sum())}
-    print(json.dumps({"PSALM_WINATTN_NWV": os.environ.get("PSALM_WINATTN_NWV", "3"), **out}))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
