@@ -2,9 +2,11 @@
 section 0): 1024x1024 panoptic, weights seed 0, inputs seed 11.  The fp32 oracle (= the reference itself on this input, 0 flipped pixels,
 profiles/r04a_reference_vs_oracle_*.log) sits on a knife edge there: evaluating EVERY linear layer of the oracle in float64 -- more exact than
 the reference's own arithmetic -- moves the mask logits by 9.2e-4 of their range and flips 558 pixels, and the product's three-f16-product
-arithmetic lands on the float64 result (1 pixel apart), not on the fp32 one (tools/exp_noise_floor_cpu.py, profiles/r04a_noise_floor_*).
+arithmetic lands either on the float64 result (r04a build: 1-2 pixels apart; tools/exp_noise_floor_cpu.py, profiles/r04a_noise_floor_*) or on
+the fp32 one (r04 HEAD, one explicit fma in the GELU epilogue later: 4 pixels) -- two resting places, rounding decides.
 This script stores WHERE the float64 control differs from the fp32 oracle -- (query, y, x) of every flipped pixel -- so that the GPU test
-(tests/test_9_e2e_gpu.py::test_config2_seed11_lands_on_the_float64_control) can check that the pixels the product flips are those pixels.
+(tests/test_9_e2e_gpu.py::test_config2_seed11_knife_edge_input_lands_on_oracle_or_float64_control) can check that the pixels the product
+flips are either (almost) none or those pixels.
 
     python tests/golden/make_seed11_control.py        (CPU only, ~4 min; needs no /root/reference)"""
 import os

@@ -324,15 +324,17 @@ def test_config2_panoptic_1024_multi_seed_default_and_fp32_control():
     assert len(below.get("f16x3", [])) <= len(below.get("fp32", [])), below
 
 
-def test_config2_seed11_lands_on_the_float64_control():
-    """VERDICT r03 weak #1, the one panoptic input of the 16-seed set on which the default arithmetic leaves the bar against the fp32 oracle:
+def test_config2_seed11_knife_edge_input_lands_on_oracle_or_float64_control():
+    """VERDICT r03 weak #1, the one panoptic input of the 16-seed set on which the default arithmetic left the bar against the fp32 oracle:
     1024x1024, inputs seed 11 -- mask logits 9.2e-4 of their range away, 558 flipped pixels, pooled IoU 0.9985.  The fp32 oracle (= the
     reference itself on this input: 0 flipped pixels between the two, profiles/r04a_reference_vs_oracle_*.log) sits on a knife edge there:
     with EVERY linear layer of the oracle evaluated in float64 -- more exact than the reference -- it moves by the same 9.2e-4 to the same
-    558 pixels (tests/golden/make_seed11_control.py -> panoptic_1024_seed11_float64_control.npz; tools/exp_noise_floor_cpu.py), and the exact-
-    fp32 GPU mode tips a different input (seed 4) by ten times as much (profiles/r04_parity_wide.jsonl).  Asserted here: the pixels the product
-    flips against the fp32 oracle on this input ARE the pixels the float64 control flips (symmetric difference <= 16 of ~558), i.e. the
-    product lands on the more exact evaluation of the network, and the move stays the documented size."""
+    558 pixels (tests/golden/make_seed11_control.py -> panoptic_1024_seed11_float64_control.npz; tools/exp_noise_floor_cpu.py).  The input
+    has exactly two resting places and rounding decides between them: the product of r04a (profiles/r04_parity_wide.jsonl) landed on the
+    float64 control's (2 pixels from it); the product after ONE explicit fma in the GELU epilogue (same arithmetic, a 1-ulp-class change of a
+    few activations) lands on the fp32 oracle's (4 flipped pixels, 1.5e-6 -- profiles/r04_test9_full_at_head.log).  Asserted here: the product
+    is within 16 pixels of ONE of the two -- the fp32 oracle, or the more exact float64 evaluation -- and nowhere else, and the logit move is
+    the oracle-class 1e-5 or the documented 9.2e-4, never larger."""
     import numpy as np
     from psalm_amd.model import PSALM
     cfg, sd = _full_model("panoptic")
@@ -345,10 +347,12 @@ def test_config2_seed11_lands_on_the_float64_control():
     mine = {tuple(int(v) for v in r) for r in torch.nonzero(gm != wm).tolist()}
     control = {tuple(int(v) for v in r) for r in ctl["flipped_qyx"].tolist()}
     rel = float((got["mask_pred"].cpu() - want["mask_pred"]).abs().max() / want["mask_pred"].abs().max())
-    _report(test="config2_seed11_float64_control", flipped_vs_fp32_oracle=len(mine), float64_control_flipped=len(control), symmetric_difference=len(mine ^ control),
+    _report(test="config2_seed11_knife_edge", flipped_vs_fp32_oracle=len(mine), float64_control_flipped=len(control), symmetric_difference=len(mine ^ control),
             mask_logit_rel_err=rel, float64_control_rel_err=float(ctl["mask_logit_rel_err"]))
-    assert len(control) > 100 and len(mine ^ control) <= 16, (len(mine), len(control), len(mine ^ control))
-    assert rel < 2e-3
+    assert len(control) > 100
+    on_oracle, on_control = len(mine) <= 16, len(mine ^ control) <= 16
+    assert on_oracle or on_control, (len(mine), len(control), len(mine ^ control))
+    assert rel < (1e-5 if on_oracle else 2e-3)
 
 
 def test_config3_referring_640_batch4_ragged():
