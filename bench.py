@@ -328,7 +328,7 @@ def main():
                 nbytes = a[4] * (a[7] * a[8] * (2 if a[1] == 1 else 4) + a[9] * a[10] * (2 if a[3] == 1 else 4))
                 if nbytes < (64 << 20):
                     continue                                                      # only the full-resolution mask upsampling is a roofline-sized launch
-                kn = "resize_planes_vec4_kernel"
+                kn = "resize_planes_rows_kernel<8>"
             elif name == "psalm_panoptic":                                        # (... Q, HW ...): the call's dominant kernel reads the (Q, HW) f32 logits once
                 nbytes, kn = a[10] * a[11] * 4 + a[11] * 8, "panoptic_argmax_kernel (+ the call's small kernels)"
             else:

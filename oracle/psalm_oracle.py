@@ -669,7 +669,8 @@ def eval_seg(sd: Dict[str, torch.Tensor], cfg, input_ids, attention_mask, images
         info = seg_info[b]
         height = info.get("height", images.shape[-2])
         width = info.get("width", images.shape[-1])
-        nz = np.where(~np.array(info["padding_mask"]))               # LP:1418-1423
+        pm = info["padding_mask"]
+        nz = np.where(~(pm.cpu().numpy() if torch.is_tensor(pm) else np.asarray(pm)).astype(bool))      # LP:1418-1423
         oh = int(nz[0].max() - nz[0].min() + 1)
         ow = int(nz[1].max() - nz[1].min() + 1)
         mp = sem_seg_postprocess(mask_up[b], [oh, ow], height, width)            # LP:1426-1429

@@ -741,11 +741,15 @@ class Ops:
         self._check(rc, "psalm_im2col_split_f16")
         return SplitF16(t, inv, K)
 
-    def resize_planes(self, x, H, W, crop=None, out_dtype=None):
-        """x (N,h,w) -> bilinear (align_corners=False) -> (N,H,W); optional crop (hc,wc) of the input first."""
+    def resize_planes(self, x, H, W, crop=None, out_dtype=None, out=None):
+        """x (N,h,w) -> bilinear (align_corners=False) -> (N,H,W); optional crop (hc,wc) of the input first.  `out`: a contiguous (N,H,W)
+        buffer to write into (tests use a view that is not 16-byte aligned to reach the one-pixel-per-thread kernel)."""
         N, h, w = x.shape
         hc, wc = crop if crop is not None else (h, w)
-        out = self.empty(N, H, W, dtype=out_dtype or x.dtype)
+        if out is None:
+            out = self.empty(N, H, W, dtype=out_dtype or x.dtype)
+        elif tuple(out.shape) != (N, H, W) or not out.is_contiguous():
+            raise PsalmHipError("resize_planes: out must be a contiguous (N, H, W) tensor")
         rc = self.lib.psalm_resize_planes(self._p(x), _dt(x), self._p(out), _dt(out), c_long(N), h, w, hc, wc, H, W, self._stream())
         self._check(rc, "psalm_resize_planes")
         return out

@@ -16,6 +16,14 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: multi-second CPU test")
+    # The CPU oracle is the long pole of the GPU suite (tests/test_9: one 1024^2 image = one full fp32 model evaluation on the host), and torch's
+    # default of one thread per hardware thread OVERSUBSCRIBES it on the GPU box: profiles/r04_cpu_baseline_threads.json, 8 / 16 / 32 / 64 threads
+    # = 9.0 / 6.8 / 7.5 / 13.9 s per image.  Same results (the tests' bars are tolerances or integer statistics), half the wall time.
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

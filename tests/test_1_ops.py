@@ -437,6 +437,30 @@ def test_im2col_and_convs(ops):
         assert (got - want).abs().max() < 1e-4
 
 
+def test_resize_planes_row_walking_kernel(ops):
+    """The fp32 -> fp32, W % 4 == 0, H >= 8 form of psalm_resize_planes (the mask up-sampling of LP:1401-1406: a block walks 8 output rows and
+    re-fetches source values only when the source row pair changes) against F.interpolate, and against the one-pixel-per-thread kernel of the
+    same entry point (reached through an output view that is not 16-byte aligned): 4x up-sampling, a non-integer scale, a crop, a row count
+    that is not a multiple of 8, a down-sampling (source row pairs that skip), a single source row / column."""
+    g = torch.Generator().manual_seed(21)
+    cases = [((3, 24, 24), (96, 96), None), ((2, 20, 28), (52, 64), None), ((2, 20, 28), (50, 36), (17, 23)), ((1, 40, 40), (12, 16), None),
+             ((2, 1, 5), (9, 8), None), ((2, 6, 1), (16, 4), None), ((1, 9, 7), (8, 1028), None)]
+    for shape, (H, W), crop in cases:
+        x = torch.randn(shape, generator=g)
+        src = x if crop is None else x[:, :crop[0], :crop[1]]
+        want = F.interpolate(src[None], size=(H, W), mode="bilinear", align_corners=False)[0]
+        xd = x.to(ops.device)
+        got = ops.resize_planes(xd, H, W, crop=crop)
+        assert (got.cpu() - want).abs().max() < 1e-5, (shape, H, W)
+        buf = ops.empty(shape[0] * H * W + 1, dtype=torch.float32)
+        other = ops.resize_planes(xd, H, W, crop=crop, out=buf[1:].view(shape[0], H, W))
+        assert other.data_ptr() % 16 != 0
+        if ops.device.type == "cuda":        # same expression, and on the hardware the same contraction into fmas: the same bits
+            assert torch.equal(got, other), (shape, H, W)
+        else:                                # (the host compiler of the emulator contracts the two source forms differently: 1 ulp)
+            assert (got - other).abs().max() <= 2e-6 * want.abs().max()
+
+
 def test_resize_and_layout(ops):
     g = torch.Generator().manual_seed(10)
     x = torch.randn(3, 16, 16, generator=g)

@@ -36,6 +36,8 @@ def main():
     order = sorted(data, key=lambda k: -dur[k][1])[:top]
     for k in order:
         row = {"dispatches_profiled": max(v[0] for v in data[k].values())}
+        if dur[k][0] and dur[k][1]:
+            row["avg_duration_us_in_this_pass"] = dur[k][1] / dur[k][0] * 1e-3          # rocpd durations are ns
         for cn, (n, sm) in sorted(data[k].items()):
             row[cn] = {"sum": sm, "per_dispatch": sm / n}
         f = data[k].get("FETCH_SIZE")
