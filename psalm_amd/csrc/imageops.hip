@@ -94,6 +94,14 @@ __device__ __forceinline__ BilinIdx bilin_idx(int d, float scale, int in_size) {
     return r;
 }
 
+// ly0 (lx0 a00 + lx1 a01) + ly1 (lx0 a10 + lx1 a11) with the fused multiply-adds WRITTEN OUT: the three resize kernels below are reached through
+// one entry point (by dtype / alignment / height) and must round alike -- left to the compiler, each instantiation contracts the expression
+// its own way (r04j on the MI355X: the one-pixel-per-thread kernel and the row-walking kernel 1 ulp apart on 30 % of the pixels).  This
+// form is also what torch's CPU kernel evaluates (bit-identical on the host emulator).
+__device__ __forceinline__ float bilin_blend(float ly0, float ly1, float lx0, float lx1, float a00, float a01, float a10, float a11) {
+    return fmaf(ly0, fmaf(lx0, a00, lx1 * a01), ly1 * fmaf(lx0, a10, lx1 * a11));
+}
+
 // planes: in (N, h, w) -> out (N, H, W), with an optional crop of the input to (hc, wc) first
 // (sem_seg_postprocess = crop + resize, llava_phi.py:1427-1429)
 template <typename TI, typename TO>
@@ -107,8 +115,8 @@ __global__ void __launch_bounds__(256) resize_planes_kernel(const TI* __restrict
         const long n = i / ((long)W * H);
         const BilinIdx iy = bilin_idx(y, sh, hc), ix = bilin_idx(x, sw, wc);
         const TI* p = in + n * h * w;
-        const float v = iy.l0 * (ix.l0 * ldf(p + (long)iy.i0 * w + ix.i0) + ix.l1 * ldf(p + (long)iy.i0 * w + ix.i1)) +
-                        iy.l1 * (ix.l0 * ldf(p + (long)iy.i1 * w + ix.i0) + ix.l1 * ldf(p + (long)iy.i1 * w + ix.i1));
+        const float v = bilin_blend(iy.l0, iy.l1, ix.l0, ix.l1, ldf(p + (long)iy.i0 * w + ix.i0), ldf(p + (long)iy.i0 * w + ix.i1),
+                                    ldf(p + (long)iy.i1 * w + ix.i0), ldf(p + (long)iy.i1 * w + ix.i1));
         stf(out + i, v);
     }
 }
@@ -131,16 +139,10 @@ __global__ void __launch_bounds__(256) resize_planes_vec4_kernel(const float* __
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const BilinIdx ix = bilin_idx(x0 + k, sw, wc);
-            o[k] = iy.l0 * (ix.l0 * r0[ix.i0] + ix.l1 * r0[ix.i1]) + iy.l1 * (ix.l0 * r1[ix.i0] + ix.l1 * r1[ix.i1]);
+            o[k] = bilin_blend(iy.l0, iy.l1, ix.l0, ix.l1, r0[ix.i0], r0[ix.i1], r1[ix.i0], r1[ix.i1]);
         }
         *reinterpret_cast<psalm_f32x4*>(out + ((n * H + y) * (long)W + x0)) = psalm_f32x4{o[0], o[1], o[2], o[3]};
     }
-}
-
-// The blend of the two kernels above as the compiler contracts it (a*b + c*d -> fma(a, b, c*d), twice), written out so that the row-walking
-// kernel below rounds like them whatever it is inlined into.
-__device__ __forceinline__ float bilin_blend(float ly0, float ly1, float lx0, float lx1, float a00, float a01, float a10, float a11) {
-    return fmaf(ly0, fmaf(lx0, a00, lx1 * a01), ly1 * fmaf(lx0, a10, lx1 * a11));
 }
 
 // fp32 -> fp32, W % 4 == 0, the form the mask up-sampling runs (100 planes 256^2 -> 1024^2: 419 MB written, 26 MB read): the vec4 kernel
