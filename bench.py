@@ -41,6 +41,7 @@ PEAK_HBM_GBPS = 8000.0         # HBM3E, same guide
 # tools/make_traffic_json.py); the file of the current round if present, else the previous round's (bf16 kernels only)
 TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"))
                      if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json"))
+SQ_JSON = os.path.join(ROOT, "profiles", "r04_sq_summary.json")     # per-kernel SQ-counter fractions + clock of the same workload (one --pmc pass)
 # the oracle's host-thread count: the fastest of the 8 / 16 / 32 / 64 sweep on the GPU box's host (tools/cpu_baseline_sweep.py ->
 # profiles/r04_cpu_baseline_threads.json), and the reference's OWN eval_seg timed in the authoring container (profiles/r04_reference_cpu.json)
 CPU_THREADS_JSON = os.path.join(ROOT, "profiles", "r04_cpu_baseline_threads.json")
@@ -380,6 +381,14 @@ def main():
                     "all_mfma_gemms": {"ms_per_step": round(all_ms / nprof, 3), "TFLOPs": round(all_fl / (all_ms * 1e-3) / 1e12, 1),
                                        "gflop_per_step": round(all_fl / nprof / 1e9, 1), "launches_per_step": sum(v[0] for v in kern.values()) / nprof},
                     "hbm_bound_kernels": hbm_roof}
+            if os.path.exists(SQ_JSON):                                          # committed SQ-counter pass of this workload (tools/make_sq_json.py)
+                with open(SQ_JSON) as f:
+                    sq = json.load(f)
+                e = sq.get("kernels", {}).get(kname.split(" + ")[0])
+                if e:
+                    roof["sq_counters"] = dict(e, source=sq.get("source"),
+                                               note="fractions of the wavefront cycles (parked at s_waitcnt / s_barrier, issue-stalled, issuing) and of the chip's "
+                                                    "matrix-pipe CYCLES; `frac` / `mfma_issue` are against the 2.4 GHz peak, this launch ran at clock_GHz")
         if args.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
             with open(args.breakdown, "w") as f:
