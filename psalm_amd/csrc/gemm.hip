@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel form, or 32-deep slices in two stages");
     static_assert(X3 >= 0 && X3 <= 2, "X3: 0 bf16 operands, 1 split-f16 K-panel form, 2 split-f16 slice form");
-    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && (BK == 64 || (BK == 32 && X3 == 2 && PH8 == 3)) && !CONV), "PH8 configuration");
+    static_assert(!PH8 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && (BK == 64 || (BK == 32 && X3 == 2 && (PH8 == 3 || PH8 == 4))) && !CONV), "PH8 configuration");
     static_assert(!X3 || !CONV, "split-f16 variants: plain GEMM");
     static_assert(X3 != 1 || BK == 64, "split-f16 K-panel form: 64-deep K tiles");
-    static_assert(X3 != 2 || ((!PH8 && (BK == 64 || BK == 32)) || (PH8 == 3 && BK == 32)), "split-f16 slice form: generic K loop, or the phased 256 x 256 loop on 32-deep slices");
+    static_assert(X3 != 2 || ((!PH8 && (BK == 64 || BK == 32)) || ((PH8 == 3 || PH8 == 4) && BK == 32)), "split-f16 slice form: generic K loop, or the phased 256 x 256 loop on 32-deep slices");
     constexpr int XS = X3 == 2 ? 2 : 1;                          // operand images per stage (slice form: hi and lo)
     const GemmArgs& g = fa.g;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -526,8 +526,19 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // K-panel form walks it twice, 32 K steps apart: its second pass missed the XCD's L2 -- counter traffic 1.8x compulsory, r03p).
         // Halves, phases, refill points, hazards and the vmcnt counts are those of the 64-deep schedule below: a half is the SAME rows, now
         // as a (hi, lo) pair of 16-row chunks per wave instead of two 8-row chunks.
-        static_assert(PH8 == 3, "slice form: copies inside the MFMA segment, bare barriers");
+        static_assert(PH8 == 3 || PH8 == 4, "slice form: copies inside the MFMA segment, bare barriers");
         constexpr int LO = (BM + BN) * BK;                       // the lo images sit behind the hi images of a stage
+        // PH8 == 4 (experiment, psalm_gemm_set_tile_policy(2582); NOT the default): the wave leaves out the matrix instructions and fragment
+        // reads of its 32-row m-tiles that lie entirely in the padding below row M.  Those rows are never stored, so no output changes; the
+        // launch does not get shorter either (the full tiles set its duration) -- the point is power: Phi's M = 899 puts 12 % of the matrix
+        // instructions of [k|v|q|fc1] on padding rows (wave row 1 of the last row of tiles: 3 valid rows of 128), and the launch is clock-limited
+        // (1.76 GHz by the r04j SQ-counter pass).  Phases, barriers, copies and waits are untouched.
+        constexpr bool SKIP_PAD = PH8 == 4;
+        int mt_valid = 4;                                        // m-tiles of this wave that hold at least one row < M
+        if constexpr (SKIP_PAD) {
+            const int rows_left = g.M - bm - wm * (BM / WM);
+            mt_valid = __builtin_amdgcn_readfirstlane(rows_left <= 0 ? 0 : (rows_left >= 128 ? 4 : (rows_left + 31) >> 5));
+        }
         const int abl = PSALM_ABL();                             // (experiment build only; the constant 0 in the product)
         bf16x8 ah[2][2] = {}, al[2][2] = {}, bh[2] = {}, bl[2] = {};   // [m-tile of the half][kk] / [kk]
         auto read_a = [&](const bf16_t* As_, int q) {
@@ -537,6 +548,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const int co = ((2 * kk + hi) ^ fsw) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    if (SKIP_PAD && 2 * q + i >= mt_valid) continue;
                     const int off = (a_row0 + 32 * (2 * q + i)) * BK + co;
                     ah[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[off]));
                     al[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[LO + off]));
@@ -568,17 +580,18 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // 12 matrix instructions, the two accumulators of the quadrant alternating; the phase's two copies after the 2nd and the 8th
         auto mma = [&](int q, int j, auto&& copy) {
             if (abl & 4) { copy(0); copy(1); return; }
+            const bool on0 = !SKIP_PAD || 2 * q < mt_valid, on1 = !SKIP_PAD || 2 * q + 1 < mt_valid;     // (wave-uniform)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(ah[i][kk], bh[kk], acc[2 * q + i][j]);
+                if (on0) acc[2 * q][j] = mma16(ah[0][kk], bh[kk], acc[2 * q][j]);
+                if (on1) acc[2 * q + 1][j] = mma16(ah[1][kk], bh[kk], acc[2 * q + 1][j]);
                 __builtin_amdgcn_sched_barrier(0);
                 copy(kk);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(al[i][kk], bh[kk], acc[2 * q + i][j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[2 * q + i][j] = mma16(ah[i][kk], bl[kk], acc[2 * q + i][j]);
+                if (on0) acc[2 * q][j] = mma16(al[0][kk], bh[kk], acc[2 * q][j]);
+                if (on1) acc[2 * q + 1][j] = mma16(al[1][kk], bh[kk], acc[2 * q + 1][j]);
+                if (on0) acc[2 * q][j] = mma16(ah[0][kk], bl[kk], acc[2 * q][j]);
+                if (on1) acc[2 * q + 1][j] = mma16(ah[1][kk], bl[kk], acc[2 * q + 1][j]);
             }
         };
 #define PHS_ENTER_MFMA() do { __builtin_amdgcn_sched_barrier(0); if (!(abl & 8)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
@@ -1658,7 +1671,8 @@ static int g_x3_slice = 0;
 // phase: 2/3 of the L2 -> LDS bytes, fragment reads and barriers of the K-panel form, W hi fetched once), 0 = the K-panel form (3 Kp-long
 // loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).  r04a on MI355X (profiles/r04a_gemm_x3_sweep.json, back to back): Phi
 // [k|v|q|fc1] 158.9 -> 150.5 us, [dense|fc2] on 256^2 tiles 131.1 -> 124.4 us (128^2 tiles: 142), M65536 N256 K2304 231 -> 215; in the model
-// [k|v|q|fc1] 172 -> 164 us by events (profiles/r04a_bench_phased_slice_ab.txt): the default.
+// [k|v|q|fc1] 172 -> 164 us by events (profiles/r04a_bench_phased_slice_ab.txt): the default.  2 (policy 2582) = the same with the matrix
+// instructions of all-padding m-tiles left out (<.., 32, 4, 2, ..>): built and bit-identical on the emulator, NOT yet measured on the hardware.
 static int g_ph8_slice = 1;
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
@@ -1668,7 +1682,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
-    if (bm == 2580 || bm == 2581) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices
+    if (bm >= 2580 && bm <= 2582) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices / (experiment) slices, all-padding m-tiles left out
     if (bm >= 3300 && bm <= 3305) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
@@ -1808,7 +1822,10 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
         // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
         // with 1.5x the matrix work per copy round trip
-        if (slice == 6 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true, true);
+        if (slice == 6 && g_ph8_slice == 2 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, true, true);
+        else if (slice == 6 && g_ph8_slice == 2 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, true);
+        else if (slice == 6 && g_ph8_slice == 2) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, false);
+        else if (slice == 6 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true, true);
         else if (slice == 6 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true);
         else if (slice == 6) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, false);
         else if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
