@@ -541,14 +541,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         }
         const int abl = PSALM_ABL();                             // (experiment build only; the constant 0 in the product)
         bf16x8 ah[2][2] = {}, al[2][2] = {}, bh[2] = {}, bl[2] = {};   // [m-tile of the half][kk] / [kk]
-        auto read_a = [&](const bf16_t* As_, int q) {
+        // (`part`: std::true_type in the copy of the K loop that a wave with all-padding m-tiles runs -- PH8 == 4 only; the other waves, and
+        //  every wave of the product kernel, run the copy in which the tests below are compile-time constants)
+        auto read_a = [&](auto part, const bf16_t* As_, int q) __attribute__((always_inline)) {
             if (abl & 2) return;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int co = ((2 * kk + hi) ^ fsw) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (SKIP_PAD && 2 * q + i >= mt_valid) continue;
+                    if (decltype(part)::value && 2 * q + i >= mt_valid) continue;
                     const int off = (a_row0 + 32 * (2 * q + i)) * BK + co;
                     ah[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[off]));
                     al[i][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As_[LO + off]));
@@ -578,9 +580,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             if (which != 0) psalm_glds16(bsrc[j] + fa.x3_kp + koff, d + LO);
         };
         // 12 matrix instructions, the two accumulators of the quadrant alternating; the phase's two copies after the 2nd and the 8th
-        auto mma = [&](int q, int j, auto&& copy) {
+        auto mma = [&](auto part, int q, int j, auto&& copy) __attribute__((always_inline)) {
             if (abl & 4) { copy(0); copy(1); return; }
-            const bool on0 = !SKIP_PAD || 2 * q < mt_valid, on1 = !SKIP_PAD || 2 * q + 1 < mt_valid;     // (wave-uniform)
+            const bool on0 = !decltype(part)::value || 2 * q < mt_valid, on1 = !decltype(part)::value || 2 * q + 1 < mt_valid;     // (wave-uniform)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (on0) acc[2 * q][j] = mma16(ah[0][kk], bh[kk], acc[2 * q][j]);
@@ -599,29 +601,29 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #define PHS_LEAVE_MFMA() do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); if (!(abl & 8)) __builtin_amdgcn_s_barrier(); \
                               __builtin_amdgcn_sched_barrier(0); } while (0)
         // mode 0: steady state (tile t+2 exists);  1: t = nk-2 (only B0 of tile t+1 left to copy; drain);  2: t = nk-1
-        auto tile_phases = [&](int t, int mode) {
+        auto tile_phases = [&](auto part, int t, int mode) __attribute__((always_inline)) {
             const int cur = t & 1;
             const bf16_t* As_ = smem[cur];
             const bf16_t* Bs_ = smem[cur] + BM * BK;
             read_b(Bs_, 0);                                      // P1
-            read_a(As_, 0);
+            read_a(part, As_, 0);
             PHS_ENTER_MFMA();
-            mma(0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
+            mma(part, 0, 0, [&](int w_) { if (mode <= 1) stage_b(cur ^ 1, (t + 1) * BK, 0, w_); });
             PHS_LEAVE_MFMA();
             read_b(Bs_, 1);                                      // P2
             PHS_ENTER_MFMA();
-            mma(0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
+            mma(part, 0, 1, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 0, w_); });
             PHS_LEAVE_MFMA();
-            read_a(As_, 1);                                      // P3
+            read_a(part, As_, 1);                                      // P3
             PHS_ENTER_MFMA();
-            mma(1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
+            mma(part, 1, 1, [&](int w_) { if (mode == 0) stage_b(cur, (t + 2) * BK, 1, w_); });
             PHS_LEAVE_MFMA();
             read_b(Bs_, 0);                                      // P4
             // everything but the 2 most recent halves has landed = all of tile t+1 (this phase's copies are issued after the wait)
             if (mode == 0) wait_vmcnt_le<4>();
             else if (mode == 1) wait_vmcnt_le<0>();
             PHS_ENTER_MFMA();
-            mma(1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
+            mma(part, 1, 0, [&](int w_) { if (mode == 0) stage_a(cur, (t + 2) * BK, 1, w_); });
             PHS_LEAVE_MFMA();
         };
         stage_a(0, 0, 0); stage_a(0, 0, 1); stage_b(0, 0, 0); stage_b(0, 0, 1);        // tile 0 (8 copies per wave)
@@ -631,11 +633,19 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         PSALM_RAW_BARRIER();
         PSALM_TL(2);
         if (wm == 1) PSALM_RAW_BARRIER();                        // wave row 1 starts one barrier interval late
-        int t = 0;
+        auto k_loop = [&](auto part) __attribute__((always_inline)) {
+            int t = 0;
 #pragma unroll 1
-        for (; t + 2 < nk; ++t) tile_phases(t, 0);
-        tile_phases(t, 1);
-        tile_phases(t + 1, 2);
+            for (; t + 2 < nk; ++t) tile_phases(part, t, 0);
+            tile_phases(part, t, 1);
+            tile_phases(part, t + 1, 2);
+        };
+        if constexpr (SKIP_PAD) {                                // two copies of the loop: the same barriers in both, a wave takes one of them
+            if (mt_valid < 4) k_loop(std::true_type{});
+            else k_loop(std::false_type{});
+        } else {
+            k_loop(std::false_type{});
+        }
         if (wm == 0) PSALM_RAW_BARRIER();                        // pairs with wave row 1's last barrier
 #undef PHS_ENTER_MFMA
 #undef PHS_LEAVE_MFMA
