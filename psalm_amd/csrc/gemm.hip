@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         // as a (hi, lo) pair of 16-row chunks per wave instead of two 8-row chunks.
         static_assert(PH8 == 3 || PH8 == 4, "slice form: copies inside the MFMA segment, bare barriers");
         constexpr int LO = (BM + BN) * BK;                       // the lo images sit behind the hi images of a stage
-        // PH8 == 4 (experiment, psalm_gemm_set_tile_policy(2582); NOT the default): the wave leaves out the matrix instructions and fragment
+        // PH8 == 4 (psalm_gemm_set_tile_policy(2582), the default since r04p): the wave leaves out the matrix instructions and fragment
         // reads of its 32-row m-tiles that lie entirely in the padding below row M.  Those rows are never stored, so no output changes; the
         // launch does not get shorter either (the full tiles set its duration) -- the point is power: Phi's M = 899 puts 12 % of the matrix
         // instructions of [k|v|q|fc1] on padding rows (wave row 1 of the last row of tiles: 3 valid rows of 128), and the launch is clock-limited
@@ -1681,9 +1681,11 @@ static int g_x3_slice = 0;
 // phase: 2/3 of the L2 -> LDS bytes, fragment reads and barriers of the K-panel form, W hi fetched once), 0 = the K-panel form (3 Kp-long
 // loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).  r04a on MI355X (profiles/r04a_gemm_x3_sweep.json, back to back): Phi
 // [k|v|q|fc1] 158.9 -> 150.5 us, [dense|fc2] on 256^2 tiles 131.1 -> 124.4 us (128^2 tiles: 142), M65536 N256 K2304 231 -> 215; in the model
-// [k|v|q|fc1] 172 -> 164 us by events (profiles/r04a_bench_phased_slice_ab.txt): the default.  2 (policy 2582) = the same with the matrix
-// instructions of all-padding m-tiles left out (<.., 32, 4, 2, ..>): built and bit-identical on the emulator, NOT yet measured on the hardware.
-static int g_ph8_slice = 1;
+// [k|v|q|fc1] 172 -> 164 us by events (profiles/r04a_bench_phased_slice_ab.txt).  2 (policy 2582) = the same with the matrix instructions
+// and fragment reads of all-padding m-tiles left out (<.., 32, 4, 2, ..>): the launch is clock-limited (1.76 GHz, r04j SQ counters), the
+// left-out work is power.  r04p on MI355X (profiles/r04p_skip_pad.json, back to back, identical output words): M899 N14336 K2048 150.3 ->
+// 141.1 us, M899 N2048 K10240 123.3 -> 117.4, M1024 N14336 K2048 (nothing to leave out) 150.3 -> 149.9: the default.
+static int g_ph8_slice = 2;
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4

@@ -114,6 +114,10 @@ class SplitF16:
 
 
 class Ops:
+    # psalm_gemm_set_tile_policy code of the library's default K loop for split-f16 GEMMs on 256 x 256 tiles (2580 K-panel form, 2581 32-deep
+    # slices, 2582 slices with the all-padding m-tiles left out): what tests that switch it restore afterwards.
+    GEMM_X3_256_DEFAULT = 2582
+
     def __init__(self, lib_path: str = DEFAULT_LIB):
         if not os.path.exists(lib_path):
             raise PsalmHipError(

@@ -458,7 +458,7 @@ def test_gemm_x3_256_phased_slice_form(ops, M, N, K, has_bias, has_res, act):
         test_gemm_x3(ops, M, N, K, has_bias, has_res, act, 256, 3300)
         assert "256, 256, 2, 4, 2, false, 32, 3, 2" in ops.gemm_last_kernel()
     finally:
-        ops.gemm_tile_policy(2580)
+        ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
 
 
 def test_gemm_x3_256_phased_slice_form_split_output(ops):
@@ -470,12 +470,12 @@ def test_gemm_x3_256_phased_slice_form_split_output(ops):
         test_gemm_x3_split_output(ops, 300, 520, 128, H.ACT_GELU, 256, 256, 0, True)
         test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
     finally:
-        ops.gemm_tile_policy(2580)
+        ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
 
 
 @pytest.mark.parametrize("M,N,K", [(899, 512, 192), (300, 520, 192), (515, 300, 128), (257, 256, 64), (270, 300, 704), (1, 256, 64)])
 def test_gemm_x3_256_phased_slice_form_padding_tiles_left_out(ops, M, N, K):
-    """Policy 2582 (experiment, not the default): the phased slice kernel leaves out the matrix instructions and fragment reads of the 32-row
+    """Policy 2582 (the default since r04p): the phased slice kernel leaves out the matrix instructions and fragment reads of the 32-row
     m-tiles of a wave that lie entirely below row M (<.., 32, 4, 2, ..>; Phi's M = 899: wave row 1 of the last row of tiles keeps 1 m-tile of
     4).  Those rows are never stored: every output word must equal the default kernel's (2581), with and without split-K, with split-f16
     output, on M that leaves 0 / 1 / 2 / 3 m-tiles of a wave, and on M = 1 (wave row 1 of the only tile leaves out everything)."""
@@ -493,7 +493,7 @@ def test_gemm_x3_256_phased_slice_form_padding_tiles_left_out(ops, M, N, K):
             outs.append(ops.gemm_x3(asp, wsp, bias.to(d), None, H.ACT_GELU).cpu())
             names.append(ops.gemm_last_kernel())
         finally:
-            ops.gemm_tile_policy(2581)
+            ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
             ops.gemm_tile_policy(0)
     assert "32, 3, 2" in names[0] and "32, 4, 2" in names[1], names
     assert torch.equal(outs[0], outs[1])
@@ -508,7 +508,7 @@ def test_gemm_x3_256_phased_slice_form_padding_tiles_left_out_split_output(ops):
         assert "256, 256, 2, 4, 2, false, 32, 4, 2, true" in ops.gemm_last_kernel() or "skinny" in ops.gemm_last_kernel() or "64, 128" in ops.gemm_last_kernel()
         test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
     finally:
-        ops.gemm_tile_policy(2581)
+        ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
 
 
 def test_gemm_x3_split_output_k_panel_form(ops):
