@@ -295,6 +295,31 @@ def test_config2_panoptic_1024_f16x3_meets_north_star_bar():
     assert float((torch.sort(got["instances"].scores.cpu()).values - torch.sort(want["instances"].scores).values).abs().max()) < 2e-3
 
 
+def test_config2_padding_tiles_left_out_is_bitwise_the_plain_slice_kernel():
+    """The library's default K loop for the Phi GEMMs (policy 2582: the phased slice kernel with the matrix instructions of all-padding m-tiles
+    left out -- M = 899 on 256-row tiles) against the same kernel with them (2581, the form every parity record of r04 before r04p was taken
+    with): the whole 1024 x 1024 panoptic evaluation, every output tensor, bit for bit."""
+    from psalm_amd import hip_ops as H
+    cfg, sd = _full_model("panoptic")
+    inputs = make_inputs(cfg, "panoptic", size=1024, batch=1, seed=0)
+    model = _full_psalm("panoptic", "f16x3")
+    ops = model.ops
+    outs = {}
+    try:
+        for pol in (2581, 2582):
+            ops.gemm_tile_policy(pol)
+            r = model.eval_seg(**inputs)[0]
+            torch.cuda.synchronize()
+            outs[pol] = (r["mask_pred"].clone(), r["sem_seg"].clone(), r["panoptic_seg"][0].clone(), r["instances"].scores.clone(),
+                         r["instances"].pred_masks.clone(), list(r["panoptic_seg"][1]))
+    finally:
+        ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
+    for a, b in zip(outs[2581][:5], outs[2582][:5]):
+        assert torch.equal(a, b)
+    assert outs[2581][5] == outs[2582][5]
+    _report(test="config2_padding_tiles_left_out_bitwise", identical=True)
+
+
 def test_config2_panoptic_1024_multi_seed_default_and_fp32_control():
     """one image is a noisy gate (0.3 % positive pixels, ~10 empty reference masks, masks of a few pixels whose IoU
     moves in steps of 1/area).  Four more seeded inputs (seed 0 is the test above), same weights, the headline mode (three f16 products
