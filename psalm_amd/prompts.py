@@ -12,6 +12,9 @@ Reference (psalm/train/train_datasets.py unless noted):
   preprocess_referring_instruction :619-624, instruction join :680-682   -> referring_tokens
   the prompt texts of COCO_panoptic_dataset :210-220, COCO_semantic_dataset :589-599, COCO_instance_dataset :459-470,
   COCO_interactive_dataset :337-345, RefCOCO_dataset :677-684      -> *_sample()
+The evaluation-only dataset classes reuse these texts: gRefcoco_Dataset (psalm/eval/eval_grefcoco.py:246-258) = referring_sample,
+DAVIS_Dataset (psalm/eval/eval_davis.py:319-326) = region_sample, common_semantic_dataset for the open-vocabulary class lists
+(psalm/eval/semantic_segmentation.py:339-373: the *panoptic* wording over ADE-150 / PC-459 / A-847 names) = panoptic_sample.
 """
 from __future__ import annotations
 
