@@ -358,6 +358,12 @@ def main():
                          "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": next((v_.get("hbm_bytes_per_launch") for kk_, v_ in tj.items() if kk_.startswith(k.replace("_kernel", ""))), None),
                          "algorithmic_bytes_per_launch": v[2] // v[0], "launches_per_step": v[0] / nprof,
                          "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])]
+        for h_ in hbm_roof or []:
+            if h_["kernel"].startswith("panoptic_argmax"):
+                # (r04: found while reading the kernel for the SQ-counter table -- its `parked` share is LDS atomics and latency, not HBM)
+                h_["note"] = ("UPPER BOUND: `achieved` counts all Q mask planes; the kernel (like LP:325-386) reads only the planes of the queries it keeps "
+                              "(not void, score > 0.8: 50 of 100 on the seed-0 input, by the oracle), i.e. the true byte rate is Q / kept = ~2x lower; the "
+                              "launch is bound by its per-pixel LDS atomics and load latency, not by HBM")
         if kern:
             # dominant kernel = the single-kernel (un-split) GEMM instantiation with the largest share of the step
             cands = {k: v for k, v in kern.items() if " + " not in k} or kern
