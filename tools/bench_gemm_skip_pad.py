@@ -11,14 +11,15 @@ from psalm_amd.hip_ops import get_ops
 def main():
     ops = get_ops()
     out = {}
-    for M, N, K in ((899, 14336, 2048), (899, 2048, 10240), (1024, 14336, 2048)):
+    quick = "--quick" in sys.argv                 # one shape, two rounds (for a kernel trace inside a few seconds)
+    for M, N, K in ((899, 14336, 2048), (899, 2048, 10240), (1024, 14336, 2048))[:1 if quick else 3]:
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
         asp, wsp = ops.split_f16(a), ops.split_f16(w)
         c = torch.empty(M, N, device="cuda")
         row = {"2581": [], "2582": []}
         ref = None
-        for rnd in range(4):
+        for rnd in range(2 if quick else 4):
             for pol in (2581, 2582):
                 ops.gemm_tile_policy(pol)
                 try:
@@ -41,7 +42,7 @@ def main():
                     ops.gemm_tile_policy(2581)
         out[f"M{M} N{N} K{K}"] = row
         print(M, N, K, row, flush=True)
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
         json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
