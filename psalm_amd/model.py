@@ -132,11 +132,25 @@ class PSALM:
         self._plan_cache: Dict = {}
         self._prep_cache: Dict = {}                   # _prepare results by prompt-tensor identity (see _prepare)
         self.max_graphs = 8                           # captured input signatures kept alive (oldest dropped first)
+        # Input-geometry independence of the captured launch sequence (r05).  The reference's evaluation loops feed images whose un-padded
+        # box and original size differ image by image (ResizeShortestEdge + FixedSizeCrop, coco_panoptic_mapper.py:81-89; crop / resize at
+        # LP:1418-1429) and referring prompts whose length differs sentence by sentence (train_datasets.py:644-695).  So that such a stream
+        # replays ONE graph: (a) the sequence length is padded to a multiple of `len_bucket` with masked, zero rows -- exactly how the
+        # shorter prompts of a ragged batch are already carried (LP:939-946) --, the variable-length row sets of the blob to multiples of
+        # `len_bucket` entries; (b) the graph ends where the per-image geometry starts: it holds everything up to the mask logits at the
+        # padded image size and the class softmax, and the crop / resize / inference tail of LP:1418-1466 (a dozen launches whose sizes are
+        # the image's own) is issued after the replay, while the GPU is still inside the graph.  graph_tail = True puts the tail back into
+        # the graph (and the geometry back into its key): the r01-r04 behaviour, kept for A/B measurements.
+        self.len_bucket = 32
+        self.graph_tail = False
+        self.graph_stats = {"calls": 0, "replays": 0, "eager": 0, "captures": 0}
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
-        # Graph replay writes its results into buffers owned by the captured graph; "copy" (default) hands the caller private copies
-        # (device-to-device, ~1 GB per 1024^2 panoptic image = ~0.3 ms), "alias" returns the graph's own buffers, which the NEXT call with the
-        # same input signature overwrites -- only for callers that consume a result before the next call (bench.py, the reference's
-        # evaluators do; an evaluator that keeps tensors across iterations would silently read the next image's masks).
+        # Graph replay writes its results into buffers owned by the captured graph; "copy" (default) hands the caller private copies,
+        # "alias" returns the graph's own buffers, which the NEXT call with the same input signature overwrites -- only for callers that
+        # consume a result before the next call (bench.py, the reference's evaluators do; an evaluator that keeps tensors across iterations
+        # would silently read the next image's masks).  Since r05 the graph ends before the per-image crop / resize / inference tail
+        # (`graph_tail`), whose results are fresh buffers anyway: the one tensor that can still alias the graph is `mask_pred` of an image
+        # that needs no crop / resize (0.4 GB at 1024^2, ~0.1 ms to copy).
         self.graph_outputs = "copy"
         # pixel decoder on a second HIP stream, concurrent with the LLM (fork / join, captured into the hipGraph).  bf16 mode, r1k: no
         # gain (the LLM GEMMs fill the chip).  f16x3, r02: the 3x longer LLM GEMMs leave room (224 tiles on 256 CUs) for the decoder's ~150
@@ -169,6 +183,7 @@ class PSALM:
         r.ops.x3, r.ops.debug_bounds = self.ops.x3, self.ops.debug_bounds
         r._cache, r._graphs, r._plan_cache, r._prep_cache = {}, {}, {}, {}
         r._side = None
+        r.graph_stats = dict.fromkeys(self.graph_stats, 0)
         return r
 
     # ======================================================================================= nn.Module / HF surface the eval scripts touch
@@ -735,6 +750,41 @@ class PSALM:
         plan["region"] = csr([[[r] for r in p[5]] for p in per]) if n_regions is not None else None
         return plan
 
+    def _bucketed(self, plan, B):
+        """The splice plan with the sequence length rounded up to a multiple of `len_bucket`: the extra positions are what the shorter
+        prompts of a ragged batch already are (LP:939-946: zero embedding rows, key mask 0, behind every real token -- the causal mask
+        alone keeps them out of every real row), the row sets are re-based to the new row stride, and the variable-length ones (class-name
+        / refer / region rows) are padded to a multiple of `len_bucket` entries behind their last CSR offset (never read).  Nothing a
+        kernel launch is sized by then depends on the exact prompt length: one captured graph serves the whole bucket."""
+        q = int(self.len_bucket or 0)
+        if q <= 1:
+            return plan
+        hit = plan.get("_bucketed")
+        if hit is not None and hit[0] == q:
+            return hit[1]
+        L = plan["L"]
+        Lp = (L + q - 1) // q * q
+        out = dict(plan)
+        out.pop("_bucketed", None)
+        if Lp != L:
+            def wide(a, fill):
+                w_ = np.full((B, Lp), fill, a.dtype)
+                w_[:, :L] = a
+                return w_
+            out["sid"], out["srow"], out["kmask"] = wide(plan["sid"], -1), wide(plan["srow"], 0), wide(plan["kmask"], 0)
+            out["L"] = Lp
+        for name in ("seg", "cls", "refer", "region"):
+            if plan[name] is None:
+                continue
+            off, rows = plan[name]
+            rows = (rows.astype(np.int64) // L * Lp + rows.astype(np.int64) % L).astype(np.int32)
+            if name != "seg":                            # (seg: B * Q rows whatever the prompt)
+                n = (rows.shape[0] + q - 1) // q * q
+                rows = np.concatenate((rows, np.zeros(max(n, q) - rows.shape[0], np.int32)))
+            out[name] = (off, rows)
+        plan["_bucketed"] = (q, out)
+        return out
+
     def _dev_i32(self, a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
@@ -1024,6 +1074,7 @@ class PSALM:
             plan = self._plan_cache[pkey] = self._splice_plan(
                 input_ids, attention_mask, n_img, class_name_ids, cls_indices, token_refer_id, n_regions,
                 class_name_embedding_indices is not None, refer_embedding_indices is not None)
+        plan = self._bucketed(plan, B)
         arrays["sid"] = plan["sid"].reshape(-1)
         arrays["srow"] = plan["srow"].reshape(-1)
         arrays["kmask"] = plan["kmask"].reshape(-1)
@@ -1115,7 +1166,8 @@ class PSALM:
                                out_dtype=torch.float32)
         hidden = self.llm(embeds, dv["kmask"].view(B, L), B, L)
         if stages is not None:
-            stages.update(inputs_embeds=embeds.view(B, L, -1), hidden_states=hidden.view(B, L, -1), lengths=meta["lens"])
+            Lr = max(meta["lens"])                    # (L is the bucketed length: hand the stage tensors out at the real one)
+            stages.update(inputs_embeds=embeds.view(B, L, -1)[:, :Lr], hidden_states=hidden.view(B, L, -1)[:, :Lr], lengths=meta["lens"])
         # ---- LLM states -> decoder embeddings (LP:1366-1390)
         Q = cfg.md_queries
         # (row-set means come out in the GEMM operand dtype: bf16 -> the skinny MFMA kernel instead of the converting path)
@@ -1155,7 +1207,10 @@ class PSALM:
             if stages is not None:
                 stages.setdefault("mask_features", []).append(mf)
                 stages.setdefault("multi_scale_features", []).append(ms)
-            outs.append(self._postprocess(r, meta["post"][b]) if postprocess else r)
+            if postprocess == "head":                    # graph capture: stop where the image's own geometry starts (see len_bucket)
+                outs.append(self._post_head(r, meta["post"][b][0], meta["post"][b][1]))
+            else:
+                outs.append(self._postprocess(r, meta["post"][b]) if postprocess else r)
         return outs
 
     def forward_logits(self, input_ids, attention_mask, images, seg_info=None, class_name_ids=None,
@@ -1184,13 +1239,26 @@ class PSALM:
         sem = o.gemm(probsT, self._wop(o.sigmoid_transpose(mflat, Kpad, self.wdt)), out_dtype=torch.float32)
         return (sem, o.mask_scores(mflat)) if want_mask_score else sem
 
-    def _postprocess(self, r, sizes):
-        """llava_phi.py:1401-1466 for one image, device side.  r: predictor outputs; sizes: (Hpad, Wpad, crop_h, crop_w,
-        out_h, out_w) from _prepare."""
+    def _post_head(self, r, Hpad, Wpad):
+        """The part of llava_phi.py:1401-1466 that does not depend on the image's own geometry: the mask logits at the padded image size
+        (LP:1401-1406) and the class softmax (LP:328,403,410).  Inside the captured graph."""
+        o, cfg = self.ops, self.cfg
+        Q = cfg.md_queries
+        h = {"r": r, "mp0": o.resize_planes(r["pred_masks"], Hpad, Wpad)}                 # LP:1401-1406
+        if self.seg_task in ("semantic", "instance", "panoptic"):
+            Kpad = (Q + 63) // 64 * 64                                   # K of the semantic GEMM (direct-to-LDS path: K % 64 == 0)
+            h["Kpad"] = Kpad
+            h["soft"] = o.class_softmax(r["pred_class_name_logits"], Kpad, probsT_dtype=self.wdt)
+        return h
+
+    def _post_tail(self, h, sizes):
+        """llava_phi.py:1418-1466 for one image, device side: crop to the un-padded box, resize to the original size, the task's
+        inference function.  h: `_post_head`'s dict; sizes: (Hpad, Wpad, crop_h, crop_w, out_h, out_w) from _prepare.  Every launch here
+        is sized by the image's own geometry, so this runs outside the captured graph (see `len_bucket` / `graph_tail`)."""
         o, cfg = self.ops, self.cfg
         Q = cfg.md_queries
         Hpad, Wpad, oh, ow, height, width = sizes
-        mp = o.resize_planes(r["pred_masks"], Hpad, Wpad)                             # LP:1401-1406
+        r, mp = h["r"], h["mp0"]
         task = self.seg_task
         resize_after = (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad)
         if resize_after and task != "semantic":                                       # sem_seg_postprocess_before_inference, LP:301,1427
@@ -1200,30 +1268,25 @@ class PSALM:
         mflat = mp.view(Q, HW)
         res = {"_hw": (height, width), "_crop": (oh, ow)}
         if task == "semantic":                                                        # semantic only, post-processed AFTER inference
-            cls = r["pred_class_name_logits"]
-            C1 = cls.shape[1]
-            Kpad = (Q + 63) // 64 * 64
-            probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
-            sem = self._semantic(mflat, probsT, Kpad).view(C1 - 1, mh, mw)                                        # LP:402-406
+            C1 = r["pred_class_name_logits"].shape[1]
+            probs, probsT, score, label = h["soft"]
+            sem = self._semantic(mflat, probsT, h["Kpad"]).view(C1 - 1, mh, mw)                                    # LP:402-406
             res["sem_seg"] = o.resize_planes(sem, height, width, crop=(oh, ow)) if resize_after else sem           # LP:1437-1440
             res["_pending"] = ("semantic",)
             res["mask_pred"] = mp
             return res
         if task == "instance":                                                        # top-k instances, no thing filter (LP:428)
-            cls = r["pred_class_name_logits"]
-            C1 = cls.shape[1]
-            probs, _, _, _ = o.class_softmax(cls, (Q + 63) // 64 * 64, probsT_dtype=self.wdt)
+            C1 = r["pred_class_name_logits"].shape[1]
+            probs = h["soft"][0]
             mscore = o.mask_scores(mflat)
             sc, cl, qq, cnt = o.topk_select(probs, C1 - 1, Q, None, mscore)
             res["_pending"] = ("instance", sc, o.to_i64(cl), o.to_i64(qq), cnt, o.binarize_gather(mp, Q, qq, cnt), o.zeros(sc.shape[0], 4))
             res["mask_pred"] = mp
             return res
         if task == "panoptic":
-            cls = r["pred_class_name_logits"]
-            C1 = cls.shape[1]
-            Kpad = (Q + 63) // 64 * 64                                   # K of the semantic GEMM (direct-to-LDS path: K % 64 == 0)
-            probs, probsT, score, label = o.class_softmax(cls, Kpad, probsT_dtype=self.wdt)
-            sem, mscore = self._semantic(mflat, probsT, Kpad, want_mask_score=True)                          # LP:402-406, 443-444
+            C1 = r["pred_class_name_logits"].shape[1]
+            probs, probsT, score, label = h["soft"]
+            sem, mscore = self._semantic(mflat, probsT, h["Kpad"], want_mask_score=True)                     # LP:402-406, 443-444
             res["sem_seg"] = sem.view(C1 - 1, height, width)
             thing = self._thing_dev(C1 - 1)
             counts = o.zeros(2 + 3 * Q, dtype=torch.int32)      # [instances kept, segments, segments_info (Q,3)]: ONE device-to-host copy
@@ -1231,8 +1294,8 @@ class PSALM:
             inst_masks = o.binarize_gather(mp, Q, qq, cnt)
             pan, pinfo, ninfo = o.panoptic(mp, score, label, thing, C1 - 1, cfg.object_mask_threshold, cfg.overlap_threshold,
                                            info_out=counts[2:].view(Q, 3), ninfo_out=counts[1:2])
-            # (LongTensor labels / indices and the all-zero pred_boxes of `Instances` are made HERE, inside the captured launch sequence,
-            #  by this library's cast / memset: _finalize only slices -- no framework kernel per image)
+            # (LongTensor labels / indices and the all-zero pred_boxes of `Instances` are made HERE, by this library's cast / memset:
+            #  _finalize only slices -- no framework kernel per image)
             res["_pending"] = ("panoptic", sc, o.to_i64(cl), o.to_i64(qq), counts, inst_masks, pan, o.zeros(sc.shape[0], 4))
         elif task == "referring":
             mscore = o.mask_scores(mflat)
@@ -1248,6 +1311,11 @@ class PSALM:
             raise NotImplementedError(f"seg_task {task}")
         res["mask_pred"] = mp
         return res
+
+    def _postprocess(self, r, sizes):
+        """llava_phi.py:1401-1466 for one image, device side.  r: predictor outputs; sizes: (Hpad, Wpad, crop_h, crop_w,
+        out_h, out_w) from _prepare."""
+        return self._post_tail(self._post_head(r, sizes[0], sizes[1]), sizes)
 
     def _thing_dev(self, C):
         key = ("thing", C, tuple(int(bool(x)) for x in self.is_thing_list))
@@ -1289,15 +1357,24 @@ class PSALM:
         return res
 
     # ---- hipGraph execution: the ~600 launches of one call are captured once per input signature and replayed
+    def _graph_key(self, meta):
+        """What a captured launch sequence is specific to.  NOT in it (unless graph_tail): the per-image geometry `meta["post"]` beyond the
+        padded image size (itself a function of img_shape); the sequence length and the row-set sizes enter bucketed (`_bucketed`)."""
+        return (self.seg_task, self.precision, meta["video"], meta["img_shape"], meta["L"], meta["n_cls"], meta["n_regions"],
+                meta["post"] if self.graph_tail else len(meta["post"]),
+                meta["layout"], tuple(int(bool(x)) for x in self.is_thing_list) if self.is_thing_list is not None else None)
+
     def _run_graphed(self, images, blob, layout, meta, vp_images=None):
-        key = (self.seg_task, self.precision, meta["video"], meta["img_shape"], meta["L"], meta["n_cls"], meta["n_regions"], meta["post"],
-               meta["layout"], tuple(int(bool(x)) for x in self.is_thing_list) if self.is_thing_list is not None else None)
+        key = self._graph_key(meta)
         ent = self._graphs.get(key)
         host = torch.from_numpy(blob)
+        st = self.graph_stats
+        st["calls"] += 1
         if ent is None:                                    # first sighting: eager run (fills caches / workspaces, warms the allocator)
             while len(self._graphs) >= self.max_graphs:    # every captured graph owns its intermediates (GBs at 1024^2): bound them
                 self._graphs.pop(next(iter(self._graphs)))  # (insertion order = oldest signature first)
             self._graphs[key] = {"seen": 1}
+            st["eager"] += 1
             dv = self._views(host.to(self.device), layout)
             return self._forward_device(images, dv, meta, vp_images=vp_images)
         if "graph" not in ent:                             # second sighting: capture
@@ -1309,17 +1386,31 @@ class PSALM:
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g):
-                    ent["outs"] = self._forward_device(ent["images"], dv, meta, vp_images=ent["vp"])
+                    ent["outs"] = self._forward_device(ent["images"], dv, meta, vp_images=ent["vp"],
+                                                       postprocess=True if self.graph_tail else "head")
             except Exception:
                 self._graphs.pop(key, None)                # a failed capture must not leave a half-built entry behind
                 raise
             ent["graph"] = g
+            st["captures"] += 1
         self.ops.copy_(ent["images"], images)
         if vp_images is not None:
             self.ops.copy_(ent["vp"], vp_images)
         ent["blob"].copy_(host)
         ent["graph"].replay()
-        if self.graph_outputs == "alias":
+        st["replays"] += 1
+        copy = self.graph_outputs != "alias"
+        if not self.graph_tail:
+            # the tail's launches are queued behind the replay while the GPU is still inside the graph; its results are fresh buffers --
+            # only `mask_pred` can still be the graph's own (an image that needs no crop / resize)
+            outs = []
+            for b, h in enumerate(ent["outs"]):
+                res = self._post_tail(h, meta["post"][b])
+                if copy and res["mask_pred"].data_ptr() == h["mp0"].data_ptr():
+                    res["mask_pred"] = res["mask_pred"].clone()
+                outs.append(res)
+            return outs
+        if not copy:
             return ent["outs"]
 
         def own(v):

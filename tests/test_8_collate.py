@@ -84,3 +84,71 @@ def test_region_mask_nonzero_fast_path_equals_torch_nonzero():
     for m in cases:
         got, want = _nonzero_2d(m), m.nonzero()
         assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want)
+
+
+def test_bucketed_splice_plan_is_the_plan_padded_like_a_ragged_batch():
+    """PSALM._bucketed: the sequence length rounded up to `len_bucket` with zero-embedding, masked positions (what the shorter prompts of
+    a ragged batch already are, LP:939-946), the CSR row sets re-based to the new row stride and padded behind their last offset -- so that
+    one captured launch sequence serves every prompt length of a bucket (the graph key holds the bucketed length, not the exact one)."""
+    from ops_backend import make_ops
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    for task, batch in (("panoptic", 2), ("referring", 4), ("region", 3)):
+        cfg = PsalmConfig.tiny(task)
+        model = PSALM(cfg, make_state_dict(cfg, seed=1), ops=make_ops("emu"), precision="fp32")
+        inp = make_inputs(cfg, task, size=96, batch=batch, seed=9, num_classes=9)
+        n_regions = None
+        if task == "region":
+            n_regions = [int(s["instances"].region_masks.tensor.shape[0]) for s in inp["seg_info"]]
+        a = model._splice_plan(inp["input_ids"], inp["attention_mask"], 9, inp.get("class_name_ids"), inp.get("cls_indices"),
+                               inp.get("token_refer_id"), n_regions, "class_name_embedding_indices" in inp, "refer_embedding_indices" in inp)
+        L = a["L"]
+        for q in (0, 1, 8, 32, 64):
+            model.len_bucket = q
+            b = model._bucketed(a, batch)
+            Lp = L if q <= 1 else (L + q - 1) // q * q
+            assert b["L"] == Lp and b["lens"] == a["lens"] and b["n_cls"] == a["n_cls"]
+            assert model._bucketed(a, batch) is b or q <= 1                               # cached with the plan
+            for k, fill in (("sid", -1), ("srow", 0), ("kmask", 0)):
+                assert b[k].shape == (batch, Lp) and np.array_equal(b[k][:, :L], a[k]) and (b[k][:, L:] == fill).all(), (task, q, k)
+            for k in ("seg", "cls", "refer", "region"):
+                assert (a[k] is None) == (b[k] is None)
+                if a[k] is None:
+                    continue
+                (ao, ar), (bo, br) = a[k], b[k]
+                assert np.array_equal(ao, bo)
+                n = ar.shape[0]
+                assert np.array_equal(br[:n] // Lp, ar // L) and np.array_equal(br[:n] % Lp, ar % L), (task, q, k)
+                if q > 1 and k != "seg":
+                    assert br.shape[0] % q == 0 and br.shape[0] >= max(n, q) and (br[n:] == 0).all()
+                else:
+                    assert br.shape[0] == n
+
+
+@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3)])
+def test_bucketed_length_gives_the_results_of_the_exact_length(task, batch):
+    """Whole tiny model on the host emulator with len_bucket = 32 (default) vs 0: the padded positions change nothing a result reads --
+    integer outputs identical, logits equal to fp32 summation-order noise (the GEMMs may pick another tile / split for the larger M)."""
+    from ops_backend import make_ops
+    from psalm_amd.config import PsalmConfig
+    from psalm_amd.model import PSALM
+    from psalm_amd.synthetic import make_inputs, make_state_dict
+    cfg = PsalmConfig.tiny(task)
+    sd = make_state_dict(cfg, seed=12)
+    inp = make_inputs(cfg, task, size=96, batch=batch, seed=4, num_classes=9, pad=32 if task == "referring" else 0)
+    outs = {}
+    for q in (0, 32):
+        model = PSALM(cfg, sd, ops=make_ops("emu"), precision="fp32")
+        model.len_bucket = q
+        outs[q] = model.eval_seg(**inp)
+        blob, layout, meta = model._prepare(inp["input_ids"], inp["attention_mask"], inp["images"], inp["seg_info"], inp.get("class_name_ids"),
+                                            inp.get("class_name_embedding_indices"), inp.get("cls_indices"), inp.get("token_refer_id"),
+                                            inp.get("refer_embedding_indices"), None)
+        assert meta["L"] % 32 == 0 if q else meta["L"] == max(meta["lens"])
+    for a, b in zip(outs[0], outs[32]):
+        rng = a["mask_pred"].abs().max()
+        assert (a["mask_pred"] - b["mask_pred"]).abs().max() <= 2e-5 * rng
+        assert torch.equal(a["instances"].pred_masks, b["instances"].pred_masks)
+        if task == "panoptic":
+            assert torch.equal(a["panoptic_seg"][0], b["panoptic_seg"][0]) and a["panoptic_seg"][1] == b["panoptic_seg"][1]
