@@ -37,32 +37,95 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0         # HBM3E, same guide
-# HBM bytes per launch per kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload (tools/gpu_profile.sh ->
-# tools/make_traffic_json.py); the file of the current round if present, else the previous round's (bf16 kernels only)
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"))
-                     if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json"))
-def _profiled_name(k):
-    """The committed counter passes of r04 (HBM traffic, SQ fractions) ran the phased slice kernel as <.., 32, 3, 2, ..>; the default since r04p is
-    <.., 32, 4, 2, ..>: the same kernel -- same copies, same barriers, same HBM traffic -- with the matrix instructions of all-padding m-tiles left
-    out, i.e. with ~10 % fewer matrix-pipe busy cycles than the pass shows."""
-    return k.replace("false, 32, 4, 2,", "false, 32, 3, 2,")
-
-
-SQ_JSON = os.path.join(ROOT, "profiles", "r04_sq_summary.json")     # per-kernel SQ-counter fractions + clock of the same workload (one --pmc pass)
+# HBM bytes per launch per kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload at THIS round's kernels
+# (tools/gpu_r05_profile.sh -> tools/make_traffic_json.py), and the SQ-counter fractions + clock of the same workload (one more --pmc pass,
+# tools/make_sq_json.py).  Both are looked up under the EXACT template instantiation the library reports for the timed launch
+# (psalm_gemm_last_kernel); a kernel the committed passes do not contain gets `traffic: null` / no `sq_counters` -- never another
+# instantiation's numbers (r04 looked the PH8 = 4 kernel up under the PH8 = 3 name).
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
+SQ_JSON = os.path.join(ROOT, "profiles", "r05_sq_summary.json")
 # the oracle's host-thread count: the fastest of the 8 / 16 / 32 / 64 sweep on the GPU box's host (tools/cpu_baseline_sweep.py ->
 # profiles/r04_cpu_baseline_threads.json), and the reference's OWN eval_seg timed in the authoring container (profiles/r04_reference_cpu.json)
 CPU_THREADS_JSON = os.path.join(ROOT, "profiles", "r04_cpu_baseline_threads.json")
 REFERENCE_CPU_JSON = os.path.join(ROOT, "profiles", "r04_reference_cpu.json")
-GATE = {"version": 3,
-        "meets_bar_plain_mean": "on every seeded input: mean over the 100 queries of mask IoU vs the CPU oracle >= 0.999 AND semantic argmax agreement >= 99.9 % "
-                                "(north_star's literal statistic; the r01 / r02 definition of meets_north_star_bar)",
-        "meets_bar_pooled": "on every seeded input: pooled mask IoU (sum of intersections / sum of unions over the queries) >= 0.999 AND mean IoU over "
-                            "reference masks of >= 64 px >= 0.999 AND semantic argmax agreement >= 99.9 % (r03 definition: one flipped pixel of a 4-pixel mask "
-                            "does not decide it)",
-        "meets_north_star_bar": "= meets_bar_pooled AND no_worse_than_fp32_control",
-        "no_worse_than_fp32_control": "over the seeded inputs, this mode is below the plain-mean bar on no more inputs than the exact-fp32 GPU mode (same path, the "
-                                      "oracle's arithmetic width in another summation order) is, and below the pooled bar on no more inputs either -- a count, not "
-                                      "an input-by-input rule: WHICH knife-edge input tips is re-drawn by every change of summation order (DESIGN.md section 0 item 1)"}
+
+
+def varied_streams(model, cfg, size, n_panoptic, fixed_images_per_s):
+    """Two input streams shaped like the reference's own evaluation loops, through the SAME model object (hipGraph replay):
+      panoptic : `n_panoptic` inputs, each its own image / prompt tensors, whose un-padded box and original (height, width) follow COCO-like
+                 sizes through the reference's eval transform (T.ResizeShortestEdge(size, size) + T.FixedSizeCrop, coco_panoptic_mapper.py:81-89;
+                 crop / resize of the results at llava_phi.py:1418-1429) -- a few pixels of jitter make (almost) every geometry distinct;
+      referring: batches of 4 at 640^2 (BASELINE.json configs[2]) whose sentences have 5-25 tokens (train_datasets.py:644-695), each batch
+                 with its own crop boxes.
+    Per stream: images/s over the whole stream after a 4-call warm-up, the graph-cache statistics of the timed part (signature misses =
+    calls that ran eagerly or captured), and the same model's rate on ONE input of the stream repeated (the fixed-shape figure it is
+    compared with)."""
+    import random
+    from psalm_amd.synthetic import COCO_LIKE_SIZES, make_inputs, resized_box
+    rnd = random.Random(5)
+
+    def geom(sz):
+        h, w = COCO_LIKE_SIZES[rnd.randrange(len(COCO_LIKE_SIZES))]
+        h, w = h - rnd.randrange(0, 24), w - rnd.randrange(0, 24)
+        oh, ow = resized_box(h, w, sz)
+        return (oh, ow, h, w)
+
+    def run(stream, per_call):
+        for inp in stream[:4]:
+            model.eval_seg(**inp)
+        torch.cuda.synchronize()
+        st0 = dict(model.graph_stats)
+        t0 = time.perf_counter()
+        for inp in stream:
+            model.eval_seg(**inp)
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        st = {k: model.graph_stats[k] - st0[k] for k in st0}
+        one = stream[len(stream) // 2]
+        for _ in range(3):
+            model.eval_seg(**one)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(len(stream)):
+            model.eval_seg(**one)
+        torch.cuda.synchronize()
+        fixed = per_call * len(stream) / (time.perf_counter() - t0)
+        v = per_call * len(stream) / dt_
+        return {"images_per_s": round(v, 3), "same_stream_fixed_shape_images_per_s": round(fixed, 3), "ratio_to_fixed_shape": round(v / fixed, 4),
+                "calls": st["calls"], "signature_misses": st["eager"] + st["captures"], "replays": st["replays"],
+                "signature_miss_rate": round((st["eager"] + st["captures"]) / max(st["calls"], 1), 4)}
+
+    out = {"note": "side metric, not `value`: per-call inputs differ in crop box, original size and (referring) sentence length; every call makes "
+                   "its own prompt / padding-mask tensors as a data loader would"}
+    graphs0 = len(model._graphs)
+    geos = [geom(size) for _ in range(n_panoptic)]
+    stream = []
+    for i, g_ in enumerate(geos):
+        inp = make_inputs(cfg, "panoptic", size=size, batch=1, seed=100 + i, geometry=[g_])
+        inp["images"] = inp["images"].cuda()
+        stream.append(inp)
+    out["panoptic"] = dict(run(stream, 1), inputs=len(stream), distinct_geometries=len(set(geos)), size=size,
+                           ratio_to_value=None)
+    out["panoptic"]["ratio_to_value"] = round(out["panoptic"]["images_per_s"] / fixed_images_per_s, 4)
+    out["panoptic"]["graphs_added"] = len(model._graphs) - graphs0
+    del stream
+    torch.cuda.empty_cache()
+    task0 = model.seg_task
+    try:
+        model.seg_task = "referring"                       # same weights; the task decides the prompt splice and the inference tail only
+        graphs0 = len(model._graphs)
+        stream, lens_seen = [], []
+        for i in range(max(4, n_panoptic // 4)):
+            lens = [rnd.randint(5, 25) for _ in range(4)]
+            lens_seen += lens
+            inp = make_inputs(cfg, "referring", size=640, batch=4, seed=300 + i, refer_lens=lens, geometry=[geom(640) for _ in range(4)])
+            inp["images"] = inp["images"].cuda()
+            stream.append(inp)
+        out["referring"] = dict(run(stream, 4), batches=len(stream), batch=4, size=640, sentence_tokens=[min(lens_seen), max(lens_seen)],
+                                graphs_added=len(model._graphs) - graphs0)
+    finally:
+        model.seg_task = task0
+    return out
 
 
 def main():
@@ -81,7 +144,17 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still run init_process_group('nccl'), the weight broadcast, the checksum all-reduce and the barriers (RCCL dry run on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
+    ap.add_argument("--no-varied", action="store_true",
+                    help="skip the varied-input-stream leg (rank 0, N=1): 64 panoptic inputs with COCO-like crop boxes / original sizes and a referring "
+                         "stream with 5-25-token sentences -> other_modes.varied (images/s, signature misses)")
+    ap.add_argument("--varied-n", type=int, default=64, help="panoptic inputs of the varied stream (the referring stream has a quarter as many batches of 4)")
+    ap.add_argument("--graph-tail", action="store_true", help="A/B: put the per-image crop / resize / inference tail back into the captured graph (r04 behaviour)")
+    ap.add_argument("--emu", action="store_true",
+                    help="TEST MODE (tests/test_5_dist.py): host-emulated kernels (tests/emu), the tiny architecture, backend gloo -- exercises this "
+                         "script's launcher / affinity / placeholder-rank / broadcast / checksum / all_gather / one-JSON-line path for N > 1 on a "
+                         "machine without GPUs.  Its numbers mean nothing; the line says \"emu\": true")
     args = ap.parse_args()
+    emu = args.emu
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # stand-alone multi-GPU launch: one rank per GPU under torch.distributed.run (the driver's own launch line sets WORLD_SIZE
@@ -109,7 +182,8 @@ def main():
             os.sched_setaffinity(0, set(cores[local_rank * per:(local_rank + 1) * per]) or set(cores))
         except OSError:
             pass
-    torch.cuda.set_device(local_rank)
+    if not emu:
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
@@ -120,7 +194,10 @@ def main():
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(so.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # N ranks build their (seeded) weights concurrently on the host
         t_pg = time.perf_counter()
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         t_pg = time.perf_counter() - t_pg
         assert dist.get_world_size() == args.gpus
 
@@ -129,11 +206,21 @@ def main():
     from psalm_amd.model import PSALM
     from psalm_amd.synthetic import make_inputs, make_state_dict
 
-    cfg = PsalmConfig(seg_task="panoptic")
+    cfg = PsalmConfig.tiny("panoptic") if emu else PsalmConfig(seg_task="panoptic")
+    dev = "cpu" if emu else "cuda"
+    ops = None
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        from psalm_amd.hip_ops import Ops
+        ops = Ops(build_emu.build(verbose=False))
+        args.size = 96
+        args.no_side_modes = args.no_cpu_baseline = args.no_varied = True
     # rank 0 owns the (seeded) checkpoint; the other ranks build their weight arena from placeholders of the same shapes and receive
     # rank 0's prepared weights through the broadcast -- which is thereby real, not a copy of identical data onto itself
     sd = make_state_dict(cfg, seed=0, shapes_only=rank != 0)
-    model = PSALM(cfg, sd, precision=args.precision, use_graphs=not args.eager)
+    model = PSALM(cfg, sd, ops=ops, precision=args.precision, use_graphs=not args.eager)
+    model.graph_tail = bool(args.graph_tail)
     for code in [int(c) for c in args.gemm_policy.split(",") if c]:
         model.ops.gemm_tile_policy(code)
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
@@ -156,14 +243,18 @@ def main():
         ctypes.CDLL(None).fflush(None)
         if rank != 0:
             del sd                                              # placeholders are not needed any more
-    inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank)
-    inputs["images"] = inputs["images"].cuda()                  # inputs resident in HBM before the timed region
+    inputs = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=rank, **({"num_classes": 9} if emu else {}))
+    inputs["images"] = inputs["images"].to(dev)                 # inputs resident in HBM before the timed region
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     if not args.eager:
         for _ in range(2):                                      # 1st call eager, 2nd captures the hipGraph (one-off set-up)
@@ -176,37 +267,39 @@ def main():
         out = model.eval_seg(**inputs)
     barrier()
     dt = time.perf_counter() - t0
+    model_graph_stats = dict(model.graph_stats) if not args.eager else None
     per_rank = None
     if use_dist:
-        mine = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)                            # each rank's own wall time for its K steps
         per_rank = [args.steps / float(t_.item()) for t_ in every]
         dt = max(float(t_.item()) for t_ in every)              # the job is done when its slowest rank is
 
-    # ---- is the host on the critical path?  GPU time of one step = the captured hipGraph replayed back to back with NO host work in
-    # between (events on the replay stream); `ms_per_step` - `gpu_ms_per_step` is what prompt handling, the blob upload, the replay call
-    # and the one result read-back per image add
+    # ---- is the host on the critical path?  GPU time of one step = K calls issued back to back WITHOUT the one host read-back per image
+    # (`_finalize` replaced by a pass-through: graph replay + the crop / resize / inference tail, nothing the host waits for), bracketed by
+    # events on the launch stream; `ms_per_step` - `gpu_ms_per_step` is what prompt handling, the blob upload and the result read-back add
     gpu_ms = None
-    if not args.eager and rank == 0:
-        ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
-        if len(ents) == 1:
-            g_ = ents[0]["graph"]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g_.replay()
+    if not args.eager and rank == 0 and not emu:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        model._finalize = lambda r_, info_: r_
+        try:
+            model.eval_seg(**inputs)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(args.steps):
-                g_.replay()
+                model.eval_seg(**inputs)
             e1.record()
             torch.cuda.synchronize()
             gpu_ms = e0.elapsed_time(e1) / args.steps
+        finally:
+            del model._finalize
 
     # ---- side metric, NOT `value`: two images in flight on one GPU.  `value` above is the reference's own usage (one synchronous eval_seg
     # at a time); a serving loop can drive a second `PSALM.replica()` (shared weights, own buffers / graphs) from a second host thread on a
     # second stream, and the hardware fills one image's partial waves and latency-bound launches with the other's (r03a: +11 %).
     inflight = None
-    if rank == 0 and world == 1 and not args.eager and not args.no_side_modes and args.precision == "f16x3":
+    if rank == 0 and world == 1 and not args.eager and not args.no_side_modes and args.precision == "f16x3" and not emu:
         try:                                                    # an auxiliary leg must never cost the run its JSON line
             import threading
             rep = model.replica()
@@ -250,10 +343,19 @@ def main():
             inflight = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         torch.cuda.empty_cache()
 
+    # ---- side metric, NOT `value`: does the throughput hold on a stream the reference's evaluation loops would feed?  (VERDICT r04 missing #2)
+    varied = None
+    if rank == 0 and world == 1 and not args.eager and not args.no_varied and not emu and args.precision == "f16x3":
+        try:
+            varied = varied_streams(model, cfg, args.size, args.varied_n, fixed_images_per_s=args.steps / dt)
+        except Exception as ex:  # noqa: BLE001  (auxiliary leg)
+            varied = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        torch.cuda.empty_cache()
+
     # ---- instrumented steps (not part of `value`): HIP events (torch's current stream = the launch stream) around every
     # C-ABI launch, attributed to kernel instantiations through psalm_gemm_describe (the library's own selection function)
     roof = None
-    if rank == 0:
+    if rank == 0 and not emu:
         recs = []
         model.use_graphs = False                                  # per-launch events need the eager launch path
         model.overlap_streams = False                             # ... and one stream: the timed region runs the pixel decoder concurrently with
@@ -377,7 +479,7 @@ def main():
             if os.path.exists(tpath):                                            # (tools/gpu_final.sh + tools/make_traffic_json.py)
                 with open(tpath) as f:
                     tj = json.load(f).get("kernels", {})
-                traffic = tj.get(_profiled_name(kname.split(" + ")[0]), {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(kname.split(" + ")[0], {}).get("hbm_bytes_per_launch")
             targs = [t.strip() for t in kname.split("<", 1)[1].split(">", 1)[0].split(",")] if "glds_kernel<" in kname else []
             x3_form = int(targs[9]) if len(targs) >= 11 else 0                   # template argument X3: 1 / 2 = split-f16 K-panel / slice form (3 products)
             is_x3 = x3_form != 0
@@ -397,9 +499,9 @@ def main():
             if os.path.exists(SQ_JSON):                                          # committed SQ-counter pass of this workload (tools/make_sq_json.py)
                 with open(SQ_JSON) as f:
                     sq = json.load(f)
-                e = sq.get("kernels", {}).get(_profiled_name(kname.split(" + ")[0]))
+                e = sq.get("kernels", {}).get(kname.split(" + ")[0])
                 if e:
-                    roof["sq_counters"] = dict(e, source=sq.get("source"), kernel_in_the_pass=_profiled_name(kname.split(" + ")[0]),
+                    roof["sq_counters"] = dict(e, source=sq.get("source"), kernel_in_the_pass=kname.split(" + ")[0],
                                                note="fractions of the wavefront cycles (parked at s_waitcnt / s_barrier, issue-stalled, issuing) and of the chip's "
                                                     "matrix-pipe CYCLES; `frac` / `mfma_issue` are against the 2.4 GHz peak, this launch ran at clock_GHz")
         if args.breakdown:
@@ -441,36 +543,17 @@ def main():
                          f"({', '.join(f'{t:.1f}' for t in tcs)} s)",
                "threads_chosen_by": (f"sweep on this host class (profiles/r04_cpu_baseline_threads.json: {sweep.get('seconds_by_threads')})" if sweep else "default"),
                "reference_itself": ref_note}
-        def parity_of(g, w_):
-            gm, wm = g["mask_pred"].cpu() > 0, w_["mask_pred"] > 0
-            inter = (gm & wm).flatten(1).sum(1).float()
-            union = (gm | wm).flatten(1).sum(1).float()
-            iou = torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
-            big = wm.flatten(1).sum(1) >= 64                     # a smaller mask's IoU moves in steps of >= 1/64 per flipped pixel
-            return {"mask_iou_mean": round(float(iou.mean()), 5), "mask_iou_min": round(float(iou.min()), 5),
-                    "mask_iou_mean_area_ge_64": round(float(iou[big].mean()), 6) if bool(big.any()) else None, "ref_masks_lt_64px": int((~big).sum()),
-                    "mask_iou_pooled": round(float(inter.sum() / union.sum().clamp(min=1)), 6), "flipped_mask_pixels": int((gm != wm).sum()),
-                    "mask_logit_rel_err": float(f"{((g['mask_pred'].cpu() - w_['mask_pred']).abs().max() / w_['mask_pred'].abs().max()).item():.3e}"),
-                    "mask_pixel_agreement": round(float((gm == wm).float().mean()), 6),
-                    "semantic_argmax_agreement": round(float((g["sem_seg"].argmax(0).cpu() == w_["sem_seg"].argmax(0)).float().mean()), 6),
-                    "panoptic_id_agreement": round(float((g["panoptic_seg"][0].cpu() == w_["panoptic_seg"][0]).float().mean()), 6),
-                    "panoptic_segments": [len(g["panoptic_seg"][1]), len(w_["panoptic_seg"][1])]}
-        def at_bar(p_):
-            """North-star bar on ONE image: mask IoU within 1e-3 and argmax-identical labels (>= 99.9 %).  The IoU statistic is the pooled IoU
-            over all queries and the mean over reference masks of >= 64 pixels -- NOT the plain mean over the 100 queries: random weights
-            give a handful of masks of a few pixels per image, and one flipped pixel in a 4-pixel mask is IoU 0.75 for that query and
-            0.9975 for the plain mean (r03h, three-product arithmetic, inputs seed 1: 2 flipped pixels in the whole image).  The plain
-            mean is reported next to it (`meets_bar_plain_mean`)."""
-            big = p_["mask_iou_mean_area_ge_64"]
-            return bool(p_["mask_iou_pooled"] >= 0.999 and (big is None or big >= 0.999) and p_["semantic_argmax_agreement"] >= 0.999)
-        def at_plain(p_):
-            return bool(p_["mask_iou_mean"] >= 0.999 and p_["semantic_argmax_agreement"] >= 0.999)
-        parity = parity_of(out[0], want[0])
-        parity["meets_bar_pooled"] = at_bar(parity)
-        parity["meets_bar_plain_mean"] = at_plain(parity)
+        # ---- parity gate, version 4 (oracle/parity_gate.py: definitions, the flip-margin property, the knife-edge list)
+        from oracle import parity_gate as PG
+
+        def judged(g_, w_, seed_):
+            p_ = PG.parity_of(g_, w_)
+            PG.judge(p_, g_, w_, PG.knife_edge_entry("panoptic", args.size, seed_, 0))
+            return dict(p_, inputs_seed=seed_)
+        parity = judged(out[0], want[0], rank)
         # ... and over more inputs (same weights, other seeded images / prompts): one image is a noisy gate -- 0.3 % positive pixels, ~10
         # empty reference masks, masks of a few pixels whose IoU moves in steps of 1/area (VERDICT r02 weak #1).  min / max over the seeds.
-        per_seed = [dict(parity, inputs_seed=rank)]
+        per_seed = [dict(parity)]
         wants = {rank: want[0]}
         if args.parity_seeds > 1 and not args.eager:
             for s_ in range(1, args.parity_seeds):
@@ -480,23 +563,30 @@ def main():
                 pin["images"] = pin["images"].cuda()
                 g_s = model.eval_seg(**pin)[0]
                 torch.cuda.synchronize()
-                per_seed.append(dict(parity_of(g_s, w_s), inputs_seed=rank + s_))
+                per_seed.append(judged(g_s, w_s, rank + s_))
             parity["seeds"] = {"n": len(per_seed), "inputs_seeds": [p_["inputs_seed"] for p_ in per_seed],
                                "mask_iou_mean_min": min(p_["mask_iou_mean"] for p_ in per_seed),
                                "mask_iou_pooled_min": min(p_["mask_iou_pooled"] for p_ in per_seed),
                                "mask_iou_mean_area_ge_64_min": min((p_["mask_iou_mean_area_ge_64"] for p_ in per_seed if p_["mask_iou_mean_area_ge_64"] is not None), default=None),
                                "mask_logit_rel_err_max": max(p_["mask_logit_rel_err"] for p_ in per_seed),
+                               "flip_margin_rel_max": max(p_["flip_margin_rel_max"] for p_ in per_seed),
                                "semantic_argmax_agreement_min": min(p_["semantic_argmax_agreement"] for p_ in per_seed),
                                "panoptic_id_agreement_min": min(p_["panoptic_id_agreement"] for p_ in per_seed),
                                "flipped_mask_pixels_max": max(p_["flipped_mask_pixels"] for p_ in per_seed), "per_seed": per_seed}
-            parity["meets_bar_pooled"] = all(at_bar(p_) for p_ in per_seed)
-            parity["meets_bar_plain_mean"] = all(at_plain(p_) for p_ in per_seed)
+        parity["meets_bar_pooled"] = all(p_["meets_bar_pooled"] for p_ in per_seed)
+        parity["meets_bar_plain_mean"] = all(p_["meets_bar_plain_mean"] for p_ in per_seed)
+        parity["flips_within_margin"] = all(p_["flips_within_margin"] for p_ in per_seed)
+        parity["meets_north_star_bar"] = all(p_["passes_gate"] for p_ in per_seed)
+        small = [p_["inputs_seed"] for p_ in per_seed if p_["flips_within_margin"] and not p_["meets_bar_plain_mean"]]
+        if small:
+            parity["note"] = (f"inputs {small}: every differing pixel is within the flip margin of the oracle's threshold, the plain mean over the 100 queries is "
+                              "below 0.999 because a reference mask of a few pixels quantises its IoU in steps of 1 / area")
+        parity["gate"] = PG.GATE
         side_fp32 = None
-        ctrl_ok = None
         if not args.no_side_modes and args.precision == "f16x3":
-            # side line AND control: the exact-fp32 GPU mode (fp32 MFMA GEMMs -- the reference's arithmetic width in another summation order) on
-            # the same inputs: its throughput, and per seed how far an input moves under re-ordering alone (the floor any re-implementation
-            # sits on).  `no_worse_than_fp32_control` ties the default arithmetic's verdict to that floor.
+            # side line, reported as information (NOT part of any pass / fail decision since gate version 4): the exact-fp32 GPU mode (fp32
+            # MFMA GEMMs -- the reference's arithmetic width in another summation order) on the same inputs: its throughput, and per seed how
+            # far an input moves under re-ordering alone (the floor any re-implementation sits on).
             try:
                 m32 = PSALM(cfg, sd, precision="fp32", use_graphs=not args.eager)
                 m32.graph_outputs = "alias"
@@ -512,22 +602,18 @@ def main():
                 for sd_, w_s in wants.items():
                     pin = make_inputs(cfg, "panoptic", size=args.size, batch=1, seed=sd_)
                     pin["images"] = pin["images"].cuda()
-                    p32 = parity_of(m32.eval_seg(**pin)[0], w_s)
+                    ctrl.append(judged(m32.eval_seg(**pin)[0], w_s, sd_))
                     torch.cuda.synchronize()
-                    ctrl.append(dict(p32, inputs_seed=sd_, meets_bar_pooled=at_bar(p32), meets_bar_plain_mean=at_plain(p32)))
-                ctrl_ok = bool(sum(not at_plain(p_) for p_ in per_seed) <= sum(not c_["meets_bar_plain_mean"] for c_ in ctrl) and
-                               sum(not at_bar(p_) for p_ in per_seed) <= sum(not c_["meets_bar_pooled"] for c_ in ctrl))
                 side_fp32 = {"value": round(args.steps / t32, 3), "unit": "images/s", "ms_per_step": round(t32 / args.steps * 1e3, 3),
                              "parity_vs_cpu_oracle": {"n": len(ctrl), "meets_bar_pooled": all(c_["meets_bar_pooled"] for c_ in ctrl),
-                                                      "meets_bar_plain_mean": all(c_["meets_bar_plain_mean"] for c_ in ctrl), "per_seed": ctrl},
-                             "note": "exact-fp32 MFMA GEMMs + fp32 attention: the reference's own arithmetic width; side line and noise-floor control"}
+                                                      "meets_bar_plain_mean": all(c_["meets_bar_plain_mean"] for c_ in ctrl),
+                                                      "flips_within_margin": all(c_["flips_within_margin"] for c_ in ctrl), "per_seed": ctrl},
+                             "note": "exact-fp32 MFMA GEMMs + fp32 attention: the reference's own arithmetic width in another summation order; side line, "
+                                     "information only"}
                 del m32, o32
                 torch.cuda.empty_cache()
             except Exception as ex:  # noqa: BLE001  (auxiliary leg)
                 side_fp32 = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-        parity["no_worse_than_fp32_control"] = ctrl_ok
-        parity["meets_north_star_bar"] = bool(parity["meets_bar_pooled"] and ctrl_ok is not False)
-        parity["gate"] = GATE
         if not args.no_side_modes and args.precision != "bf16":
             try:
                 # side line: the bf16 fast mode on the same image (NOT `value`: it does not meet the parity bar on this network)
@@ -543,9 +629,8 @@ def main():
                     ob = mb.eval_seg(**inputs)
                 torch.cuda.synchronize()
                 tb = time.perf_counter() - t1
-                pb = parity_of(ob[0], want[0])
+                pb = PG.parity_of(ob[0], want[0])
                 pb["n"] = 1
-                pb["meets_bar_pooled"], pb["meets_bar_plain_mean"] = at_bar(pb), at_plain(pb)
                 side = {"bf16": {"value": round(args.steps / tb, 3), "unit": "images/s", "ms_per_step": round(tb / args.steps * 1e3, 3),
                                  "parity_vs_cpu_oracle": pb}}
             except Exception as ex:  # noqa: BLE001  (auxiliary leg)
@@ -559,13 +644,17 @@ def main():
             "gpu_ms_per_step": round(gpu_ms, 3) if gpu_ms is not None else None,
             "host_ms_per_step": round(dt / args.steps * 1e3 - gpu_ms, 3) if gpu_ms is not None else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
-                                   "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing",
+            "config": {"workload": (f"BASELINE.json configs[1]: COCO-panoptic {args.size}x{args.size} batch=1 per GPU, PSALM (Swin-B + Phi-1.5 24L + Mask2Former head), "
+                                    "134 class prompts, 100 queries, full semantic+instance+panoptic post-processing") if not emu else
+                                   f"TEST MODE: the tiny architecture at {args.size}x{args.size} on host-emulated kernels (launcher / collective path only)",
                        "arithmetic": ("GEMMs in split-f16 (22-bit operands as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulate)"
                                       "; fp32 norms / softmax / attention") if args.precision == "f16x3" else args.precision,
                        "parallelism": f"image-sharded x{world} (replicated weights, RCCL broadcast at init)",
                        "launch": "eager" if args.eager else "hipGraph replay (one graph per input signature)"},
-            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity, "other_modes": ({**(side or {}), **({"fp32": side_fp32} if side_fp32 else {})} or None), "two_in_flight": inflight,
+            "roofline": roof, "cpu_baseline": cpu, "parity_vs_cpu_oracle": parity,
+            "other_modes": ({**(side or {}), **({"fp32": side_fp32} if side_fp32 else {}), **({"varied": varied} if varied else {})} or None), "two_in_flight": inflight,
+            "graph": dict(model_graph_stats, tail_in_graph=bool(args.graph_tail)) if model_graph_stats else None,
+            **({"emu": True, "backend": "gloo" if use_dist else None} if emu else {}),
             "weight_broadcast": bcast,
             "per_rank_images_per_s": ({"min": round(min(per_rank), 3), "max": round(max(per_rank), 3)} if per_rank else None),
         }

@@ -17,10 +17,11 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
-def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple[int, float]:
-    """Broadcast every prepared weight tensor of `model.w` from `src`, packed per dtype into flat buckets of up to
-    `bucket_bytes` (few, large messages: xGMI links are per-link bound, so bucket size >> latency*bandwidth).
-    Returns (bytes moved, seconds)."""
+def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30, direct_bytes: int = 32 << 20) -> Tuple[int, float]:
+    """Broadcast every prepared weight tensor of `model.w` from `src`.  Tensors of >= `direct_bytes` (the 96 Phi / Swin matrices that
+    make up ~95 % of the arena: 117 MB per fused Phi matrix in split-f16 form) are broadcast IN PLACE -- already large messages, no
+    staging copy; the many small ones (biases, norms, tables, scales) are packed per dtype into flat buckets of up to `bucket_bytes`
+    (few, large messages: xGMI links are per-link bound, so message size >> latency * bandwidth).  Returns (bytes moved, seconds)."""
     t0 = time.perf_counter()
     total = 0
     by_dtype = {}
@@ -35,7 +36,12 @@ def broadcast_weights(model, src: int = 0, bucket_bytes: int = 1 << 30) -> Tuple
         w = W
     model = _M
     for k in sorted(model.w):
-        by_dtype.setdefault(model.w[k].dtype, []).append(k)
+        t = model.w[k]
+        if t.numel() * t.element_size() >= direct_bytes and t.is_contiguous():
+            dist.broadcast(t, src=src)                       # in place: no torch.cat staging copy, no copy back
+            total += t.numel() * t.element_size()
+            continue
+        by_dtype.setdefault(t.dtype, []).append(k)
     for dt, keys in by_dtype.items():
         bucket, size = [], 0
         esz = torch.empty((), dtype=dt).element_size()

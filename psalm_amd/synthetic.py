@@ -232,14 +232,35 @@ class RegionInstances:
             self.vp_region_masks = RegionInstances._T(vp_region_masks)
 
 
+# (height, width) of COCO val2017-like originals: the common 4:3 / 3:2 landscape and portrait sizes, a square, a panorama, a small one
+COCO_LIKE_SIZES = [(480, 640), (640, 480), (427, 640), (640, 427), (426, 640), (375, 500), (500, 375), (480, 640), (640, 640),
+                   (333, 500), (612, 612), (360, 640), (640, 360), (428, 640), (500, 333), (240, 320)]
+
+
+def resized_box(height: int, width: int, size: int):
+    """Extent (rows, cols) of an original (height, width) image after the reference's eval transform T.ResizeShortestEdge(short_edge_length=size,
+    max_size=size) (coco_panoptic_mapper.py:81-86; detectron2's rounding: scale the short edge to `size`, re-scale if the long edge then
+    exceeds max_size, int(x + 0.5)) -- the un-padded box that T.FixedSizeCrop then pads to (size, size) at the bottom / right."""
+    scale = size / min(height, width)
+    nh, nw = (size, scale * width) if height < width else (scale * height, size)
+    if max(nh, nw) > size:
+        sc = size / max(nh, nw)
+        nh, nw = nh * sc, nw * sc
+    return int(nh + 0.5), int(nw + 0.5)
+
+
 def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batch: int = 1, seed: int = 0,
-                num_classes: int = 133, pad: Optional[int] = None, video: bool = False) -> dict:
+                num_classes: int = 133, pad: Optional[int] = None, video: bool = False, geometry=None, refer_lens=None) -> dict:
     """Keyword dict for `eval_seg(**inputs)`.
 
     panoptic : [txt.. <image> txt..] + C x [<cls> ,] + [txt.. <seg> txt]   (train_datasets.py:208-217)
     referring: [.. <image> .. <refer> .. <seg> ..]                          (train_datasets.py:644-695)
     region   : [.. <image> .. k x <region> .. <seg> ..]                     (train_datasets.py:307-354)
     `pad`: number of bottom/right padded pixels flagged in `padding_mask` (None -> 0).
+    `geometry`: per image (crop_h, crop_w, height, width) -- the un-padded box inside the (size, size) canvas (`padding_mask` False there,
+    pixels outside it zero as T.FixedSizeCrop leaves them after normalisation of its pad value) and the ORIGINAL image size the results
+    are resized to (`seg_info[i]["height" / "width"]`, LP:1416-1429); overrides `pad`.
+    `refer_lens`: referring task, tokens per sentence for each image (default: a fixed cycle of lengths).
     """
     g = torch.Generator(device="cpu")
     g.manual_seed(1000 + seed)
@@ -252,6 +273,14 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
         if pad:
             pm[size - pad:, :] = True
             pm[:, size - pad:] = True
+        if geometry is not None:
+            oh, ow, gh, gw = geometry[b % len(geometry)]
+            pm[oh:, :] = True
+            pm[:, ow:] = True
+            images[b, :, oh:, :] = 0
+            images[b, :, :, ow:] = 0
+            seg_info.append({"padding_mask": pm, "height": int(gh), "width": int(gw)})
+            continue
         seg_info.append({"padding_mask": pm, "height": size - pad, "width": size - pad})
 
     def txt(n):
@@ -281,7 +310,7 @@ def make_inputs(cfg: PsalmConfig, task: str = "panoptic", size: int = 1024, batc
         for b in range(batch):
             ids = txt(4 + b) + [IMAGE_TOKEN_INDEX] + txt(3) + [REFER_TOKEN_INDEX] + txt(2) + [SEG_TOKEN_INDEX] + txt(1)
             ids_list.append(ids)
-            refer.append(torch.tensor(txt(lens[b % len(lens)]) + [V], dtype=torch.int64))
+            refer.append(torch.tensor(txt(refer_lens[b % len(refer_lens)] if refer_lens else lens[b % len(lens)]) + [V], dtype=torch.int64))
         out["token_refer_id"] = refer
     elif task == "region":
         for b in range(batch):
