@@ -587,8 +587,8 @@ __global__ void __launch_bounds__(64 * NW) causal_attention_f32_mfma_kernel(cons
 __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __restrict__ base, long ld, int q_off, int k_off,
                                                                 const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                                 const unsigned char* __restrict__ key_mask, float* __restrict__ Qr,
-                                                                float* __restrict__ Kr, unsigned char* __restrict__ Mk, int L, int Lp, int heads,
-                                                                float scale) {
+                                                                float* __restrict__ Kr, unsigned char* __restrict__ Mk,
+                                                                unsigned char* __restrict__ Tk, int L, int Lp, int heads, float scale) {
     constexpr int HD = 64, ROT = 32, half = 16;
     const int h = blockIdx.y, b = blockIdx.z;
     const int t = blockIdx.x * 32 + (threadIdx.x >> 3), c0 = (threadIdx.x & 7) * 8;     // token, 8-wide head-dim chunk
@@ -596,6 +596,11 @@ __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __r
     float* qd = Qr + (((long)b * heads + h) * Lp + t) * HD + c0;
     float* kd = Kr + (((long)b * heads + h) * Lp + t) * HD + c0;
     if (h == 0 && c0 == 0) Mk[(long)b * Lp + t] = t < L ? (key_mask[(long)b * L + t] ? 1 : 0) : 0;
+    if (h == 0 && threadIdx.x == 0) {                   // Tk[b][tile]: every key of this 32-key tile is a real, un-masked token (r05: such a tile
+        bool all = true;                                 // below the diagonal needs no per-element mask work in the attention kernel)
+        for (int i = 0; i < 32; ++i) { const int tt = blockIdx.x * 32 + i; all = all && tt < L && key_mask[(long)b * L + tt] != 0; }
+        Tk[(long)b * (Lp / 32) + blockIdx.x] = all ? 1 : 0;
+    }
     float q[8], k[8];
     if (t < L) {
         const float* p = base + ((long)b * L + t) * ld;
@@ -632,10 +637,10 @@ __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __r
 // waves 52 % issue-stalled behind the partner wave's products, 31 % in s_waitcnt -- profiles/r02n_attn_*).
 // PSALM_WAVES_PER_EU(2): 138 instead of 135 + 48 accumulation registers -> 3 resident waves per SIMD (r02n: 80.4 -> 75.0 us unpaired).
 template <bool SO>
-__global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(2)
+__global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(3)
 causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr, const unsigned char* __restrict__ Mk,
-                                   const float* __restrict__ base, long ld, int v_off, float* out, long ldo, int o_off, int L, int Lp,
-                                   int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
+                                   const unsigned char* __restrict__ Tk, const float* __restrict__ base, long ld, int v_off, float* out, long ldo,
+                                   int o_off, int L, int Lp, int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
@@ -662,27 +667,37 @@ causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m = -3.0e38f, l = 0.f;
-    const float* vbase = base + (long)b * L * ld + v_off + h * HD + n32;
-    for (int kt = w0; kt <= qt; kt += 4) {                                // key tiles 0..qt (the diagonal tile is qt)
-        // ---- fragments of this tile, all loads issued up front (rows clamped: padded keys are masked below)
+    // r05: every fragment fetch goes through a buffer descriptor -- a per-lane offset that never changes (one VGPR, set up once) + a
+    // wave-uniform offset in an SGPR that walks the key tiles.  The pointer form computed a 64-bit address per V row on the vector ALU:
+    // 134 of the loop's 326 VALU instructions, 48 of them quarter-rate integer multiplies (ISA of r04: 32 v_mul_lo_u32 + 16 v_mad_u64_u32 per
+    // key tile).  Rows >= L of V (the padding of the last tile; the pointer form clamped them to row L - 1) read as zeros: their
+    // probabilities are zeros either way.
+    const psalm_rsrc vrs = psalm_make_rsrc(base + (long)b * L * ld + v_off + h * HD, (unsigned)((((long)L - 1) * ld + HD) * 4));
+    const unsigned vvo = (unsigned)((4L * hi * ld + n32) * 4);            // lane: key 4 hi of a group of 8, head dim n32 (+32: second d-tile)
+    const unsigned vrow = (unsigned)(ld * 4);
+    const psalm_rsrc krs = psalm_make_rsrc(Kr + bh * Lp * HD, (unsigned)((long)Lp * HD * 4));
+    const unsigned kvo = (unsigned)((n32 * HD + 32 * hi) * 4);
+    const int nkt = Lp / 32;
+    for (int kt = __builtin_amdgcn_readfirstlane(w0); kt <= qt; kt += 4) {                                // key tiles 0..qt (the diagonal tile is qt)
+        // ---- fragments of this tile, all loads issued up front
         psalm_f32x4 kf[8];
-        {
-            const float* kp = Kr + (bh * Lp + kt * 32 + n32) * HD + 32 * hi;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) kf[c] = reinterpret_cast<const psalm_f32x4*>(kp)[c];
+        for (int c = 0; c < 8; ++c) {
+            const psalm_u32x4 t = psalm_buf_load_b128_s(krs, kvo + 16u * c, (unsigned)(kt * 32 * HD * 4));
+            kf[c] = psalm_f32x4{__builtin_bit_cast(float, t.x), __builtin_bit_cast(float, t.y), __builtin_bit_cast(float, t.z), __builtin_bit_cast(float, t.w)};
         }
         float va[16], vb[16];                                             // V^T fragments: step r = 4g + i contracts key 8g + 4hi + i
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float* vp = vbase + (long)min(kt * 32 + 8 * g + 4 * hi + i, L - 1) * ld;
-                va[4 * g + i] = vp[0];
-                vb[4 * g + i] = vp[32];
+                const unsigned so_ = (unsigned)(kt * 32 + 8 * g + i) * vrow;
+                va[4 * g + i] = psalm_buf_load_f32_s(vrs, vvo, so_);
+                vb[4 * g + i] = psalm_buf_load_f32_s(vrs, vvo + 128u, so_);
             }
-        unsigned mw[4];                                                   // key-valid bytes of keys 8g + 4hi .. +3
-#pragma unroll
-        for (int g = 0; g < 4; ++g) mw[g] = *reinterpret_cast<const unsigned*>(Mk + (long)b * Lp + kt * 32 + 8 * g + 4 * hi);
+        // a tile below the diagonal whose 32 keys are all real tokens (Tk, written by the pre-pass) needs no mask: the causal and key-mask
+        // tests pass for every element, so the selects below would all take their first operand -- same values, ~90 VALU instructions less
+        const bool plain = __builtin_amdgcn_readfirstlane((int)(kt < qt && Tk[(long)b * nkt + kt] != 0)) != 0;       // (wave-uniform)
         // ---- S^T = K . Q^T
         f32x16 sacc;
 #pragma unroll
@@ -694,23 +709,39 @@ causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].z, qv[4 * c + 2], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c].w, qv[4 * c + 3], sacc, 0, 0, 0);
         }
-        float mc = -3.0e38f;
+        float mc = -3.0e38f, mn, alpha, psum = 0.f;
+        if (plain) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool ok = (kt * 32 + j <= qi) && ((mw[r >> 2] >> (8 * (r & 3))) & 0xffu);
-            sacc[r] = ok ? sacc[r] : -3.0e38f;
-            mc = fmaxf(mc, sacc[r]);
-        }
-        mc = fmaxf(mc, __shfl_xor(mc, 32));
-        const float mn = fmaxf(m, mc);
-        const float alpha = __expf(m - mn);
-        float psum = 0.f;
+            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, sacc[r]);
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            mn = fmaxf(m, mc);
+            alpha = __expf(m - mn);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
-            sacc[r] = p;
-            psum += p;
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(sacc[r] - mn);
+                sacc[r] = p;
+                psum += p;
+            }
+        } else {
+            unsigned mw[4];                                               // key-valid bytes of keys 8g + 4hi .. +3
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mw[g] = *reinterpret_cast<const unsigned*>(Mk + (long)b * Lp + kt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = (kt * 32 + j <= qi) && ((mw[r >> 2] >> (8 * (r & 3))) & 0xffu);
+                sacc[r] = ok ? sacc[r] : -3.0e38f;
+                mc = fmaxf(mc, sacc[r]);
+            }
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            mn = fmaxf(m, mc);
+            alpha = __expf(m - mn);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = sacc[r] > -1.0e38f ? __expf(sacc[r] - mn) : 0.f;
+                sacc[r] = p;
+                psum += p;
+            }
         }
         psum += __shfl_xor(psum, 32);
         l = l * alpha + psum;
@@ -780,7 +811,7 @@ causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __
 
 extern "C" long psalm_causal_attention_f32_workspace(int B, int L, int heads) {
     const long Lp = (L + 31) / 32 * 32;
-    return 2L * B * heads * Lp * 64 * (long)sizeof(float) + (long)B * Lp + 64;
+    return 2L * B * heads * Lp * 64 * (long)sizeof(float) + (long)B * Lp + (long)B * (Lp / 32) + 64;
 }
 
 // Phi prefill attention for fp32 buffers, same operands as psalm_causal_attention + a workspace of psalm_causal_attention_f32_workspace
@@ -799,19 +830,21 @@ static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k
     float* Qr = (float*)workspace;
     float* Kr = Qr + (long)B * heads * Lp * 64;
     unsigned char* Mk = (unsigned char*)(Kr + (long)B * heads * Lp * 64);
+    unsigned char* Tk = Mk + (long)B * Lp;                                 // per 32-key tile: all keys real and un-masked
+    PSALM_CHECK_ARG(((long)L - 1) * ld * 4 + 256 < 0x7fffffffL, "psalm_causal_attention_f32: L * ld * 4 must stay below 2 GiB (buffer-descriptor fetches)");
     const float scale = 1.0f / sqrtf((float)head_dim);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phi_rope_prep_f32_kernel, dim3(Lp / 32, heads, B), dim3(256), 0, s, qkv, ld, q_off, k_off, cos_table, sin_table, key_mask,
-                       Qr, Kr, Mk, L, Lp, heads, scale);
+                       Qr, Kr, Mk, Tk, L, Lp, heads, scale);
     const int pair = 1;                                                   // balanced pairs of query tiles per block (r02n; the one-tile form stays in the kernel)
     const int nqt = Lp / 32;
     const dim3 grid(pair ? (nqt + 1) / 2 : nqt, heads, B);
     if (so_inv)
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
+                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
     else
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
+                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
     PSALM_LAUNCH_END(name);
 }
 extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,

@@ -131,6 +131,9 @@ __device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128(psalm_rsrc r, unsigne
 }
 __device__ __forceinline__ void psalm_buf_store_f32_s(float v, psalm_rsrc r, unsigned voff, unsigned soff) { if (voff < PSALM_BUF_OOB) psalm_buf_store_f32(v, r, voff + soff); }
 __device__ __forceinline__ float psalm_buf_load_f32_s(psalm_rsrc r, unsigned voff, unsigned soff) { return voff < PSALM_BUF_OOB ? psalm_buf_load_f32(r, voff + soff) : 0.f; }
+__device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128_s(psalm_rsrc r, unsigned voff, unsigned soff) {
+    return voff < PSALM_BUF_OOB ? psalm_buf_load_b128(r, voff + soff) : psalm_u32x4{0u, 0u, 0u, 0u};
+}
 #else
 __device__ __forceinline__ unsigned psalm_swap_adjacent(unsigned v) {                              // DPP quad_perm [1,0,3,2]: no LDS crossbar
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
@@ -164,6 +167,10 @@ __device__ __forceinline__ void psalm_buf_store_f32_s(float v, psalm_rsrc r, uns
 }
 __device__ __forceinline__ float psalm_buf_load_f32_s(psalm_rsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128_s(psalm_rsrc r, unsigned voff, unsigned soff) {
+    const psalm_u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return psalm_u32x4{v.x, v.y, v.z, v.w};
 }
 #endif
 

@@ -1695,7 +1695,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
     if (bm >= 2580 && bm <= 2582) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices / (experiment) slices, all-padding m-tiles left out
-    if (bm >= 3300 && bm <= 3305) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles
+    if (bm >= 3300 && bm <= 3308) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles (7 / 8: r05 ring depths)
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
     g_tile_policy = bm;
@@ -1786,6 +1786,11 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
     int slice = !x3 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
+    // r05 ring depths (one block per CU by LDS: for grids that put <= 1 block on a CU anyway, the stages that a second block would have used
+    // buy prefetch distance instead): 7 = 64 x 128, 64-deep slices, 3 stages (144 KB);  8 = 128 x 128, 32-deep slices, 3 stages (96 KB)
+    if (slice == 7 && BM != 64) slice = 3;
+    if (slice == 8 && BM != 128) slice = 3;
+    if ((slice == 7 || slice == 8) && fa.so) slice = 3;
     if (x3 && BM == 256 && g_ph8 && g_ph8_slice) {        // 256 x 256: the phased loop on 32-deep slices (form 6) when every K slice of the grid has >= 2 of them
         const int kp_ = fa.x3_kp, kps_ = splits > 1 ? cdiv(cdiv(kp_, 64), splits) * 64 : kp_, sp_ = cdiv(kp_, kps_);
         if (kps_ >= 64 && kp_ - (sp_ - 1) * kps_ >= 64) slice = 6;
@@ -1843,10 +1848,12 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (slice == 3 && fa.so && fa.so_paired) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);
+        else if (BM == 128 && slice == 8) GO(256, "float", float, 128, 128, 2, 2, 3, false, 32, 0, 2, false);
         else if (BM == 128 && slice >= 3) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, false);
         else if (slice == 3 && fa.so) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true);
         else if (slice == 3) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, false);
         else if (slice == 4) GO(256, "float", float, 64, 128, 2, 2, 3, false, 32, 0, 2, false);
+        else if (slice == 7) GO(256, "float", float, 64, 128, 2, 2, 3, false, 64, 0, 2, false);
         else if (BM == 128 && slice == 2) GO(256, "float", float, 128, 128, 2, 2, 4, false, 32, 0, 2, false);
         else if (BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 2, false);
         else if (slice == 2) GO(256, "float", float, 64, 128, 2, 2, 4, false, 32, 0, 2, false);

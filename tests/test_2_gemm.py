@@ -282,7 +282,9 @@ X3_CASES = [
 
 # K loop forms: 3300 automatic (32-deep slices, 2 stages = 3303) on every case; the others (3301 64-deep slices, 3302 / 3304 deeper rings, 3305 K panel)
 # on the tiled (policy != 0) cases
-X3_PARAMS = [c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302, 3304, 3305)]
+# (r05: 3307 = 64 x 128 tiles, 64-deep slices, 3 stages; 3308 = 128 x 128 tiles, 32-deep slices, 3 stages -- each on its own tile height)
+X3_PARAMS = ([c + (3300,) for c in X3_CASES] + [c + (k,) for c in X3_CASES if c[6] in (128, 64) for k in (3301, 3302, 3304, 3305)] +
+             [c + (3307 if c[6] == 64 else 3308,) for c in X3_CASES if c[6] in (128, 64)])
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,has_res,act,policy,kloop", X3_PARAMS)

@@ -11,14 +11,28 @@ SHAPES = [(899, 14336, 2048), (899, 2048, 10240), (4096, 2048, 512), (4096, 512,
           (1024, 4096, 1024), (100, 65536, 256), (65536, 256, 2304),
           (21504, 288, 256), (1296, 3072, 1024), (17424, 768, 256), (69696, 384, 128), (256, 2048, 18432), (1024, 1024, 4096)]
 # 3301 / 3302: slice forms with one block per CU (r02l: lose); 3303 / 3304: 32-deep slices in a 2- / 3-deep ring (the K-panel form's LDS footprint)
+# r05 (--ring): the ring depths that spend the LDS of a second resident block on prefetch distance: 3307 = 64 x 128, 64-deep slices, 3 stages
+# (144 KB); 3308 = 128 x 128, 32-deep slices, 3 stages (96 KB); 3302 = 32-deep slices, 4 stages
 POLICIES = [("auto", [0]), ("auto_s3", [3303]), ("t128", [128]), ("t128_s3", [128, 3303]), ("t64", [64]), ("t64_s3", [64, 3303]), ("t64_s4", [64, 3304]),
             ("t64_slice", [64, 3301]), ("t256", [256]), ("auto_ps", [2581]), ("t256_ps", [256, 2581])]     # _ps: 256 x 256 phased loop on 32-deep slices (r04)
+RING = [("auto", [0]), ("t64_k32n2", [64, 3303]), ("t64_k32n3", [64, 3304]), ("t64_k32n4", [64, 3302]), ("t64_k64n2", [64, 3301]), ("t64_k64n3", [64, 3307]),
+        ("t128_k32n2", [128, 3303]), ("t128_k32n3", [128, 3308]), ("t128_k32n4", [128, 3302]), ("t128_k64n2", [128, 3301])]
+RING_SHAPES = [(4096, 512, 2048), (4096, 2048, 512), (5184, 1536, 512), (5184, 512, 512), (21504, 1024, 256), (21504, 256, 1024), (21504, 256, 256),
+               (100, 65536, 256), (65536, 512, 128), (21504, 288, 256), (16384, 1024, 256), (69696, 384, 128), (1024, 1024, 4096), (1024, 4096, 1024),
+               (65536, 128, 512), (16384, 256, 1024), (17424, 768, 256), (1296, 3072, 1024), (16384, 768, 256), (1296, 1024, 1024), (256, 2048, 18432),
+               (65536, 256, 256), (69696, 128, 128), (17424, 256, 256), (4096, 512, 1024), (4096, 768, 256), (16384, 256, 512), (16384, 256, 256)]
 
 
 def main():
     ops = get_ops()
     out = {}
-    for M, N, K in SHAPES:
+    ring = "--ring" in sys.argv
+    if ring:
+        sys.argv.remove("--ring")
+    global POLICIES
+    if ring:
+        POLICIES = RING
+    for M, N, K in (RING_SHAPES if ring else SHAPES):
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda")
         asp, wsp = ops.split_f16(a), ops.split_f16(w)
@@ -32,7 +46,7 @@ def main():
                     ops.gemm_x3(asp, wsp, out=c)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                reps = 20
+                reps = 30
                 e0.record()
                 for _ in range(reps):
                     ops.gemm_x3(asp, wsp, out=c)
