@@ -104,12 +104,23 @@ __global__ void __launch_bounds__(256) mask_score_partial_kernel(const float* __
         partial[((long)q * nchunks + chunk) * 2 + 1] = sd[0] + sd[1] + sd[2] + sd[3];
     }
 }
-__global__ void mask_score_final_kernel(const float* __restrict__ partial, float* __restrict__ score, int Q, int nchunks) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per query: lane l sums the partials l, l + 64, ... in double, the 64 lane sums meet in a shuffle tree (r04: ONE thread per
+// query walked its 512 partials of the fused semantic pass in a chain of dependent loads -- 54 us for 100 KB; the sums are of <= 512 floats
+// of like magnitude in double, whose grouping does not reach the float result)
+__global__ void __launch_bounds__(64) mask_score_final_kernel(const float* __restrict__ partial, float* __restrict__ score, int Q, int nchunks) {
+    const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= Q) return;
     double num = 0.0, den = 0.0;
-    for (int k = 0; k < nchunks; ++k) { num += partial[((long)q * nchunks + k) * 2]; den += partial[((long)q * nchunks + k) * 2 + 1]; }
-    score[q] = (float)(num / (den + 1e-6));
+    for (int k = lane; k < nchunks; k += 64) { num += partial[((long)q * nchunks + k) * 2]; den += partial[((long)q * nchunks + k) * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long nb = __builtin_bit_cast(long long, num), db = __builtin_bit_cast(long long, den);
+        const int nlo = __shfl_xor((int)(nb & 0xffffffffll), o), nhi = __shfl_xor((int)(nb >> 32), o);
+        const int dlo = __shfl_xor((int)(db & 0xffffffffll), o), dhi = __shfl_xor((int)(db >> 32), o);
+        num += __builtin_bit_cast(double, ((long long)nhi << 32) | (long long)(unsigned)nlo);
+        den += __builtin_bit_cast(double, ((long long)dhi << 32) | (long long)(unsigned)dlo);
+    }
+    if (lane == 0) score[q] = (float)(num / (den + 1e-6));
 }
 
 // workspace: Q * 64 * 2 floats
@@ -117,7 +128,7 @@ extern "C" int psalm_mask_scores(const float* mask, float* score, float* workspa
     if (Q == 0) return 0;
     const int nchunks = 64;
     hipLaunchKernelGGL(mask_score_partial_kernel, dim3(nchunks, Q), dim3(256), 0, (hipStream_t)stream, mask, workspace, HW, nchunks);
-    hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, score, Q, nchunks);
+    hipLaunchKernelGGL(mask_score_final_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, workspace, score, Q, nchunks);
     PSALM_LAUNCH_END("psalm_mask_scores");
 }
 
@@ -561,7 +572,7 @@ extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* prob
             hipLaunchKernelGGL(semantic_from_masks_x3_pair_kernel<128>, dim3(grid2), dim3(512), 0, (hipStream_t)stream, mask, probsT_f32, out,
                                mask_score ? workspace : nullptr, Q, C, HW, nt64, order_env);
         if (mask_score)
-            hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, 2 * grid2);
+            hipLaunchKernelGGL(mask_score_final_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, 2 * grid2);
         PSALM_LAUNCH_END("psalm_semantic_from_masks_x3");
     }
     const int ntiles = (int)((HW + 127) / 128);
@@ -573,7 +584,7 @@ extern "C" int psalm_semantic_from_masks_x3(const float* mask, const float* prob
         hipLaunchKernelGGL(semantic_from_masks_x3_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, probsT_f32, out,
                            mask_score ? workspace : nullptr, Q, C, HW, ntiles);
     if (mask_score)
-        hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
+        hipLaunchKernelGGL(mask_score_final_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
     PSALM_LAUNCH_END("psalm_semantic_from_masks_x3");
 }
 
@@ -596,7 +607,7 @@ extern "C" int psalm_semantic_from_masks(const float* mask, const void* probsT_b
         hipLaunchKernelGGL(semantic_from_masks_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, (const bf16_t*)probsT_bf16,
                            out, mask_score ? workspace : nullptr, Q, C, HW, ntiles);
     if (mask_score)
-        hipLaunchKernelGGL(mask_score_final_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
+        hipLaunchKernelGGL(mask_score_final_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, workspace, mask_score, Q, grid);
     PSALM_LAUNCH_END("psalm_semantic_from_masks");
 }
 
@@ -641,20 +652,25 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned long long prefix = prefix_s;
+        const int rem0 = remaining_s;
         const unsigned long long himask = shift == 48 ? 0ull : (~0ull << (shift + 8));
         for (int i = tid; i < n; i += 1024) {
             const unsigned long long key = topk_key(value(i), i);
             if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
         }
         __syncthreads();
-        if (tid == 0) {                                               // walk the digits from the top: where does the k-th key fall
-            int rem = remaining_s, d = 255;
-            for (; d > 0; --d) {
-                if (hist[d] >= rem) break;
-                rem -= hist[d];
+        // Where does the k-th key fall: the digit d with  (keys above d) < rem <= (keys above d) + hist[d],  d = 0 if no digit >= 1 gets
+        // there.  Thread d sums the bins above its own -- independent LDS reads -- and the ONE thread whose digit matches publishes it
+        // (r04: thread 0 walked the 256 bins in a chain of dependent LDS reads, 7 times: about half of this kernel's 97 us).
+        if (tid < 256) {
+            int above = 0;
+#pragma unroll 8
+            for (int d = tid + 1; d < 256; ++d) above += hist[d];
+            const bool mine = tid == 0 ? above < rem0 : (above < rem0 && rem0 <= above + hist[tid]);
+            if (mine) {
+                remaining_s = rem0 - above;
+                prefix_s = prefix | ((unsigned long long)tid << shift);
             }
-            remaining_s = rem;
-            prefix_s = prefix | ((unsigned long long)d << shift);
         }
         __syncthreads();
     }
@@ -762,6 +778,80 @@ __global__ void __launch_bounds__(256) panoptic_argmax_kernel(const float* __res
         if (lc[i]) atomicAdd(&counts[i], lc[i]);
 }
 
+// ... the form the entry point launches when HW % 4 == 0 and the planes are 16-byte aligned (r05; the kernel above stays for the rest).
+// Same integers out -- the counts are sums of indicator values and the arg-max walks the kept queries in the same (ascending) order with
+// the same strict `>` -- from a loop the memory system can fill: the kept queries are compacted into an LDS list ONCE per block (the old
+// loop tested all Q per pixel and `continue`d), a thread owns 4 consecutive pixels (16-byte loads), the loads of 4 kept queries are issued
+// before the first is used, and the `sigmoid >= 0.5` area counts leave through one ballot + population count per wavefront and pixel
+// column instead of an LDS atomic per (pixel, query).  SQ counters of the old kernel (r04j): 86 % of the wavefront cycles parked.
+__global__ void __launch_bounds__(256) panoptic_argmax_vec4_kernel(const float* __restrict__ mask, const float* __restrict__ score,
+                                                                   const int* __restrict__ label, int* __restrict__ argq,
+                                                                   int* __restrict__ counts, int Q, long HW, int void_label, float thr) {
+    HIP_DYNAMIC_SHARED(int, sm)
+    int* lc = sm;                        // (Q,3) block-local counts
+    float* ksc = (float*)(sm + 3 * Q);   // kept scores, compacted
+    int* kq = sm + 4 * Q;                // their query indices (ascending)
+    __shared__ int nk_s;
+    for (int i = threadIdx.x; i < 3 * Q; i += 256) lc[i] = 0;
+    if (threadIdx.x == 0) {              // (Q <= a few hundred: a serial scan keeps the order without a prefix sum)
+        int n = 0;
+        for (int q = 0; q < Q; ++q)
+            if (label[q] != void_label && score[q] > thr) { ksc[n] = score[q]; kq[n] = q; ++n; }
+        nk_s = n;
+    }
+    __syncthreads();
+    const int nk = nk_s, lane = threadIdx.x & 63;
+    const long nquad = HW >> 2;
+    for (long pq = (long)blockIdx.x * 256 + threadIdx.x; pq - threadIdx.x < nquad; pq += (long)gridDim.x * 256) {
+        const bool live = pq < nquad;                                // (whole wavefronts stay in the loop: the ballots below need them)
+        const long p = (live ? pq : 0) << 2;
+        float best[4] = {-1.f, -1.f, -1.f, -1.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+        int bq[4] = {-1, -1, -1, -1};
+        for (int k0 = 0; k0 < nk; k0 += 4) {
+            psalm_f32x4 m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = kq[min(k0 + u, nk - 1)];
+                m4[u] = *reinterpret_cast<const psalm_f32x4*>(mask + (long)q * HW + p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= nk) break;                             // (block-uniform)
+                const int q = kq[k0 + u];
+                const float sc = ksc[k0 + u];
+                const float mv[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
+                int c1 = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s_ = sigmoidf_(mv[e]);
+                    const float v = sc * s_;
+                    c1 += __builtin_popcountll(__ballot(live && s_ >= 0.5f));
+                    if (v > best[e]) { best[e] = v; bq[e] = q; bs[e] = s_; }
+                }
+                if (lane == 0 && c1) atomicAdd(&lc[3 * q + 1], c1);
+            }
+        }
+        if (live) {
+            *reinterpret_cast<psalm_u32x4*>(argq + p) = psalm_u32x4{(unsigned)bq[0], (unsigned)bq[1], (unsigned)bq[2], (unsigned)bq[3]};
+            // the 4 pixels of a thread mostly share their winner: one LDS atomic per run of equal winners
+            int run_q = bq[0], run_a = 0, run_i = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (bq[e] != run_q) {
+                    if (run_q >= 0) { atomicAdd(&lc[3 * run_q + 0], run_a); if (run_i) atomicAdd(&lc[3 * run_q + 2], run_i); }
+                    run_q = bq[e]; run_a = 0; run_i = 0;
+                }
+                run_a += 1;
+                run_i += (bq[e] >= 0 && bs[e] >= 0.5f) ? 1 : 0;
+            }
+            if (run_q >= 0) { atomicAdd(&lc[3 * run_q + 0], run_a); if (run_i) atomicAdd(&lc[3 * run_q + 2], run_i); }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * Q; i += 256)
+        if (lc[i]) atomicAdd(&counts[i], lc[i]);
+}
+
 // stage b (one thread): the sequential merge; final_id[q] = segment id or 0; info (n,3) = (id, isthing, category)
 __global__ void panoptic_merge_kernel(const float* __restrict__ score, const int* __restrict__ label, const int* __restrict__ counts,
                                       const int* __restrict__ is_thing, int* __restrict__ final_id, int* __restrict__ info,
@@ -813,8 +903,14 @@ extern "C" int psalm_panoptic(const float* mask, const float* score, const int* 
     long gx = (HW + 255) / 256;
     const int grid = (int)(gx > 4096 ? 4096 : gx);
     const size_t shmem = (size_t)(3 * Q) * sizeof(int) + (size_t)Q * sizeof(float);
-    hipLaunchKernelGGL(panoptic_argmax_kernel, dim3(grid), dim3(256), shmem, s, mask, score, label, argq, counts, Q, HW, num_classes,
-                       obj_thr);
+    if (HW % 4 == 0 && (uintptr_t)mask % 16 == 0 && (uintptr_t)argq % 16 == 0) {
+        const long gq = (HW / 4 + 255) / 256;
+        hipLaunchKernelGGL(panoptic_argmax_vec4_kernel, dim3((unsigned)(gq > 4096 ? 4096 : gq)), dim3(256), (size_t)(5 * Q) * sizeof(int), s, mask, score,
+                           label, argq, counts, Q, HW, num_classes, obj_thr);
+    } else {
+        hipLaunchKernelGGL(panoptic_argmax_kernel, dim3(grid), dim3(256), shmem, s, mask, score, label, argq, counts, Q, HW, num_classes,
+                           obj_thr);
+    }
     hipLaunchKernelGGL(panoptic_merge_kernel, dim3(1), dim3(64), 0, s, score, label, counts, is_thing, final_id, info, ninfo, Q,
                        num_classes, obj_thr, overlap_thr, num_classes);
     hipLaunchKernelGGL(panoptic_write_kernel, dim3(grid), dim3(256), 0, s, mask, argq, final_id, pan, HW);

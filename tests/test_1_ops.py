@@ -577,3 +577,34 @@ def test_swin_split_emitting_kernels(ops, B, H, W, C, shift):
     h2s = ops.split_f16(h2)
     assert torch.equal(x1, x2)
     assert torch.equal(h1.t.cpu().view(torch.int16), h2s.t.cpu().view(torch.int16)) and torch.equal(h1.inv_scale.cpu(), h2s.inv_scale.cpu())
+
+
+@pytest.mark.parametrize("Q,C,Hh,Ww", [(100, 133, 96, 96), (24, 9, 37, 41), (100, 133, 64, 100), (16, 5, 20, 12)])
+def test_panoptic_matches_oracle_inference(ops, Q, C, Hh, Ww):
+    """psalm_panoptic (class_name_panoptic_inference, llava_phi.py:325-386) on blobs that survive the score / overlap tests, against the
+    oracle's restatement: identical id map and segments_info.  H * W % 4 == 0 takes the 4-pixels-per-thread arg-max kernel (r05), the
+    odd sizes the one-pixel form -- the two must agree with each other through the oracle."""
+    from oracle import psalm_oracle as O
+    g = torch.Generator().manual_seed(Q + Hh * Ww)
+    yy, xx = torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij")
+    mask = torch.randn(Q, Hh, Ww, generator=g) * 0.7 - 5.0
+    for q in range(Q):
+        if q % 3 == 2:
+            continue                                                   # a third of the queries: empty masks
+        cy, cx = int(torch.randint(0, Hh, (1,), generator=g)), int(torch.randint(0, Ww, (1,), generator=g))
+        r = int(torch.randint(1, max(2, min(Hh, Ww) // 12), (1,), generator=g))
+        mask[q][((yy - cy).abs() <= r) & ((xx - cx).abs() <= r)] += 9.0
+    mask[:, 0, :3] = 0.0                                                # sigmoid == 0.5 exactly: the >= 0.5 tests on the boundary
+    cls = torch.randn(Q, C + 1, generator=g)
+    hot = torch.randint(0, C + 1, (Q,), generator=g)
+    cls[torch.arange(Q), hot] += torch.where(torch.rand(Q, generator=g) < 0.7, 8.0, 1.0)      # ~70 % confident queries, some of them void
+    thing = [int(v) for v in (torch.rand(C, generator=g) < 0.6)]
+    want_pan, want_info = O.panoptic_inference(cls, mask, thing)
+    d = ops.device
+    probs, probsT, score, label = ops.class_softmax(cls.to(d), (Q + 63) // 64 * 64)
+    pan, info, ninfo = ops.panoptic(mask.to(d).contiguous(), score, label, torch.tensor(thing, dtype=torch.int32, device=d), C, 0.8, 0.8)
+    n = int(ninfo.item())
+    got_info = [{"id": a, "isthing": bool(b), "category_id": c} for a, b, c in info.cpu()[:n].tolist()]
+    assert len(want_info) >= (3 if Q >= 24 else 1)                      # the case exercises the merge
+    assert got_info == want_info
+    assert torch.equal(pan.cpu(), want_pan)
