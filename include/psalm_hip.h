@@ -26,8 +26,9 @@ const char* psalm_last_error(void);
 /* Version of this binary interface: bumped whenever an entry point's arguments change.  A binding MUST compare it with the constant it was
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
- * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone). */
-#define PSALM_ABI_VERSION 5
+ * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
+ * 6: psalm_gemm_x3_set_products (r05); psalm_causal_attention_f32_workspace grew by one byte per 32-key tile. */
+#define PSALM_ABI_VERSION 6
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
 
@@ -102,6 +103,11 @@ int psalm_conv2d_nhwc(const void* x, int B, int H, int W, int Cin, const void* W
  *   one f16 GEMM over the 3*Kp-long panel hi.hi + lo.hi + hi.lo (or, slice by slice, the same three products), fp32 accumulate, scales in
  *   the epilogue; tiles / split-K as psalm_gemm. */
 int psalm_split_f16(const float* x, long ldx, void* out, long ldo, float* inv_scale, int rows, int K, void* stream);
+/* Products formed per algorithmic product by the psalm_gemm_x3* calls of the CALLING host thread: 3 (default; hi.hi + lo.hi + hi.lo, the
+ * fp32-class arithmetic) or 1 (hi.hi only = f16 operands with 11-bit mantissas under the same row scales, a third of the matrix work) -- the
+ * reduced-precision LLM side mode of BASELINE.json configs[4]; the reference has no counterpart (fp32, psalm/eval/panoptic_segmentation.py:126-127).
+ * Results under 1 do NOT meet the fp32 parity bar.  Thread-local; read at launch (a captured graph keeps what it was captured with). */
+int psalm_gemm_x3_set_products(int n);
 /* im2col (K order ky,kx,c; as psalm_im2col_nhwc) emitted directly in split form -- the convolution-as-GEMM A operand of the f16x3 mode
  * (F.conv2d at multimodal_projector/builder.py:85-111 and msdeformattn.py:248-254) without the fp32 im2col matrix in HBM. */
 int psalm_im2col_split_f16(const float* x, void* out, float* inv_scale, int B, int H, int W, int C, int k, int stride, int pad, void* stream);
@@ -172,6 +178,10 @@ int psalm_mask_rle_count(const void* masks, int dtype_is_u8, int n, int H, int W
 int psalm_mask_rle_emit(const void* masks, int dtype_is_u8, int n, int H, int W, const int* col_off, const long* base, int* out, void* stream);
 int psalm_iou_counts(const void* pred, int pred_is_u8, const unsigned char* tgt, const int* pred_idx, const int* tgt_idx, int npairs, long HW,
                      long long* counts_zeroed, void* stream);
+/*   psalm_fuse_masks           gRefCOCO's fused prediction (psalm/eval/eval_grefcoco.py:113-131 compute_metric + :277-285 fuse_masks): the union of
+ *                              the candidate masks whose score exceeds thr; none above thr -> the top-1 candidate (torch.topk(scores, 1)).
+ *       masks (n,H,W) f32|u8 (nonzero = 1), scores (n) f32, n <= 1024 -> out (HW) u8 */
+int psalm_fuse_masks(const void* masks, int dtype_is_u8, const float* scores, int n, long HW, float thr, unsigned char* out, void* stream);
 
 /* fp32 matrix-core MHA core of the predictor (nn.MultiheadAttention, mask2former_transformer_decoder.py:645-666; bool mask with the
  * all-masked-row rule :647) for the fp32 / f16x3 modes: exact-fp32 products (v_mfma_f32_16x16x4_f32), split over 64..256-key chunks.

@@ -110,3 +110,16 @@ def compute_metric_update(meters, pred_top1, gt):
     meters["U"] += union
     meters["acc"] += acc
     meters["n"] += 1
+
+
+def grefcoco_fused_prediction(preds, scores, thr=0.6):
+    """eval_grefcoco.py:113-131 (compute_metric) with fuse_masks (:277-285): logical OR of the candidate masks with score > thr; none above
+    thr -> the top-1 candidate (torch.topk(scores, 1): first maximal element).  preds (n,H,W) uint8, scores (n) -> (H,W) uint8."""
+    preds = np.asarray(preds).astype(np.uint8)
+    keep = [i for i, s_ in enumerate(scores) if s_ > thr]
+    if not keep:
+        keep = [int(np.argmax(np.asarray(scores)))]
+    fused = np.zeros(preds.shape[1:], bool)
+    for i in keep:
+        fused |= preds[i] != 0
+    return fused.astype(np.uint8)

@@ -168,3 +168,39 @@ extern "C" int psalm_iou_counts(const void* pred, int pred_is_u8, const unsigned
     else hipLaunchKernelGGL((iou_counts_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)pred, tgt, pred_idx, tgt_idx, HW, (unsigned long long*)counts_zeroed);
     PSALM_LAUNCH_END("psalm_iou_counts");
 }
+
+// ---------------------------------------------------------------- gRefCOCO: the fused prediction of compute_metric (eval_grefcoco.py:113-131)
+// out[p] = OR over the candidates i with scores[i] > thr of (masks[i][p] != 0); when NO candidate passes the threshold, the single candidate
+// with the largest score (torch.topk(scores, 1): the first maximal element) -- the reference's "no candidate -> top-1" fall-back.  The
+// selection is re-derived by every block from the <= 1024 scores (one thread, a few hundred compares) instead of a host round trip.
+__global__ void __launch_bounds__(256) fuse_masks_kernel(const void* __restrict__ masks, int is_u8, const float* __restrict__ scores, int n, long HW,
+                                                         float thr, unsigned char* __restrict__ out) {
+    __shared__ int sel[1024];
+    __shared__ int nsel_s;
+    if (threadIdx.x == 0) {
+        int k = 0, best = 0;
+        for (int i = 0; i < n; ++i) {
+            if (scores[i] > thr) sel[k++] = i;
+            if (scores[i] > scores[best]) best = i;
+        }
+        if (k == 0 && n > 0) sel[k++] = best;
+        nsel_s = k;
+    }
+    __syncthreads();
+    const int nsel = nsel_s;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        unsigned v = 0;
+        for (int k = 0; k < nsel; ++k) {
+            const long idx = (long)sel[k] * HW + p;
+            v |= is_u8 ? (unsigned)(reinterpret_cast<const unsigned char*>(masks)[idx] != 0) : (unsigned)(reinterpret_cast<const float*>(masks)[idx] != 0.f);
+        }
+        out[p] = (unsigned char)v;
+    }
+}
+extern "C" int psalm_fuse_masks(const void* masks, int dtype_is_u8, const float* scores, int n, long HW, float thr, unsigned char* out, void* stream) {
+    if (HW == 0) return 0;
+    PSALM_CHECK_ARG(n >= 1 && n <= 1024, "psalm_fuse_masks: 1 <= n <= 1024 candidates");
+    const long gx = (HW + 1023) / 1024;
+    hipLaunchKernelGGL(fuse_masks_kernel, dim3((unsigned)(gx > 4096 ? 4096 : gx)), dim3(256), 0, (hipStream_t)stream, masks, dtype_is_u8, scores, n, HW, thr, out);
+    PSALM_LAUNCH_END("psalm_fuse_masks");
+}

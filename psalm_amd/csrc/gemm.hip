@@ -1686,6 +1686,17 @@ static int g_x3_slice = 0;
 // left-out work is power.  r04p on MI355X (profiles/r04p_skip_pad.json, back to back, identical output words): M899 N14336 K2048 150.3 ->
 // 141.1 us, M899 N2048 K10240 123.3 -> 117.4, M1024 N14336 K2048 (nothing to leave out) 150.3 -> 149.9: the default.
 static int g_ph8_slice = 2;
+// Products per algorithmic product of the split-f16 GEMMs launched by THIS host thread: 3 (default) = hi.hi + lo.hi + hi.lo -- the fp32-class
+// arithmetic of precision "f16x3"; 1 = hi.hi only -- plain f16 operands (11-bit mantissas under the same per-row power-of-two scales), one
+// third of the matrix work.  The reduced-precision LLM side mode of BASELINE.json configs[4] (PSALM(llm_products=1)): NOT at the parity
+// bar, measured and labelled as such.  Implementation: the K-panel kernels walk logical k in [0, 3 Kp) = [hi.hi | lo.hi | hi.lo]; stopping
+// at Kp is the hi.hi product -- no kernel of its own.
+static thread_local int g_x3_products = 3;
+extern "C" int psalm_gemm_x3_set_products(int n) {
+    if (n != 1 && n != 3) { psalm_set_error("psalm_gemm_x3_set_products: 1 (hi.hi only) or 3"); return -1; }
+    g_x3_products = n;
+    return 0;
+}
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
@@ -1795,6 +1806,13 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         const int kp_ = fa.x3_kp, kps_ = splits > 1 ? cdiv(cdiv(kp_, 64), splits) * 64 : kp_, sp_ = cdiv(kp_, kps_);
         if (kps_ >= 64 && kp_ - (sp_ - 1) * kps_ >= 64) slice = 6;
     }
+    const bool p1 = x3 && g_x3_products == 1;                    // hi.hi only: the K-panel kernels over the first Kp of their 3 Kp-long range
+    if (p1) {                                                    // (tiles / split count as chosen for the three-product problem above)
+        slice = 0;
+        g.K = fa.x3_kp;
+        kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
+        splits = cdiv(g.K, kps);
+    }
     if (fa.so && slice != 3 && slice != 6) slice = 0;             // split-f16 output: K-panel form, form 3 or form 6
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
@@ -1814,7 +1832,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
                          (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
     const dim3 grid((unsigned)tiles, splits);
     if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
-        const bool ph_ = x3 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
+        const bool ph_ = x3 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (g.K - (splits - 1) * fa.k_per_split) >= 128;
         if (!(slice == 3 || slice == 6 || ph_) || fa.so_col_start % BN != 0) {
             psalm_set_error("psalm_gemm_x3_split: paired output is not available under this tile policy / for this column start");
             return -1;
@@ -1859,7 +1877,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (slice == 2) GO(256, "float", float, 64, 128, 2, 2, 4, false, 32, 0, 2, false);
         else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
-        const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (K - (splits - 1) * fa.k_per_split) >= 128;
+        const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (g.K - (splits - 1) * fa.k_per_split) >= 128;
         const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
 #define GO_X3(NT_, ...) do { if (fa.so) GO(NT_, "float", float, __VA_ARGS__, true); else GO(NT_, "float", float, __VA_ARGS__, false); } while (0)
         if (ph && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 1, true, true);
@@ -2231,6 +2249,7 @@ static int gemm_x3_impl(const void* A2, long lda, const float* a_scale, const vo
     hipStream_t s = (hipStream_t)stream;
     if (!so && !ln && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         const dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        g.K = g_x3_products * Kp;                                // (1 product: the first Kp of the K panel = hi.hi)
         snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_bf16_skinny_kernel<float, true>");
         hipLaunchKernelGGL((gemm_bf16_skinny_kernel<float, true>), grid, dim3(256), 0, s, g, SkinnyX3{a_scale, w_scale, Kp});
         PSALM_LAUNCH_END(name);

@@ -11,6 +11,7 @@ with one tiny RCCL all-reduce (`psalm_amd.dist.reduce_metrics`, the role of Aver
     panoptic_png_rgb(panoptic_ids)                panoptic_evaluation.py:204 (id2rgb) -> (H,W,3) uint8, ready for the PNG encoder
     masks_to_rle(pred_masks)                      region_segmentation.py:282 (pycocotools mask.encode) -> [{"size": [h,w], "counts": bytes}]
     iou_counts(pred_masks, gt_masks, pairs)       referring_segmentation.py:101-113 (intersectionAndUnionGPU, K=2) -> intersection, union
+    fuse_masks_by_score(pred_masks, scores, thr)  eval_grefcoco.py:113-131,277-285 (gRefCOCO: union of the candidates above thr, else top-1)
     IoUMeters                                     referring_segmentation.py:139-177 + :58-79 (cIoU / gIoU bookkeeping + all-reduce)
 """
 from __future__ import annotations
@@ -160,6 +161,24 @@ def iou_counts(pred_masks: torch.Tensor, gt_masks: torch.Tensor, pairs: Sequence
                                     o._p(counts), o._stream()), "psalm_iou_counts")
     inter, outp, tgt = counts[:, 0:2], counts[:, 2:4], counts[:, 4:6]
     return inter, outp + tgt - inter, tgt
+
+
+def fuse_masks_by_score(pred_masks: torch.Tensor, scores: torch.Tensor, thr: float = 0.6, ops=None) -> torch.Tensor:
+    """gRefCOCO's fused prediction (psalm/eval/eval_grefcoco.py:113-131: `compute_metric` + `fuse_masks` :277-285) on the device: the
+    union of the candidate masks whose score exceeds `thr`; when none does, the top-1 candidate (the reference's fall-back).
+    pred_masks (n,H,W) float32|uint8|bool (nonzero = 1), scores (n) -> (H,W) uint8.  Feed the result to `iou_counts` / `IoUMeters`
+    (the no-object target, union == 0 -> accuracy 1, is IoUMeters.update's rule, eval_grefcoco.py:147-148)."""
+    o = _ops(ops)
+    if pred_masks.dim() != 3 or scores.dim() != 1 or scores.shape[0] != pred_masks.shape[0] or not (1 <= pred_masks.shape[0] <= 1024):
+        raise H.PsalmHipError("fuse_masks_by_score: (n,H,W) masks and (n) scores, 1 <= n <= 1024")
+    pred_masks = _on_device(o, pred_masks, (torch.float32, torch.uint8, torch.bool), "fuse_masks_by_score")
+    sc = _on_device(o, scores, (torch.float32,), "fuse_masks_by_score")
+    n, Hh, Ww = pred_masks.shape
+    out = torch.empty(Hh, Ww, dtype=torch.uint8, device=o.device)
+    from ctypes import c_float
+    o._check(o.lib.psalm_fuse_masks(o._p(pred_masks), 1 if pred_masks.dtype == torch.uint8 else 0, o._p(sc), n, c_long(Hh * Ww), c_float(float(thr)),
+                                    o._p(out), o._stream()), "psalm_fuse_masks")
+    return out
 
 
 class IoUMeters:

@@ -207,6 +207,19 @@ def make_state_dict(cfg: PsalmConfig, seed: int = 0, include_lm_head: bool = Fal
     return sd
 
 
+def scale_residual_branches(sd: Dict[str, torch.Tensor], s: float) -> Dict[str, torch.Tensor]:
+    """A copy of `sd` whose residual-branch OUTPUT projections are scaled by `s`: Phi dense / fc2, Swin attn.proj / mlp.fc2, the deformable
+    encoder's output_proj / linear2, the mask decoder's out_proj / linear2 (weights and biases).  s < 1 makes every residual block more
+    contractive -- the weight set of the experiment "is the reduced-precision modes' IoU a property of the arithmetic or of the unit-gain
+    random network" (VERDICT r04 "Next" #7; tools/bench_configs.py --contractive)."""
+    out = dict(sd)
+    pats = (".self_attn.dense.", ".mlp.fc2.", ".attn.proj.", ".self_attn.output_proj.", ".linear2.", ".out_proj.")
+    for k, v in sd.items():
+        if any(p in k for p in pats) and (k.endswith(".weight") or k.endswith(".bias")) and torch.is_floating_point(v):
+            out[k] = v * s
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md §8(d) "Config 1..5"): sentinel-id prompts + side index tensors, the
 # exact `eval_seg` keyword contract of llava_phi.py:1317-1336.

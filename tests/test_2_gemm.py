@@ -714,3 +714,39 @@ def test_split_output_bound_debug_check_heavy_tailed_weights(ops):
             ops.gemm_x3_split(asp, wsp, bias.to(d), H.ACT_NONE, so, inv, (par * torch.tensor([2.0 ** 12, 2.0 ** 12, 1.0, 1.0])).to(d))
     finally:
         ops.debug_bounds = False
+
+
+@pytest.mark.parametrize("M,N,K,policy", [(300, 520, 192, 256), (300, 260, 128, 128), (200, 130, 704, 64), (100, 72, 64, 0), (270, 300, 704, 128)])
+def test_gemm_x3_single_product_is_the_hi_hi_term(ops, M, N, K, policy):
+    """psalm_gemm_x3_set_products(1) -- the reduced-precision LLM side mode of BASELINE.json configs[4]: the split-f16 GEMM stops after the hi.hi
+    product, i.e. it is the plain f16 GEMM of the operands' hi halves under the same per-row scales (fp32 accumulate: exact to fp32 round-off
+    against the float64 product of those halves), and a few 2^-11 of sum |a||w| away from the fp32-class three-product result.  The setting is
+    per host thread and read at launch; 3 restores the default."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.5
+    bias = torch.randn(N, generator=g)
+    d = ops.device
+    asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+    ops.gemm_tile_policy(policy)
+    try:
+        full = ops.gemm(asp, wsp, bias.to(d)).cpu().double()
+        ops.x3_products(1)
+        got = ops.gemm(asp, wsp, bias.to(d)).cpu().double()
+        ops.x3_products(3)
+        again = ops.gemm(asp, wsp, bias.to(d)).cpu().double()
+    finally:
+        ops.x3_products(3)
+        ops.gemm_tile_policy(0)
+    hi_a = asp.t[:, :asp.Kp].cpu().double() * asp.inv_scale.cpu().double()[:, None]
+    hi_w = wsp.t[:, :wsp.Kp].cpu().double() * wsp.inv_scale.cpu().double()[:, None]
+    want = hi_a @ hi_w.t() + bias.double()
+    mag = a.abs().double() @ w.abs().double().t()
+    assert (got - want).abs().max() <= 2e-6 * mag.max()                       # the hi.hi product, fp32 accumulation
+    exact = a.double() @ w.double().t() + bias.double()
+    assert ((full - exact).abs() <= 6 * 2.0 ** -22 * mag + 1e-6).all()        # default: fp32 class
+    err1 = ((got - exact).abs() / mag).max().item()
+    assert 2.0 ** -16 < err1 < 2.0 ** -9                                      # one product: f16 operands (11-bit mantissas)
+    assert torch.equal(again, full)                                           # the default is back
+    with pytest.raises(Exception):
+        ops.x3_products(2)

@@ -210,3 +210,30 @@ def test_replica_shares_weights_owns_state_and_agrees():
     b = r.eval_seg(**inputs)[0]
     assert torch.equal(a["mask_pred"], b["mask_pred"]) and torch.equal(a["sem_seg"], b["sem_seg"])
     assert torch.equal(a["panoptic_seg"][0], b["panoptic_seg"][0]) and a["panoptic_seg"][1] == b["panoptic_seg"][1]
+
+
+def test_llm_single_product_side_mode_changes_the_llm_only_and_leaves_the_default_alone():
+    """PSALM(llm_products=1) -- BASELINE.json configs[4]'s reduced-precision LLM path as an opt-in side mode: the Phi GEMMs form one f16 product
+    (hi.hi) instead of three.  On the tiny model: the vision tower's outputs are bit for bit those of the default (only the LLM's GEMMs
+    change), the LLM's hidden states move by an f16-operand-sized amount (between 1e-5 and 2e-2 relative L2 -- stated, looser tolerance), and
+    a default model evaluated afterwards on the same binding gives its own bits again (the setting is reset after the LLM)."""
+    cfg = PsalmConfig.tiny("panoptic")
+    sd = make_state_dict(cfg, seed=11)
+    inputs = make_inputs(cfg, "panoptic", size=96, batch=1, seed=3, num_classes=9)
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    ops = make_ops("emu")
+    m3 = PSALM(cfg, sd, ops=ops, precision="f16x3")
+    m1 = PSALM(cfg, sd, ops=ops, precision="f16x3", llm_products=1)
+    s3, s1, s3b = {}, {}, {}
+    o3 = m3.forward_logits(stages=s3, **kw)
+    o1 = m1.forward_logits(stages=s1, **kw)
+    o3b = m3.forward_logits(stages=s3b, **kw)
+    assert torch.equal(s3["image_tokens"], s1["image_tokens"]) and torch.equal(s3["inputs_embeds"], s1["inputs_embeds"])
+    h3, h1 = s3["hidden_states"].double(), s1["hidden_states"].double()
+    rel = float((h3 - h1).norm() / h3.norm())
+    assert 1e-5 < rel < 2e-2, rel
+    assert torch.equal(s3["hidden_states"], s3b["hidden_states"]) and torch.equal(o3[0]["pred_masks"], o3b[0]["pred_masks"])
+    rm = float((o3[0]["pred_masks"].double() - o1[0]["pred_masks"].double()).abs().max() / o3[0]["pred_masks"].abs().max())
+    assert rm < 0.2, rm
+    with pytest.raises(ValueError):
+        PSALM(cfg, sd, ops=ops, precision="fp32", llm_products=1)

@@ -173,3 +173,43 @@ def test_device_evalout_matches_reference_evaluator_golden(ops):
     cm = E.ConfusionMatrix(C, 255, ops=ops)
     cm.update(E.semantic_labels(torch.from_numpy(G["sem/logits"]).to(ops.device), ops=ops), torch.from_numpy(G["sem/gt"]))
     assert np.array_equal(cm.conf.cpu().numpy(), G["sem/conf_matrix"])
+
+
+# ---- gRefCOCO: the reference's compute_metric / fuse_masks (psalm/eval/eval_grefcoco.py) run on seeded candidates -> grefcoco.npz -----------
+def _gref():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grefcoco.npz"))
+
+
+def test_oracle_matches_reference_grefcoco_fusion_golden():
+    """oracle/evalout_ref.py::grefcoco_fused_prediction vs what the reference's compute_metric kept and counted: several candidates above the
+    threshold, one, none (top-1 fall-back), a no-object target, a tie."""
+    G = _gref()
+    ref = {"I": np.zeros(2), "U": np.zeros(2), "acc": np.zeros(2), "n": 0}
+    for i in range(5):
+        fused = R.grefcoco_fused_prediction(G[f"s{i}/pred"], G[f"s{i}/scores"], 0.6)
+        assert np.array_equal(fused, G[f"s{i}/fused"]), i
+        ai, au, _ = R.intersection_and_union(fused, G[f"s{i}/gt"])
+        assert np.array_equal(ai, G[f"s{i}/intersection"].astype(np.int64)) and np.array_equal(au, G[f"s{i}/union"].astype(np.int64))
+        R.compute_metric_update(ref, fused, G[f"s{i}/gt"])
+    assert np.array_equal(ref["I"], G["meters/intersection_sum"]) and np.array_equal(ref["U"], G["meters/union_sum"])
+    assert np.allclose(ref["acc"], G["meters/acc_iou_sum"], rtol=0, atol=1e-12) and ref["n"] == int(G["meters/count"])
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_device_grefcoco_fusion_matches_reference_golden(ops, dtype):
+    """psalm_amd.evalout.fuse_masks_by_score + iou_counts + IoUMeters (kernels: emulator here, the GPU under -m gpu) vs the same golden."""
+    G = _gref()
+    meters = E.IoUMeters()
+    for i in range(5):
+        pred = torch.from_numpy(G[f"s{i}/pred"]).to(dtype)
+        fused = E.fuse_masks_by_score(pred.to(ops.device), torch.from_numpy(G[f"s{i}/scores"]).to(ops.device), 0.6, ops=ops)
+        assert fused.dtype == torch.uint8 and np.array_equal(fused.cpu().numpy(), G[f"s{i}/fused"]), i
+        inter, union, _ = E.iou_counts(fused[None], torch.from_numpy(G[f"s{i}/gt"])[None], [(0, 0)], ops=ops)
+        assert np.array_equal(inter[0].cpu().numpy(), G[f"s{i}/intersection"].astype(np.int64))
+        assert np.array_equal(union[0].cpu().numpy(), G[f"s{i}/union"].astype(np.int64))
+        meters.update(inter, union)
+    assert np.array_equal(meters.sum[0:2].numpy(), G["meters/intersection_sum"]) and np.array_equal(meters.sum[2:4].numpy(), G["meters/union_sum"])
+    assert np.allclose(meters.sum[4:6].numpy(), G["meters/acc_iou_sum"], rtol=0, atol=1e-12) and int(meters.sum[6]) == int(G["meters/count"])
+    with pytest.raises(Exception):
+        E.fuse_masks_by_score(torch.zeros(2, 4, 4), torch.zeros(3), ops=ops)

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from parity_seeds import compare  # noqa: E402
 from psalm_amd.config import PsalmConfig  # noqa: E402
 from psalm_amd.model import PSALM  # noqa: E402
-from psalm_amd.synthetic import make_inputs, make_state_dict  # noqa: E402
+from psalm_amd.synthetic import make_inputs, make_state_dict, scale_residual_branches  # noqa: E402
 
 CONFIGS = {2: ("2: panoptic 1024 b1", "panoptic", 1024, 1), 3: ("3: referring 640 b4", "referring", 640, 4),
            5: ("5: region 1024 b2", "region", 1024, 2)}
@@ -55,14 +55,16 @@ def dominant(model, inputs, nprof=2):
             "top": [{"kernel": k, "launches_per_step": v[0] / nprof, "ms_per_step": round(v[1] / nprof, 3), "share": round(v[1] / tot, 4)} for k, v in top]}
 
 
-def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
+def run(key, precision, sd_cache, seeds, oracle_cache, steps=10, llm_products=3, branch_scale=None):
     name, task, size, batch = CONFIGS[key]
     cfg = PsalmConfig(seg_task=task)
-    if task not in sd_cache:
+    if (task, branch_scale) not in sd_cache:
         sd_cache.clear()
-        sd_cache[task] = make_state_dict(cfg, seed=0)
-    sd = sd_cache[task]
-    model = PSALM(cfg, sd, precision=precision, use_graphs=True)
+        oracle_cache.clear()
+        sd0 = make_state_dict(cfg, seed=0)
+        sd_cache[(task, branch_scale)] = sd0 if branch_scale is None else scale_residual_branches(sd0, branch_scale)
+    sd = sd_cache[(task, branch_scale)]
+    model = PSALM(cfg, sd, precision=precision, use_graphs=True, llm_products=llm_products)
     model.graph_outputs = "alias"
     inputs = make_inputs(cfg, task, size=size, batch=batch, seed=3)
     inputs["images"] = inputs["images"].cuda()
@@ -74,21 +76,24 @@ def run(key, precision, sd_cache, seeds, oracle_cache, steps=10):
         model.eval_seg(**inputs)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision,
-           "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 2)}
-    ents = [e for e in model._graphs.values() if isinstance(e, dict) and "graph" in e]
-    if len(ents) == 1:
+    res = {"config": name, "task": task, "size": size, "batch": batch, "precision": precision, "llm_products": llm_products,
+           "residual_branch_scale": branch_scale, "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 2)}
+    if task != "region":                                 # (region: _finalize uploads the ground truth -- part of the call)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            ents[0]["graph"].replay()
-        e1.record()
-        torch.cuda.synchronize()
-        res["gpu_ms_per_batch"] = round(e0.elapsed_time(e1) / steps, 3)
+        model._finalize = lambda r_, info_: r_            # graph replay + tail, without the one host read-back per image
+        try:
+            e0.record()
+            for _ in range(steps):
+                model.eval_seg(**inputs)
+            e1.record()
+            torch.cuda.synchronize()
+            res["gpu_ms_per_batch"] = round(e0.elapsed_time(e1) / steps, 3)
+        finally:
+            del model._finalize
     res["kernels"] = dominant(model, inputs)
     if seeds:
         from oracle import psalm_oracle as O
-        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))   # (profiles/r04_cpu_baseline_threads.json: 16 is the fastest on the GPU box's host; 64 oversubscribes)
         model.graph_outputs = "copy"
         rows = []
         for s in range(seeds):
@@ -125,10 +130,21 @@ def main():
     seeds = 0 if "--skip-oracle" in av else int(av[av.index("--seeds") + 1]) if "--seeds" in av else 5
     only = [int(x) for x in av[av.index("--only") + 1].split(",")] if "--only" in av else [3, 5]
     out, sd_cache, oc = [], {}, {}
+    # --llm1: one more line per config with the Phi GEMMs on ONE f16 product (PSALM(llm_products=1): BASELINE configs[4]'s reduced-precision LLM
+    # path, a labelled side mode); --contractive S: the reduced-precision lines again on a weight set whose residual-branch output
+    # projections are scaled by S (is their IoU the arithmetic's or the unit-gain random network's?)
+    llm1 = "--llm1" in av
+    contr = float(av[av.index("--contractive") + 1]) if "--contractive" in av else None
     for key in only:
         out.append(run(key, "f16x3", sd_cache, seeds, oc))
+        if llm1:
+            out.append(run(key, "f16x3", sd_cache, seeds, oc, llm_products=1))
         if "--no-bf16" not in av:
             out.append(run(key, "bf16", sd_cache, min(seeds, 1), oc))   # contrast line: does not meet the bar on this network
+        if contr is not None:
+            out.append(run(key, "f16x3", sd_cache, min(seeds, 2), oc, branch_scale=contr))
+            out.append(run(key, "f16x3", sd_cache, min(seeds, 2), oc, llm_products=1, branch_scale=contr))
+            out.append(run(key, "bf16", sd_cache, min(seeds, 2), oc, branch_scale=contr))
     if "--json" in av:
         with open(av[av.index("--json") + 1], "w") as f:
             json.dump(out, f, indent=1)
