@@ -57,7 +57,10 @@ int psalm_msda_fused(const void* value, int value_dtype, const int64_t* spatial_
                      const int64_t* level_start_host, const float* offsets_logits, void* out, int out_dtype, int B, int S,
                      int M, int D, int L, int P, void* stream);
 /* Tuning / test knob of psalm_msda_fused (head dim 32): 1 (default) = the bilinear taps of a sample are computed once per (query, head) and
- * shared by its 4 channel-group lanes, 0 = every lane computes all samples (the r01 - r03 kernel).  Same values either way. */
+ * shared by its 4 channel-group lanes, 0 = every lane computes all samples (the r01 - r03 kernel).  The shared form is only selected for a bf16
+ * `value` (fp32 value keeps the per-lane form whatever the knob says) and sums the softmax denominator in another order: equal to ~1e-5
+ * relative, not bit for bit (tests/test_3_msda.py).  Like psalm_gemm_set_tile_policy a process-wide tuning / test knob: do not call it
+ * while another host thread is launching. */
 int psalm_msda_set_policy(int v);
 
 
@@ -219,7 +222,9 @@ const char* psalm_gemm_last_kernel(void);
 int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4);
 /* Tuning / test knob for the direct-to-LDS path: 0 = automatic tile selection (default), 256 | 128 | 64 = force BM;
  * 2560 | 2568 | 2569 | 2570 = K loop of the 256x256 configuration: plain 2-buffer loop | 4-phase schedule, copy placement 1 | 2 | 3
- * (3 = default).  Other codes: experiment switches documented at psalm_gemm_set_tile_policy in csrc/gemm.hip. */
+ * (3 = default).  Other codes: experiment switches documented at psalm_gemm_set_tile_policy in csrc/gemm.hip.  Process-wide and NOT
+ * synchronised: a tuning / test knob, to be set before launches start (tests restore the defaults); never call it while another host thread
+ * (a PSALM.replica() worker) is inside a GEMM call. */
 int psalm_gemm_set_tile_policy(int bm);
 
 /* ------------------------------------------------------------------------------------------------------------------

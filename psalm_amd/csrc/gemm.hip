@@ -1705,7 +1705,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 7777 || bm == 7778) { g_skinny_nmax = bm == 7777 ? (1L << 20) : 4096; return 0; }   // skinny-kernel N limit (tuning)
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
-    if (bm >= 2580 && bm <= 2582) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices / (experiment) slices, all-padding m-tiles left out
+    if (bm >= 2580 && bm <= 2582) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices / slices with the all-padding m-tiles left out (2582: the DEFAULT since r04p)
     if (bm >= 3300 && bm <= 3308) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles (7 / 8: r05 ring depths)
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
@@ -1833,7 +1833,8 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     const dim3 grid((unsigned)tiles, splits);
     if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
         const bool ph_ = x3 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (g.K - (splits - 1) * fa.k_per_split) >= 128;
-        if (!(slice == 3 || slice == 6 || ph_) || fa.so_col_start % BN != 0) {
+        const bool kpanel_small = x3 && !slice && BM != 256;     // K-panel form on 128 x 128 / 64 x 128 tiles (reached by the one-product mode)
+        if (!(slice == 3 || slice == 6 || ph_ || kpanel_small) || fa.so_col_start % BN != 0) {
             psalm_set_error("psalm_gemm_x3_split: paired output is not available under this tile policy / for this column start");
             return -1;
         }
@@ -1881,6 +1882,8 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
 #define GO_X3(NT_, ...) do { if (fa.so) GO(NT_, "float", float, __VA_ARGS__, true); else GO(NT_, "float", float, __VA_ARGS__, false); } while (0)
         if (ph && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 1, true, true);
+        else if (fa.so && fa.so_paired && BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 1, true, true);
+        else if (fa.so && fa.so_paired && BM == 64) GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 1, true, true);
         else if (ph) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 3, 1);
         else if (BM == 256) GO_X3(512, 256, 256, 2, 4, 2, false, 64, 0, 1);
         else if (BM == 128 && g_ring_depth == 3) GO_X3(256, 128, 128, 2, 2, 3, false, 64, 0, 1);

@@ -1465,6 +1465,7 @@ class PSALM:
         blob, layout, meta = self._prepare(input_ids, attention_mask, images, seg_info, class_name_ids,
                                            class_name_embedding_indices, cls_indices, token_refer_id, refer_embedding_indices,
                                            region_point_sampler, video=vp_images is not None)
+        self._last_meta = meta                          # (bench.py: the bucketed vs real sequence length of the last call)
         if self.use_graphs and not self.ops.is_emu:
             results = self._run_graphed(images, blob, layout, meta, vp_images)
         else:

@@ -397,9 +397,11 @@ def test_gemm_x3_split_output(ops, M, N, K, act, policy, col_start, col_off, glo
     (300, 512, 192, H.ACT_RELU, 128, 0, 64, False),
     (300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True),     # Phi layout on the 256 x 256 tile: [.. | fc1], fc1 columns paired
 ])
-def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start, col_off, glob):
+@pytest.mark.parametrize("products", [3, 1])
+def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start, col_off, glob, products):
     """`paired`: with the W rows / bias >= col_start permuted by so_pair_perm the emitted operand, its scales and the fp32 columns are
-    bit for bit those of the un-permuted call (same dot products; only the store path differs: registers -> 4-byte stores, no LDS pass)."""
+    bit for bit those of the un-permuted call (same dot products; only the store path differs: registers -> 4-byte stores, no LDS pass).
+    products = 1: the same through the K-panel kernels of the one-product side mode (psalm_gemm_x3_set_products), on all three tile sizes."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
     w = torch.randn(N, K, generator=g) * 0.2
@@ -411,6 +413,7 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
     perm = torch.cat([torch.arange(col_start), col_start + H.Ops.so_pair_perm(Ns)])
     res = []
     ops.gemm_tile_policy(policy)
+    ops.x3_products(products)
     try:
         for paired in (False, True):
             wq, bq = (w[perm], bias[perm]) if paired else (w, bias)
@@ -423,6 +426,7 @@ def test_gemm_x3_split_output_paired_stores(ops, M, N, K, act, policy, col_start
                               out=out, global_rows=glob, paired=paired)
             res.append((so.cpu(), inv.cpu(), out.cpu() if out is not None else None))
     finally:
+        ops.x3_products(3)
         ops.gemm_tile_policy(0)
     (so0, inv0, out0), (so1, inv1, out1) = res
     assert (so0[:, col_off:col_off + Ns] != 0).any()

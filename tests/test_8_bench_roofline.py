@@ -17,7 +17,7 @@ def _run_block(kern, hbm, traffic_json=None, sq_json=None):
     block = "\n".join(l[8:] for l in lines[start[0]:end[0]])
     ns = {"__file__": os.path.join(ROOT, "bench.py"), "__name__": "bench_extract"}
     exec(src.split("def varied_streams")[0], ns)                          # constants, file locations
-    ns.update(dict(hbm=hbm, kern=kern, nprof=2, ev_over=0.005))
+    ns.update(dict(hbm=hbm, kern=kern, nprof=2, ev_over=0.005, rows_real=899, rows_padded=928))
     if traffic_json is not None:
         ns["TRAFFIC_JSON"] = traffic_json
     if sq_json is not None:
@@ -38,6 +38,7 @@ def test_roofline_object_is_assembled_for_the_default_kernel_and_reads_the_commi
     assert roof["bound"] == "mfma" and roof["kernel"] == DOMINANT and roof["peak"] == 2500.0
     assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3 and 0.0 < roof["frac"] < 1.0
     assert roof["mfma_issue"]["f16_product_equivalents"] == 3
+    assert roof["algorithmic_rows"]["real_tokens"] == 899 and roof["algorithmic_rows"]["launched_rows"] == 928
     names = [h["kernel"] for h in roof["hbm_bound_kernels"]]
     assert set(names) == set(HBM)
     for h in roof["hbm_bound_kernels"]:

@@ -1,5 +1,6 @@
 """Fused semantic pass (psalm_semantic_from_masks_x3) at the bench shape: Q = 100 mask logits x 1024^2 pixels -> 133 class planes.
-    python tools/bench_semantic.py            -> one JSON line per tile order (PSALM_SEM_ORDER = 0 strided / 1 contiguous per block)"""
+    python tools/bench_semantic.py            -> one JSON line (warm / cold Infinity Cache), two runs in fresh processes
+(r03 compared two tile orders through an environment switch the library no longer reads: profiles/r03n_semantic_tile_order.jsonl keeps that A/B.)"""
 import json
 import os
 import subprocess
@@ -35,12 +36,12 @@ def one():
             del out, ms
         us = sorted(ts)[len(ts) // 2]
         res[mode] = {"us": round(us, 1), "TB_s": round((Q + C) * HW * 4 / us / 1e6, 3)}
-    print(json.dumps({"PSALM_SEM_ORDER": os.environ.get("PSALM_SEM_ORDER", "0"), **res}), flush=True)
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
     if "--one" in sys.argv:
         one()
     else:
-        for order in ("0", "1", "0", "1"):
-            subprocess.call([sys.executable, os.path.abspath(__file__), "--one"], env=dict(os.environ, PSALM_SEM_ORDER=order))
+        for _ in range(2):
+            subprocess.call([sys.executable, os.path.abspath(__file__), "--one"])

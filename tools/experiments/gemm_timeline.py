@@ -58,11 +58,10 @@ def main():
     out = {}
     for shape in SHAPES:
         M, N, K, so_from, act = shape[:5]
-        x8 = len(shape) > 5 and shape[5]                     # operands (and the emitted operand) in the x8 form: e4m3 cross terms
         paired = len(shape) > 6 and shape[6]                 # paired split-f16 stores (timing only: the W rows are NOT permuted here)
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * 0.05
-        asp, wsp = (ops.split_f16(a, 1), ops.split_f16(w, 2)) if x8 else (ops.split_f16(a), ops.split_f16(w))
+        asp, wsp = ops.split_f16(a), ops.split_f16(w)
         c = torch.empty(M, N, device="cuda")
         bias = torch.randn(N, device="cuda")
         if so_from is not None:                              # the model's fused form: columns >= so_from leave as the next GEMM's split-f16 operand
@@ -73,17 +72,17 @@ def main():
 
             def launch():
                 ops.gemm_x3_split(asp, wsp, bias, act, so, so_inv, bnd, split_col_off=2048, split_col_start=so_from, act_col_start=so_from, out=c,
-                                  split_form=1 if x8 else 0, paired=bool(paired))
+                                  paired=bool(paired))
         else:
             def launch():
                 ops.gemm_x3(asp, wsp, out=c)
         big = torch.empty(64 << 20, device="cuda")        # 256 MB: evicts the operands from the Infinity Cache between cold launches
         row = {}
-        for name, pol in (POLICIES[:1] if x8 or os.environ.get("TL_SHAPES") else POLICIES):
+        for name, pol in (POLICIES[:1] if os.environ.get("TL_SHAPES") else POLICIES):
             for p in pol:
                 ops.gemm_tile_policy(p)
             try:
-                desc = ops.gemm_describe(M, N, 2 * asp.Kp, x8=True) if x8 else ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)
+                desc = ops.gemm_describe(M, N, 3 * asp.Kp, x3=True)
                 res = {}
                 for mode in ("warm", "cold"):
                     for _ in range(2):
@@ -120,7 +119,7 @@ def main():
             finally:
                 for p in (1282, 640, 3300, 0):
                     ops.gemm_tile_policy(p)
-        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "") + (" x8" if x8 else "") + (" paired" if paired else "")
+        key = f"M{M} N{N} K{K}" + (f" so>={so_from} act{act}" if so_from is not None else "") + (" paired" if paired else "")
         out[key] = row
         print(key, json.dumps(row), flush=True)
         del a, w, asp, wsp, c, big

@@ -15,9 +15,13 @@ def main(path, top=60):
     tot = sum(r[2] for r in rows) or 1
     print(f"# source: {path}")
     print(f"# total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
-    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'pct':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7}  name")
+    print("# med_us = median launch duration: what bench.py's HIP-event figures aggregate by (its instrumented steps count a (kernel, shape)'s launches with their")
+    print("#          median, so that one stalled eager launch does not move a line); avg_us is the mean over ALL launches of the process, cold first ones included")
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'med_us':>9} {'min_us':>9} {'max_us':>9} {'pct':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7}  name")
     for n, k, s, a, mn, mx, vg, ag, sg, lds in rows[:top]:
-        print(f"{k:7d} {s / 1e6:10.3f} {a / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * s / tot:6.2f} {vg or 0:5d} {ag or 0:5d} {sg or 0:5d} {lds or 0:7d}  {n[:150]}")
+        d = [r[0] for r in c.execute("select duration from kernels where name = ? order by duration", (n,)).fetchall()]
+        med = d[len(d) // 2] if d else 0
+        print(f"{k:7d} {s / 1e6:10.3f} {a / 1e3:10.2f} {med / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * s / tot:6.2f} {vg or 0:5d} {ag or 0:5d} {sg or 0:5d} {lds or 0:7d}  {n[:150]}")
 
 
 if __name__ == "__main__":
