@@ -1767,6 +1767,18 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
     } else if (x3) {
         int BM, BN, splits;
         select_fast_config(M, N, K, workspace_bytes > 0, workspace_bytes, BM, BN, splits, true);
+        // the slice forms (every default K loop of the split-f16 GEMM) walk the TRUE K range Kp = K / 3: the split count is re-derived on it,
+        // as launch_fast does (this function reported the K-panel form's count)
+        const int kp = K / 3;
+        bool slice = BM == 256 ? (g_ph8 && g_ph8_slice) : g_x3_slice != 5;
+        if (BM == 256 && slice) {
+            const int kps_ = splits > 1 ? cdiv(cdiv(kp, 64), splits) * 64 : kp, sp_ = cdiv(kp, kps_);
+            slice = kps_ >= 64 && kp - (sp_ - 1) * kps_ >= 64;
+        }
+        if (slice && g_x3_products == 3 && splits > 1) {
+            const int kps = cdiv(cdiv(kp, 64), splits) * 64;
+            splits = cdiv(kp, kps);
+        }
         out4[0] = 1; out4[1] = BM; out4[2] = BN; out4[3] = splits;
     } else if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;                     // skinny kernel

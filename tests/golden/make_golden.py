@@ -42,6 +42,10 @@ CASES = {
     "instance_384": dict(task="instance", size=384, batch=1, layers=2, seed=4, pad=32),
     # PSALMForDAVISEval.eval_video (LP:1845-1998): region prompts pooled from the previous frame (vp_images, vp_region_masks)
     "video_region_384": dict(task="region", size=384, batch=1, layers=2, seed=5, pad=0, video=True),
+    # BASELINE.json configs[1] with what the reference's evaluation loop really feeds (r05): the full 24-layer model at
+    # 1024 x 1024, a 480 x 640 original -> un-padded box 768 x 1024 inside the canvas (coco_panoptic_mapper.py:81-89), results cropped to the box
+    # and resized to 480 x 640 (LP:1418-1429).  Mask logits kept at stride 8 (410 kB), label maps in full.
+    "panoptic_1024_box": dict(task="panoptic", size=1024, batch=1, layers=24, seed=7, pad=0, geometry=(768, 1024, 480, 640), mask_stride=8),
 }
 RNG_SEED_AT_CALL = 1234
 
@@ -85,7 +89,8 @@ def run_case(name, c):
     sd = make_state_dict(cfg, seed=c["seed"], include_lm_head=True)
     print(f"[{name}] synthetic state dict: {len(sd)} tensors, {sum(v.numel() for v in sd.values())/1e9:.2f} B params, {time.time()-t0:.1f}s")
     model = build_reference(cfg, sd, video=c.get("video", False))
-    inputs = make_inputs(cfg, task=c["task"], size=c["size"], batch=c["batch"], seed=c["seed"], pad=c["pad"], video=c.get("video", False))
+    inputs = make_inputs(cfg, task=c["task"], size=c["size"], batch=c["batch"], seed=c["seed"], pad=c["pad"], video=c.get("video", False),
+                         **({"geometry": [c["geometry"]]} if c.get("geometry") else {}))
 
     stages = {}
     hooks = []
@@ -127,7 +132,8 @@ def run_case(name, c):
         save["pred_SEG_logits"] = stages["pred_SEG_logits"].numpy()
     if stages.get("pred_region_logits") is not None:
         save["pred_region_logits"] = torch.cat([x.reshape(-1) for x in stages["pred_region_logits"]]).numpy()
-    save["pred_masks_s4"] = stages["pred_masks"][:, :, ::4, ::4].contiguous().numpy()
+    st_ = int(c.get("mask_stride", 4))
+    save[f"pred_masks_s{st_}"] = stages["pred_masks"][:, :, ::st_, ::st_].contiguous().numpy()
     save["pred_masks_pos_frac"] = (stages["pred_masks"] > 0).float().mean((2, 3)).numpy()
     r = out[0]
     if "sem_seg" in r:

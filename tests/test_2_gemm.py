@@ -474,7 +474,7 @@ def test_gemm_x3_256_phased_slice_form_split_output(ops):
         test_gemm_x3_split_output(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
         assert "256, 256, 2, 4, 2, false, 32, 3, 2, true" in ops.gemm_last_kernel() or "skinny" in ops.gemm_last_kernel() or "64, 128" in ops.gemm_last_kernel()
         test_gemm_x3_split_output(ops, 300, 520, 128, H.ACT_GELU, 256, 256, 0, True)
-        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
+        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, 3)
     finally:
         ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
 
@@ -512,7 +512,7 @@ def test_gemm_x3_256_phased_slice_form_padding_tiles_left_out_split_output(ops):
     try:
         test_gemm_x3_split_output(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
         assert "256, 256, 2, 4, 2, false, 32, 4, 2, true" in ops.gemm_last_kernel() or "skinny" in ops.gemm_last_kernel() or "64, 128" in ops.gemm_last_kernel()
-        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True)
+        test_gemm_x3_split_output_paired_stores(ops, 300, 768, 192, H.ACT_GELU_NEW, 256, 512, 256, True, 3)
     finally:
         ops.gemm_tile_policy(H.Ops.GEMM_X3_256_DEFAULT)
 

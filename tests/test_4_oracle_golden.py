@@ -19,7 +19,7 @@ def _run(name):
     cfg = PsalmConfig(num_layers=case["layers"], seg_task=case["task"])
     sd = make_state_dict(cfg, seed=case["seed"])
     inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"],
-                         video=case.get("video", False))
+                         video=case.get("video", False), **({"geometry": [case["geometry"]]} if case.get("geometry") else {}))
     torch.manual_seed(RNG_SEED_AT_CALL)
     results, st = O.eval_seg(sd, cfg, return_stages=True, **inputs)
     return case, z, cfg, results, st
@@ -116,3 +116,19 @@ def test_video_region_384():
     got = torch.cat([x.reshape(-1) for x in st["pred_region_logits"]]).numpy()
     np.testing.assert_allclose(got, z["pred_region_logits"], rtol=0, atol=2e-4 * np.abs(z["pred_region_logits"]).max())
     np.testing.assert_allclose(results[0]["instances"].scores.numpy(), z["inst_scores"], atol=1e-4)
+
+
+@pytest.mark.slow
+def test_panoptic_1024_box():
+    """The oracle at the headline configuration -- full model, 1024 x 1024 canvas with a 768 x 1024 box of a 480 x 640 original (crop + resize
+    of LP:1418-1429) -- against the reference's own outputs: mask logits (stride 8), class logits, label maps and segments in full."""
+    case, z, cfg, results, st = _run("panoptic_1024_box")
+    _check_stages(z, st)
+    np.testing.assert_allclose(st["pred_masks"][:, :, ::8, ::8].numpy(), z["pred_masks_s8"], rtol=0, atol=2e-4 * np.abs(z["pred_masks_s8"]).max())
+    np.testing.assert_allclose(st["pred_class_name_logits"].numpy(), z["pred_class_name_logits"], rtol=0, atol=2e-4 * np.abs(z["pred_class_name_logits"]).max())
+    r = results[0]
+    assert tuple(r["sem_seg"].shape[-2:]) == (480, 640)
+    assert (r["sem_seg"].argmax(0).to(torch.uint8).numpy() == z["sem_seg_argmax"]).mean() >= 1 - 1e-4
+    pan, info = r["panoptic_seg"]
+    assert (pan.to(torch.uint8).numpy() == z["panoptic_ids"]).mean() >= 1 - 1e-4
+    assert [[s["id"], int(s["isthing"]), s["category_id"]] for s in info] == z["panoptic_info"].tolist()

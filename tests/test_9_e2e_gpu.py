@@ -42,7 +42,7 @@ def _run_golden(name, precision):
     cfg = PsalmConfig(num_layers=case["layers"], seg_task=case["task"])
     sd = make_state_dict(cfg, seed=case["seed"])
     inputs = make_inputs(cfg, task=case["task"], size=case["size"], batch=case["batch"], seed=case["seed"], pad=case["pad"],
-                         video=case.get("video", False))
+                         video=case.get("video", False), **({"geometry": [case["geometry"]]} if case.get("geometry") else {}))
     model = PSALM(cfg, sd, precision=precision)
     del sd
     torch.manual_seed(RNG_SEED_AT_CALL)
@@ -122,12 +122,15 @@ def test_golden_referring_384_b2(precision, rtol):
     seg_err = float(np.abs(seg - z["pred_SEG_logits"]).max() / np.abs(z["pred_SEG_logits"]).max())
     sc = np.sort(results[0]["instances"].scores.cpu().numpy())
     sc_err = float(np.abs(sc - np.sort(z["inst_scores"])).max())
-    _report(test="referring_384_b2", precision=precision, stage_err=errs, seg_err=seg_err, score_err=sc_err)
+    sc_mean = float(np.abs(sc - np.sort(z["inst_scores"])).mean())
+    _report(test="referring_384_b2", precision=precision, stage_err=errs, seg_err=seg_err, score_err=sc_err, score_err_mean=sc_mean)
     assert len(results) == 2
-    # bf16 (the mode that does NOT meet the north-star bar): its outputs move chaotically with every change of rounding -- the score
-    # of one instance sat at 0.05 from the reference in r03 and at 0.2005 in r04 (a GELU expression evaluated with one explicit fma) -- so
-    # the bf16 line only guards against gross breakage
-    assert seg_err < (rtol if precision in EXACT else 0.15) and sc_err < (2e-3 if precision in EXACT else 0.5)
+    # bf16 (the mode that does NOT meet the north-star bar): single outputs move chaotically with every change of rounding -- the
+    # score of one instance sat at 0.05 from the reference in r03 and at 0.2005 in r04 (a GELU expression evaluated with one explicit fma).  A bound
+    # on the WORST of 100 scores therefore has to be loose (0.3 on [0, 1]); what stays meaningful is the distribution: the mean distance between
+    # the sorted score lists (the previous `max < 0.5` alone was close to vacuous)
+    assert seg_err < (rtol if precision in EXACT else 0.15) and sc_err < (2e-3 if precision in EXACT else 0.3)
+    assert precision in EXACT or sc_mean < 0.03, sc_mean
 
 
 @pytest.mark.parametrize("precision,rtol", [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", 6e-2)])
@@ -219,6 +222,37 @@ def test_graph_replay_is_bitwise_eager(task, batch, precision):
     torch.cuda.synchronize()
     assert all(torch.equal(got[b]["mask_pred"], want[b]["mask_pred"]) and torch.equal(got[b]["instances"].pred_masks, want[b]["instances"].pred_masks)
                for b in range(batch))
+
+
+def test_golden_panoptic_1024_box_full_model_vs_the_reference_itself():
+    """The headline configuration against the REFERENCE's own outputs, not through the oracle: full 24-layer model,
+    1024 x 1024 canvas holding the 768 x 1024 box of a 480 x 640 original, results at 480 x 640 (tests/golden/make_golden.py
+    panoptic_1024_box: the reference's `eval_seg` run on the CPU).  Headline arithmetic; stage signatures at 1e-3 of their range, the label maps
+    and segments in full."""
+    case, z, cfg, stages, outs, results = _run_golden("panoptic_1024_box", "f16x3")
+    errs, pm = _stage_checks(z, case, cfg, stages, outs, 1e-3, "f16x3:")
+    r = results[0]
+    assert tuple(r["sem_seg"].shape[-2:]) == (480, 640) == tuple(r["panoptic_seg"][0].shape)
+    sem_agree = float((r["sem_seg"].argmax(0).to(torch.uint8).cpu().numpy() == z["sem_seg_argmax"]).mean())
+    pan, info = r["panoptic_seg"]
+    pan_agree = float((pan.to(torch.uint8).cpu().numpy() == z["panoptic_ids"]).mean())
+    info_same = [[s["id"], int(s["isthing"]), s["category_id"]] for s in info] == z["panoptic_info"].tolist()
+    g = torch.from_numpy(z["pred_masks_s8"])[0]
+    c = pm[0, :, ::8, ::8].cpu()
+    rel = float((g - c).abs().max() / g.abs().max())
+    flips = int(((g > 0) != (c > 0)).sum())
+    cls_err = float(np.abs(outs[0]["pred_class_name_logits"].cpu().numpy() - z["pred_class_name_logits"][0]).max() / np.abs(z["pred_class_name_logits"]).max())
+    _report(test="panoptic_1024_box", precision="f16x3", stage_err=errs, cls_err=cls_err, sem_argmax_agree=sem_agree, panoptic_agree=pan_agree,
+            panoptic_info_identical=info_same, mask_logit_rel_err_stride8=rel, flipped_stride8=flips, n_segments=len(info))
+    assert rel < 2e-5 and flips <= 2 and cls_err < 1e-4
+    assert sem_agree > 0.9999 and pan_agree > 0.9999 and info_same
+    gi = r["instances"]
+    og = np.lexsort((gi.pred_classes.cpu().numpy(), -gi.scores.cpu().numpy()))
+    ow = np.lexsort((z["inst_classes"], -z["inst_scores"]))
+    assert len(og) == len(ow) and (gi.pred_classes.cpu().numpy()[og] == z["inst_classes"][ow]).all()
+    np.testing.assert_allclose(gi.scores.cpu().numpy()[og], z["inst_scores"][ow], atol=2e-4)
+    assert tuple(gi.pred_masks.shape[-2:]) == (480, 640)
+    assert np.array_equal(gi.pred_masks.flatten(1).sum(1).cpu().numpy()[og], z["inst_mask_area"][ow])
 
 
 @pytest.mark.parametrize("precision,rtol", [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", 6e-2)])

@@ -98,6 +98,9 @@ def compare_dev(g, w_):
            "flipped_pixels": int((gm != wm).sum()), "ref_positive_pixels": int(wm.sum()), "ref_masks_empty": int((area == 0).sum()),
            "ref_masks_lt_64px": int(((area > 0) & ~big).sum()),
            "mask_logit_rel_err": float(f"{((gp - wp).abs().max() / wp.abs().max()).item():.3e}")}
+    # gate version 4 (oracle/parity_gate.py): the largest oracle |logit| at a pixel whose sign differs, relative to the logit range
+    diff = gm != wm
+    out["flip_margin_rel_max"] = float(f"{(wp.abs()[diff].max() / wp.abs().max()).item():.3e}") if bool(diff.any()) else 0.0
     if "sem_argmax" in w_ and "sem_argmax" in g:
         out["semantic_argmax_agreement"] = round(float((g["sem_argmax"] == w_["sem_argmax"].to(dev).long()).double().mean()), 6)
     if "pan_ids" in w_ and "panoptic_seg" in g:
@@ -109,15 +112,17 @@ def compare_dev(g, w_):
 def gates(r):
     lab = r.get("semantic_argmax_agreement", 1.0) >= 0.999
     big = r["mask_iou_mean_area_ge_64"]
+    margin = bool(r["flip_margin_rel_max"] <= 1e-5)
     return {"pooled": bool(r["mask_iou_pooled"] >= 0.999 and (big is None or big >= 0.999) and lab),
-            "plain_mean": bool(r["mask_iou_mean"] >= 0.999 and lab)}
+            "plain_mean": bool(r["mask_iou_mean"] >= 0.999 and lab), "flips_within_margin": margin,
+            "v4": bool(margin and r["mask_iou_mean"] >= 0.999 and lab)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sets", default="panoptic:1024:1:0-15,referring:640:4:3-15")
     ap.add_argument("--modes", default="f16x3,fp32")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_parity_wide.jsonl"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_parity_wide.jsonl"))
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--weights-seed", type=int, default=0)
@@ -204,6 +209,9 @@ def main():
                     continue
                 summ["summary"][f"{m}/{task}"] = {
                     "images": len(rs), "at_gate_pooled": sum(r["gates"]["pooled"] for r in rs), "at_gate_plain_mean": sum(r["gates"]["plain_mean"] for r in rs),
+                    "flips_within_margin": sum(r["gates"]["flips_within_margin"] for r in rs), "at_gate_v4": sum(r["gates"]["v4"] for r in rs),
+                    "flip_margin_rel_max_over_inputs_within_margin": max((r["flip_margin_rel_max"] for r in rs if r["gates"]["flips_within_margin"]), default=0.0),
+                    "inputs_outside_margin": [[r["inputs_seed"], r["image"], r["flip_margin_rel_max"], r["mask_logit_rel_err"], r["flipped_pixels"]] for r in rs if not r["gates"]["flips_within_margin"]],
                     "mask_iou_mean_min": min(r["mask_iou_mean"] for r in rs), "mask_iou_pooled_min": min(r["mask_iou_pooled"] for r in rs),
                     "mask_iou_mean_area_ge_64_min": min((r["mask_iou_mean_area_ge_64"] for r in rs if r["mask_iou_mean_area_ge_64"] is not None), default=None),
                     "mask_logit_rel_err_max": max(r["mask_logit_rel_err"] for r in rs), "flipped_pixels_max": max(r["flipped_pixels"] for r in rs),
