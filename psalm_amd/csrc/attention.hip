@@ -136,6 +136,11 @@ __global__ void __launch_bounds__(64 * NWV) window_attention_f32_mfma_kernel(con
         *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
     }
     for (int e = tid; e < NB; e += 64 * NWV) Bs[e] = bias_table[(long)e * heads + h];
+    // r05: the relative-position index of a (query, key) pair is (yi - yj + WS-1) (2 WS-1) + (xi - xj + WS-1) = c(query) - c'(key) with
+    // c'(j) = (j / WS) (2 WS-1) + j % WS; the key's part, as a BYTE offset into Bs, sits in a 288-byte LDS table instead of being re-derived per
+    // score element (two divisions by 12 and the index arithmetic: ~10 of the ~16 VALU instructions an element cost -- ISA of r04: 590 per query tile)
+    unsigned short* Ki = reinterpret_cast<unsigned short*>(Bs + NB);
+    for (int e = tid; e < N; e += 64 * NWV) Ki[e] = (unsigned short)(((e / WS) * (2 * WS - 1) + e % WS) * 4);
     float so_sc = 1.f;
     if constexpr (SO) {
         float gmax = 0.f;
@@ -179,6 +184,8 @@ __global__ void __launch_bounds__(64 * NWV) window_attention_f32_mfma_kernel(con
             qf[4] = b.x * scale; qf[5] = b.y * scale; qf[6] = b.z * scale; qf[7] = b.w * scale;
         }
         const int yi = qi / WS, xi = qi % WS;
+        const int qc4 = ((yi + WS - 1) * (2 * WS - 1) + (xi + WS - 1)) * 4;            // byte offset of this query's part of the bias index
+        const unsigned short* Kik = Ki + 4 * kk;                                        // this lane's keys: 16 tk + 4 kk + r
         const int qlab = shift > 0 ? label(qi) : 0;
         f32x4 sc[NT];
         float mx = -3.0e38f;
@@ -197,9 +204,7 @@ __global__ void __launch_bounds__(64 * NWV) window_attention_f32_mfma_kernel(con
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k1.w, qf[7], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = 16 * tk + 4 * kk + r;
-                const int yj = j / WS, xj = j % WS;
-                float v = acc[r] + Bs[(yi - yj + WS - 1) * (2 * WS - 1) + (xi - xj + WS - 1)];
+                float v = acc[r] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bs) + (qc4 - (int)Kik[16 * tk + r]));
                 if (shift > 0 && klab[tk][r] != qlab) v += -100.0f;
                 acc[r] = v;
                 mx = fmaxf(mx, v);
@@ -265,7 +270,7 @@ extern "C" int psalm_window_attention_split(const float* qkv, const float* bias_
                         (uintptr_t)split_out % 16 == 0, "psalm_window_attention_split: operand scales, bound parameters, aligned buffers");
     const int nwin = B * nWh * nWw;
     if (nwin == 0) return 0;
-    const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float);
+    const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float) + 288;                 // V rows + bias column + the key-index table
     if ((long)nwin * heads <= 320)                                        // wavefronts per (window, head): as psalm_window_attention
         hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 3>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream, qkv,
                            bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
@@ -283,7 +288,7 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
     if (nwin == 0) return 0;
     const int N = ws * ws;
     if (dtype == PSALM_F32 && ws == 12 && C % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {     // fp32 matrix-core kernel
-        const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float);
+        const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float) + (size_t)((N * 2 + 3) / 4 * 4);
         // wavefronts per (window, head): 3 only when the grid cannot give every SIMD a wavefront anyway (r02n, 1024^2 image: stage 4, 288
         // pairs: 41 -> 32 us; stage 3, 576 pairs: 48.5 -> 52.4; stage 1, 1936 pairs: 100 -> 136 -- profiles/r02n_winattn_nwv.jsonl)
         const int nwv = (long)nwin * heads <= 320 ? 3 : 1;

@@ -45,7 +45,7 @@ CASES = {
     # BASELINE.json configs[1] with what the reference's evaluation loop really feeds (r05): the full 24-layer model at
     # 1024 x 1024, a 480 x 640 original -> un-padded box 768 x 1024 inside the canvas (coco_panoptic_mapper.py:81-89), results cropped to the box
     # and resized to 480 x 640 (LP:1418-1429).  Mask logits kept at stride 8 (410 kB), label maps in full.
-    "panoptic_1024_box": dict(task="panoptic", size=1024, batch=1, layers=24, seed=7, pad=0, geometry=(768, 1024, 480, 640), mask_stride=8),
+    "panoptic_1024_box": dict(task="panoptic", size=1024, batch=1, layers=24, seed=0, pad=0, geometry=(768, 1024, 480, 640), mask_stride=8),
 }
 RNG_SEED_AT_CALL = 1234
 
