@@ -9,9 +9,18 @@ from psalm_amd import hip_ops as H
 
 
 def main():
-    ops = H.get_ops()
+    libs = [None]
+    if "--libs" in sys.argv:                                     # two builds of the library on the same box, alternating (e.g. the r04 attention build)
+        libs = sys.argv[sys.argv.index("--libs") + 1].split(",")
+    for rnd in range(2):
+        for lib in libs:
+            ops = H.Ops(os.path.join(ROOT, lib)) if lib else H.get_ops()
+            run(ops, {"round": rnd, "lib": lib or os.path.relpath(ops.lib_path, ROOT)})
+
+
+def run(ops, tag):
     g = torch.Generator().manual_seed(0)
-    out = {}
+    out = dict(tag)
     for stage, (hw, heads) in enumerate(((256, 4), (128, 8), (64, 16), (32, 32))):
         nW = (hw + 11) // 12
         C = heads * 32
@@ -29,7 +38,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out[f"stage{stage}_shift{shift}"] = {"us": round(e0.elapsed_time(e1) * 1e3 / 30, 2), "checksum": float(o.double().sum())}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
