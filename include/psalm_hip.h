@@ -27,7 +27,8 @@ const char* psalm_last_error(void);
  * written against before making any other call (psalm_amd/hip_ops.py does): a stale library loaded by a newer binding would otherwise take
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
  * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
- * 6: psalm_gemm_x3_set_products (r05); psalm_causal_attention_f32_workspace grew by one byte per 32-key tile. */
+ * 6: psalm_gemm_x3_set_products, psalm_fuse_masks, the stage-level psalm_phi_forward (r05); psalm_causal_attention_f32_workspace grew by one
+ *    byte per 32-key tile. */
 #define PSALM_ABI_VERSION 6
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -370,6 +371,35 @@ int psalm_panoptic(const float* mask, const float* score, const int* label, cons
                    float overlap_thr, void* stream);
 /* region_inference scores (llava_phi.py:387-400). */
 int psalm_region_scores(const float* logits, const float* mask_score, float* out, int K, int Q, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Stage-level entries ("C-ABI groups behind B2"; csrc/stages.hip): one call issues the launch sequence of a whole
+ * stage of PSALM.eval_seg from native code, through the op-level entries above, in the order and with the arguments psalm_amd/model.py uses
+ * -- same bits.  The caller owns every buffer; no allocation, no synchronisation.
+ *
+ * psalm_phi_forward: PhiModel.forward on inputs_embeds (transformers modeling_phi.py:343-396 as called from
+ * psalm/model/language_model/llava_phi.py:1350-1365), precision "f16x3".  Per layer (host array `layers`): w1 = [k | v | q | fc1] and
+ * w2 = [dense | fc2] in split-f16 form (rows of 2*ceil64(K) f16 + inverse row scales, psalm_split_f16), biases (b2 = dense + fc2), the layer's
+ * input LayerNorm, bnd = the 4 bound parameters of psalm_gemm_x3_split for the fc1 rows, paired = the fc1 rows of w1 / b1 are permuted for
+ * paired stores.  embeds (B*L, hidden) f32; key_mask (B, L) u8; cos / sin (L, rot) f32; hidden_out (B*L, hidden) f32 = final LayerNorm output.
+ * workspace: psalm_phi_forward_workspace(d, B, L) bytes, 256-byte aligned; gemm_workspace: split-K scratch as for psalm_gemm_x3. */
+typedef struct psalm_phi_layer {
+    const void* w1; const float* w1_scale; const float* b1;
+    const void* w2; const float* w2_scale; const float* b2;
+    const float* ln_g; const float* ln_b;
+    const float* bnd;
+    int paired;
+} psalm_phi_layer;
+typedef struct psalm_phi_desc {
+    int num_layers, hidden, intermediate, heads, head_dim, rot;
+    float ln_eps;
+    const psalm_phi_layer* layers;           /* HOST array of num_layers entries (device pointers inside) */
+    const float* final_g; const float* final_b;
+} psalm_phi_desc;
+long psalm_phi_forward_workspace(const psalm_phi_desc* d, int B, int L);
+int psalm_phi_forward(const psalm_phi_desc* d, const float* embeds, const unsigned char* key_mask, const float* cos_table, const float* sin_table,
+                      int B, int L, float* hidden_out, void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes,
+                      void* stream);
 
 #ifdef __cplusplus
 }

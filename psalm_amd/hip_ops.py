@@ -113,6 +113,16 @@ class SplitF16:
         return torch.float32                      # the values it stands for
 
 
+class _PhiLayer(ctypes.Structure):           # psalm_phi_layer of include/psalm_hip.h
+    _fields_ = [("w1", c_void_p), ("w1_scale", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("w2_scale", c_void_p), ("b2", c_void_p),
+                ("ln_g", c_void_p), ("ln_b", c_void_p), ("bnd", c_void_p), ("paired", c_int)]
+
+
+class _PhiDesc(ctypes.Structure):            # psalm_phi_desc
+    _fields_ = [("num_layers", c_int), ("hidden", c_int), ("intermediate", c_int), ("heads", c_int), ("head_dim", c_int), ("rot", c_int),
+                ("ln_eps", c_float), ("layers", ctypes.POINTER(_PhiLayer)), ("final_g", c_void_p), ("final_b", c_void_p)]
+
+
 class Ops:
     # psalm_gemm_set_tile_policy code of the library's default K loop for split-f16 GEMMs on 256 x 256 tiles (2580 K-panel form, 2581 32-deep
     # slices, 2582 slices with the all-padding m-tiles left out): what tests that switch it restore afterwards.
@@ -394,6 +404,42 @@ class Ops:
     def gemm_last_kernel(self) -> str:
         """template instantiation of this thread's last direct-to-LDS GEMM launch, as a kernel trace spells it"""
         return self._cdll_raw.psalm_gemm_last_kernel().decode()
+
+    # ------------------------------------------------------------------ stage-level entries (csrc/stages.hip)
+    def phi_desc(self, layers, hidden, intermediate, heads, head_dim, rot, ln_eps, final_g, final_b):
+        """psalm_phi_desc for psalm_phi_forward.  layers: per Phi layer a dict(w1=SplitF16, b1=, w2=SplitF16, b2=, ln_g=, ln_b=, bnd=, paired=bool)
+        of device tensors.  The returned object keeps the host array (and, through `keep`, the tensors) alive."""
+        arr = (_PhiLayer * len(layers))()
+        keep = []
+        for i, ly in enumerate(layers):
+            w1, w2 = ly["w1"], ly["w2"]
+            if not (isinstance(w1, SplitF16) and isinstance(w2, SplitF16)):
+                raise PsalmHipError("phi_desc: split-f16 weights (precision 'f16x3')")
+            arr[i] = _PhiLayer(self._p(w1.t), self._p(w1.inv_scale), self._p(ly["b1"]), self._p(w2.t), self._p(w2.inv_scale), self._p(ly["b2"]),
+                               self._p(ly["ln_g"]), self._p(ly["ln_b"]), self._p(ly["bnd"]), int(bool(ly["paired"])))
+            keep.append(ly)
+        d = _PhiDesc(len(layers), hidden, intermediate, heads, head_dim, rot, ln_eps, ctypes.cast(arr, ctypes.POINTER(_PhiLayer)),
+                     self._p(final_g), self._p(final_b))
+        d._keep = (arr, keep, final_g, final_b)
+        return d
+
+    def phi_forward(self, desc, embeds, key_mask, cos, sin, B, L):
+        """PhiModel.forward over inputs_embeds (B*L, hidden) float32 as ONE native call (psalm_phi_forward): returns the final-LayerNorm hidden
+        states (B*L, hidden) float32.  Same launches, same order, same bits as PSALM.llm's op-by-op sequence."""
+        if embeds.dtype != torch.float32 or embeds.dim() != 2 or embeds.shape[0] != B * L or embeds.shape[1] != desc.hidden:
+            raise PsalmHipError("phi_forward: float32 (B*L, hidden) embeddings")
+        self.lib.psalm_phi_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_phi_forward_workspace(ctypes.byref(desc), B, L)
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_phi_forward_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        out = self.empty(B * L, desc.hidden, dtype=torch.float32)
+        rc = self.lib.psalm_phi_forward(ctypes.byref(desc), self._p(embeds), self._p(key_mask), self._p(cos), self._p(sin), B, L, self._p(out),
+                                        c_void_p(ws.data_ptr() + off), c_long(nbytes), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES),
+                                        self._stream())
+        self._check(rc, "psalm_phi_forward")
+        return out
 
     def x3_products(self, n: int):
         """f16 products formed per algorithmic product by this thread's split-f16 GEMMs: 3 (default, fp32-class) or 1 (hi.hi only: plain f16

@@ -151,6 +151,10 @@ class PSALM:
         # the image's own) is issued after the replay, while the GPU is still inside the graph.  graph_tail = True puts the tail back into
         # the graph (and the geometry back into its key): the r01-r04 behaviour, kept for A/B measurements.
         self.len_bucket = 32
+        # Stage-level native calls (csrc/stages.hip, SURVEY section 8(b) "C-ABI groups behind B2"): the Phi decoder's ~100 launches are issued by ONE
+        # call into the library instead of one ctypes call each -- same launches, same order, same bits (tests/test_6_model_emu.py); off while
+        # bench.py's per-launch events are being recorded (they attribute time per op-level call).
+        self.c_stages = True
         self.graph_tail = False
         self.graph_stats = {"calls": 0, "replays": 0, "eager": 0, "captures": 0}
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
@@ -822,6 +826,21 @@ class PSALM:
         # f16x3: gelu(fc1) (GEMM epilogue) and the attention output leave directly as the split-f16 A operand [attn | gelu(fc1)] of the
         # [dense | fc2] GEMM -- one operand buffer, one scale per row from a magnitude bound (psalm_gemm_x3_split)
         fuse_split = self.fuse_split and (Hd + I) % 64 == 0 and Hd % 8 == 0 and "llm0.bnd" in w and cfg.head_dim == 64 and cfg.rotary_dim == 32
+        if fuse_split and self.c_stages and self.x3 and getattr(o.lib, "records", None) is None and not (H._DEBUG_BOUNDS or o.debug_bounds) \
+                and key_mask.is_contiguous():
+            key = ("phi_desc",)
+            if key not in self._cache:                # (pointers into the weight arena: built once per model instance / replica)
+                self._cache[key] = o.phi_desc([dict(w1=w[f"llm{i}.w1"], b1=w[f"llm{i}.b1"], w2=w[f"llm{i}.w2"], b2=w[f"llm{i}.b2"],
+                                                    ln_g=w[f"llm{i}.ln.g"], ln_b=w[f"llm{i}.ln.b"], bnd=w[f"llm{i}.bnd"],
+                                                    paired=self.paired.get(f"llm{i}", False)) for i in range(cfg.num_layers)],
+                                              Hd, I, cfg.num_heads, cfg.head_dim, cfg.rotary_dim, cfg.layer_norm_eps, w["llm.final.g"], w["llm.final.b"])
+            if self.llm_products != 3:
+                o.x3_products(self.llm_products)
+            try:
+                return o.phi_forward(self._cache[key], embeds, key_mask, cos, sin, B, L)
+            finally:
+                if self.llm_products != 3:
+                    o.x3_products(3)
         big = o.empty(B * L, 3 * Hd if fuse_split else 3 * Hd + I, dtype=self.adt)
         if fuse_split:
             a2 = o.empty(B * L, 2 * (Hd + I), dtype=torch.float16)

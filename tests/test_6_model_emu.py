@@ -237,3 +237,42 @@ def test_llm_single_product_side_mode_changes_the_llm_only_and_leaves_the_defaul
     assert rm < 0.2, rm
     with pytest.raises(ValueError):
         PSALM(cfg, sd, ops=ops, precision="fp32", llm_products=1)
+
+
+@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3)])
+def test_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence(task, batch):
+    """psalm_phi_forward (csrc/stages.hip; SURVEY section 8(b): the stage-level C ABI behind the model API) issues the Phi decoder's launch
+    sequence from native code -- ONE ctypes call instead of ~4 per layer.  Same launches, same order: the hidden states, and everything
+    downstream, are bit for bit those of PSALM.llm's op-by-op Python sequence (c_stages = False), on a ragged batch too; the one-product side
+    mode goes through it as well."""
+    cfg = PsalmConfig.tiny(task)
+    sd = make_state_dict(cfg, seed=11)
+    inputs = make_inputs(cfg, task, size=96, batch=batch, seed=3, num_classes=9)
+    kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
+    ops = make_ops("emu")
+    for prods in (3, 1):
+        m = PSALM(cfg, sd, ops=ops, precision="f16x3", llm_products=prods)
+        assert m.c_stages
+        sa, sb = {}, {}
+        oa = m.forward_logits(stages=sa, **kw)
+        assert ("phi_desc",) in m._cache                          # the stage-level call ran
+        m.c_stages = False
+        ob = m.forward_logits(stages=sb, **kw)
+        assert torch.equal(sa["hidden_states"], sb["hidden_states"]), prods
+        for a, b in zip(oa, ob):
+            assert torch.equal(a["pred_masks"], b["pred_masks"])
+    # the library refuses a workspace that is too small instead of writing past it
+    import ctypes
+    from ctypes import c_long, c_void_p
+    d = m._cache[("phi_desc",)]
+    ops.lib.psalm_phi_forward_workspace.restype = c_long
+    need = ops.lib.psalm_phi_forward_workspace(ctypes.byref(d), 1, 64)
+    assert need > 0
+    x = torch.zeros(64, cfg.hidden_size)
+    km = torch.ones(1, 64, dtype=torch.uint8)
+    cos, sin = m._rope(64)
+    ws = torch.zeros(need + 256, dtype=torch.uint8)
+    off = (-ws.data_ptr()) % 256
+    rc = ops.lib.psalm_phi_forward(ctypes.byref(d), c_void_p(x.data_ptr()), c_void_p(km.data_ptr()), c_void_p(cos.data_ptr()), c_void_p(sin.data_ptr()),
+                                   1, 64, c_void_p(x.data_ptr()), c_void_p(ws.data_ptr() + off), c_long(need - 1), None, c_long(0), None)
+    assert rc != 0 and b"workspace" in ops.lib.psalm_last_error()

@@ -376,6 +376,38 @@ def test_config2_padding_tiles_left_out_is_bitwise_the_plain_slice_kernel():
     _report(test="config2_padding_tiles_left_out_bitwise", identical=True)
 
 
+def test_config2_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence():
+    """psalm_phi_forward (the stage-level C ABI of the Phi decoder, csrc/stages.hip: one native call issues the ~100 launches of the 24 layers)
+    against the op-by-op Python sequence it replaces (PSALM.c_stages = False): the whole 1024 x 1024 panoptic evaluation, every output
+    tensor, bit for bit -- eagerly and through hipGraph capture / replay."""
+    from psalm_amd.model import PSALM
+    cfg, sd = _full_model("panoptic")
+    inputs = make_inputs(cfg, "panoptic", size=1024, batch=1, seed=0)
+    model = _full_psalm("panoptic", "f16x3")
+    assert model.c_stages
+    outs = {}
+    try:
+        for flag in (True, False):
+            model.c_stages = flag
+            r = model.eval_seg(**inputs)[0]
+            torch.cuda.synchronize()
+            outs[flag] = (r["mask_pred"].clone(), r["sem_seg"].clone(), r["panoptic_seg"][0].clone(), r["instances"].scores.clone(), list(r["panoptic_seg"][1]))
+    finally:
+        model.c_stages = True
+    assert ("phi_desc",) in model._cache
+    for a, b in zip(outs[True][:4], outs[False][:4]):
+        assert torch.equal(a, b)
+    assert outs[True][4] == outs[False][4]
+    graphed = PSALM(cfg, sd, precision="f16x3", use_graphs=True)
+    for _ in range(3):
+        g = graphed.eval_seg(**inputs)[0]
+    torch.cuda.synchronize()
+    assert graphed.graph_stats["captures"] == 1 and torch.equal(g["mask_pred"], outs[False][0]) and torch.equal(g["panoptic_seg"][0], outs[False][2])
+    _report(test="config2_stage_level_phi_forward_bitwise", identical=True)
+    del graphed
+    torch.cuda.empty_cache()
+
+
 def test_config2_panoptic_1024_multi_seed_default_and_fp32_control():
     """one image is a noisy gate (0.3 % positive pixels, ~10 empty reference masks, masks of a few pixels whose IoU
     moves in steps of 1/area).  Four more seeded inputs (seed 0 is the test above), same weights, the headline mode (three f16 products
