@@ -401,6 +401,50 @@ int psalm_phi_forward(const psalm_phi_desc* d, const float* embeds, const unsign
                       int B, int L, float* hidden_out, void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes,
                       void* stream);
 
+/* psalm_swin_forward: SwinTransformer.forward (swin_trans.py:608-633; blocks :194-253, window attention :117-149, patch merging :266-296, patch
+ * embedding :427-443), precision "f16x3", 12 x 12 windows, head dim 32.  GEMM weights in split-f16 form (`*_w` rows of 2*ceil64(K) f16, `*_ws`
+ * inverse row scales); qkv_bnd / fc1_bnd: the bound parameters of psalm_window_attention_split (over the v rows of qkv) / psalm_gemm_x3_split;
+ * fc1_paired: fc1 rows permuted for paired stores; rpb: relative_position_bias_table ((2*12-1)^2, heads) f32.  Stage s: `dim` channels, `heads`,
+ * `depth` blocks, the output norm (swin_trans.py:622-626) and -- but for the last stage -- the PatchMerging norm + reduction weight.
+ * images (B,3,H,W) f32; outs_host: HOST array of num_stages DEVICE pointers, stage s receives (B*h_s*w_s, dim_s) f32 tokens (post norm_s). */
+typedef struct psalm_swin_block {
+    const float* n1_g; const float* n1_b; const float* n2_g; const float* n2_b;
+    const void* qkv_w; const float* qkv_ws; const float* qkv_b; const float* qkv_bnd;
+    const void* proj_w; const float* proj_ws; const float* proj_b;
+    const void* fc1_w; const float* fc1_ws; const float* fc1_b; const float* fc1_bnd; int fc1_paired;
+    const void* fc2_w; const float* fc2_ws; const float* fc2_b;
+    const float* rpb;
+} psalm_swin_block;
+typedef struct psalm_swin_stage {
+    int depth, heads, dim;
+    const psalm_swin_block* blocks;          /* HOST array of depth entries */
+    const float* out_g; const float* out_b;
+    const float* ds_g; const float* ds_b; const void* ds_w; const float* ds_ws;   /* NULL in the last stage */
+} psalm_swin_stage;
+typedef struct psalm_swin_desc {
+    int num_stages, patch, window, pe_kpad, mlp_ratio;
+    const void* pe_w; const float* pe_ws; const float* pe_b; const float* pe_ln_g; const float* pe_ln_b;
+    const psalm_swin_stage* stages;          /* HOST array */
+} psalm_swin_desc;
+long psalm_swin_forward_workspace(const psalm_swin_desc* d, int B, int H, int W);
+int psalm_swin_forward(const psalm_swin_desc* d, const float* images, int B, int H, int W, float* const* outs_host, void* workspace,
+                       long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+
+/* psalm_projector_forward: the conv projector between Swin's last stage and the LLM (psalm/model/multimodal_projector/builder.py:365-375; the
+ * BasicBlock :85-111 with eval BatchNorm folded into the convolution weights, conv2 applied twice as in the reference).  Weights (Cout, k*k*Cin)
+ * with K order (ky, kx, c), split-f16 form.  res5 (B*h*w, in_dim) f32 NHWC tokens -> out (B*ho*wo, out_dim) f32, ho = (h - 1) / 2 + 1. */
+typedef struct psalm_projector_desc {
+    int in_dim, mid_dim, out_dim;
+    const void* c1_w; const float* c1_ws; const float* c1_b;        /* conv1 (3x3, stride 2) + bn1 folded */
+    const void* c2_w; const float* c2_ws;                            /* conv2 (3x3), first application (no norm) */
+    const void* c2f_w; const float* c2f_ws; const float* c2f_b;     /* conv2 second application + bn2 folded */
+    const void* ds_w; const float* ds_ws; const float* ds_b;        /* downsample 1x1 stride 2 + its norm folded */
+    const void* fc_w; const float* fc_ws; const float* fc_b;
+} psalm_projector_desc;
+long psalm_projector_forward_workspace(const psalm_projector_desc* d, int B, int h, int w);
+int psalm_projector_forward(const psalm_projector_desc* d, const float* res5, int B, int h, int w, float* out, void* workspace, long workspace_bytes,
+                            void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,207 @@ extern "C" int psalm_phi_forward(const psalm_phi_desc* d, const float* embeds, c
     }
     return 0;
 }
+
+// ================================================================================================= Swin tower
+//   psalm_swin_forward   SwinTransformer.forward (psalm/model/visual_prompt... swin_trans.py:608-633; blocks :194-253, window attention :117-149,
+//                        patch merging :266-296, patch embedding :427-443) for precision "f16x3": patch im2col + GEMM + LayerNorm, then per block
+//                        { norm1 + shift + window partition -> split operand; qkv GEMM; window attention -> split operand; proj GEMM; window reverse +
+//                        residual + norm2 -> split operand; fc1 GEMM with gelu -> split operand; fc2 GEMM + residual }, per stage the output norm and
+//                        (but for the last) patch merging + reduction GEMM.  The op-by-op sequence of PSALM.swin, 7 launches per block.
+static inline int c64(int v) { return (v + 63) / 64 * 64; }
+
+struct SwinGeom { int Hc[8], Wc[8], C[8]; long rows[8], rows_w[8]; };
+static SwinGeom swin_geom(const psalm_swin_desc* d, int B, int H, int W) {
+    SwinGeom g;
+    int hc = (H + d->patch - 1) / d->patch, wc = (W + d->patch - 1) / d->patch;
+    for (int s = 0; s < d->num_stages; ++s) {
+        g.Hc[s] = hc; g.Wc[s] = wc; g.C[s] = d->stages[s].dim;
+        g.rows[s] = (long)B * hc * wc;
+        const int nWh = (hc + d->window - 1) / d->window, nWw = (wc + d->window - 1) / d->window;
+        g.rows_w[s] = (long)B * nWh * nWw * d->window * d->window;
+        hc = (hc + 1) / 2; wc = (wc + 1) / 2;
+    }
+    return g;
+}
+struct SwinLayout { long x[3], xw, xwinv, qkv, aw, awinv, pw, h, hinv, hs, hsinv, cols, colsp, colsinv, total; };
+static SwinLayout swin_layout(const psalm_swin_desc* d, const SwinGeom& g) {
+    long mx = 0, mxw = 0, mqkv = 0, mpw = 0, mh = 0, mhs = 0, mrows = 0, mrw = 0, mcols = 0, mcolsp = 0;
+    for (int s = 0; s < d->num_stages; ++s) {
+        const long C = g.C[s], Kp = c64((int)C), K4 = c64((int)(d->mlp_ratio * C));
+        mx = std::max(mx, g.rows[s] * C * 4);
+        mxw = std::max(mxw, g.rows_w[s] * 2 * Kp * 2);
+        mqkv = std::max(mqkv, g.rows_w[s] * 3 * C * 4);
+        mpw = std::max(mpw, g.rows_w[s] * C * 4);
+        mh = std::max(mh, g.rows[s] * 2 * Kp * 2);
+        mhs = std::max(mhs, g.rows[s] * 2 * K4 * 2);
+        mrows = std::max(mrows, g.rows[s]);
+        mrw = std::max(mrw, g.rows_w[s]);
+        if (s + 1 < d->num_stages) {                             // patch merging: (rows / 4, 4 C) f32 and its split form
+            const long r2 = g.rows[s + 1];
+            mcols = std::max(mcols, r2 * 4 * C * 4);
+            mcolsp = std::max(mcolsp, r2 * 2 * c64((int)(4 * C)) * 2);
+        }
+    }
+    mcols = std::max(mcols, g.rows[0] * d->pe_kpad * 4);       // patch-embedding im2col and its split form
+    mcolsp = std::max(mcolsp, g.rows[0] * 2 * c64(d->pe_kpad) * 2);
+    SwinLayout o;
+    long p = 0;
+    for (int i = 0; i < 3; ++i) { o.x[i] = p; p += al256(mx); }
+    o.xw = p; p += al256(mxw);
+    o.xwinv = p; p += al256(mrw * 4);
+    o.qkv = p; p += al256(mqkv);
+    o.aw = p; p += al256(mxw);
+    o.awinv = p; p += al256(mrw * 4);
+    o.pw = p; p += al256(mpw);
+    o.h = p; p += al256(mh);
+    o.hinv = p; p += al256(mrows * 4);
+    o.hs = p; p += al256(mhs);
+    o.hsinv = p; p += al256(mrows * 4);
+    o.cols = p; p += al256(mcols);
+    o.colsp = p; p += al256(mcolsp);
+    o.colsinv = p; p += al256(mrows * 4);
+    o.total = p;
+    return o;
+}
+static int swin_check(const psalm_swin_desc* d) {
+    PSALM_CHECK_ARG(d && d->stages && d->num_stages >= 1 && d->num_stages <= 8 && d->window == 12 && d->patch >= 1 && d->pe_kpad % 8 == 0,
+                    "psalm_swin_forward: descriptor (1..8 stages, 12 x 12 windows)");
+    for (int s = 0; s < d->num_stages; ++s) {
+        const psalm_swin_stage* st = &d->stages[s];
+        PSALM_CHECK_ARG(st->blocks && st->depth >= 1 && st->dim % 8 == 0 && st->dim <= 2048 && st->dim == st->heads * 32,
+                        "psalm_swin_forward: stage dims multiples of 8, <= 2048, head dim 32");
+    }
+    return 0;
+}
+extern "C" long psalm_swin_forward_workspace(const psalm_swin_desc* d, int B, int H, int W) {
+    if (swin_check(d) != 0 || B <= 0 || H <= 0 || W <= 0) return -1;
+    return swin_layout(d, swin_geom(d, B, H, W)).total;
+}
+
+extern "C" int psalm_swin_forward(const psalm_swin_desc* d, const float* images, int B, int H, int W, float* const* outs_host, void* workspace,
+                                  long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    if (swin_check(d) != 0) return -1;
+    PSALM_CHECK_ARG(images && outs_host && workspace && B > 0 && H > 0 && W > 0, "psalm_swin_forward: null argument");
+    const SwinGeom g = swin_geom(d, B, H, W);
+    const SwinLayout lo = swin_layout(d, g);
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_swin_forward: workspace of psalm_swin_forward_workspace() bytes, 256-byte aligned");
+    char* ws = (char*)workspace;
+    float* X[3] = {(float*)(ws + lo.x[0]), (float*)(ws + lo.x[1]), (float*)(ws + lo.x[2])};
+    void* xw = ws + lo.xw; float* xwinv = (float*)(ws + lo.xwinv);
+    float* qkv = (float*)(ws + lo.qkv);
+    void* aw = ws + lo.aw; float* awinv = (float*)(ws + lo.awinv);
+    float* pw = (float*)(ws + lo.pw);
+    void* hsp = ws + lo.h; float* hinv = (float*)(ws + lo.hinv);
+    void* hs = ws + lo.hs; float* hsinv = (float*)(ws + lo.hsinv);
+    float* cols = (float*)(ws + lo.cols); void* colsp = ws + lo.colsp; float* colsinv = (float*)(ws + lo.colsinv);
+    const int wsz = d->window;
+    const float eps = 1e-5f;
+    int rc;
+#define SW(call) do { rc = (call); if (rc) return rc; } while (0)
+    // ---- patch embedding: im2col (K order c, ky, kx) -> split -> GEMM -> LayerNorm
+    {
+        const int M = (int)g.rows[0], Kpe = d->pe_kpad, Kp = c64(Kpe), E = g.C[0];
+        SW(psalm_patch_im2col(images, cols, PSALM_F32, B, 3, H, W, d->patch, Kpe, stream));
+        SW(psalm_split_f16(cols, Kpe, colsp, 2L * Kp, colsinv, M, Kpe, stream));
+        SW(psalm_gemm_x3(colsp, 2L * Kp, colsinv, d->pe_w, 2L * Kp, d->pe_ws, Kp, d->pe_b, nullptr, 0, X[1], E, M, E, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        SW(psalm_layernorm3(X[1], PSALM_F32, E, X[0], PSALM_F32, E, nullptr, 0, nullptr, 0, nullptr, 0, d->pe_ln_g, d->pe_ln_b, M, E, eps, stream));
+    }
+    int cur = 0;                                                // X[cur] holds the stream x
+    for (int s = 0; s < d->num_stages; ++s) {
+        const psalm_swin_stage* st = &d->stages[s];
+        const int C = g.C[s], Kp = c64(C), N4 = d->mlp_ratio * C, K4 = c64(N4), Hc = g.Hc[s], Wc = g.Wc[s];
+        const int M = (int)g.rows[s], Mw = (int)g.rows_w[s];
+        const int nWh = (Hc + wsz - 1) / wsz, nWw = (Wc + wsz - 1) / wsz;
+        for (int b = 0; b < st->depth; ++b) {
+            const psalm_swin_block* bl = &st->blocks[b];
+            const int shift = (b % 2 == 0) ? 0 : wsz / 2;
+            float* x = X[cur];
+            float* xn = X[(cur + 1) % 3];
+            float* xo = X[(cur + 2) % 3];
+            SW(psalm_swin_window_gather_split(x, xw, xwinv, bl->n1_g, bl->n1_b, B, Hc, Wc, C, wsz, shift, eps, stream));
+            SW(psalm_gemm_x3(xw, 2L * Kp, xwinv, bl->qkv_w, 2L * Kp, bl->qkv_ws, Kp, bl->qkv_b, nullptr, 0, qkv, 3L * C, Mw, 3 * C, 0, 0, gemm_workspace,
+                             gemm_workspace_bytes, stream));
+            if (Kp != C) SW(psalm_memset_zero(aw, (long)Mw * 2 * Kp * 2, stream));
+            SW(psalm_window_attention_split(qkv, bl->rpb, xwinv, bl->qkv_bnd, aw, Kp, awinv, B, nWh, nWw, C, st->heads, wsz, shift, stream));
+            SW(psalm_gemm_x3(aw, 2L * Kp, awinv, bl->proj_w, 2L * Kp, bl->proj_ws, Kp, bl->proj_b, nullptr, 0, pw, C, Mw, C, 0, 0, gemm_workspace,
+                             gemm_workspace_bytes, stream));
+            SW(psalm_swin_window_merge_ln_split(pw, x, xn, hsp, hinv, bl->n2_g, bl->n2_b, B, Hc, Wc, C, wsz, shift, eps, stream));
+            if (K4 != N4) SW(psalm_memset_zero(hs, (long)M * 2 * K4 * 2, stream));
+            SW(psalm_gemm_x3_split(hsp, 2L * Kp, hinv, bl->fc1_w, 2L * Kp, bl->fc1_ws, Kp, bl->fc1_b, nullptr, 0, M, N4, /*gelu (erf)*/ 2, 0, hs, 2L * K4, K4, 0, 0,
+                                   bl->fc1_paired, hsinv, bl->fc1_bnd, 0, gemm_workspace, gemm_workspace_bytes, stream));
+            SW(psalm_gemm_x3(hs, 2L * K4, hsinv, bl->fc2_w, 2L * K4, bl->fc2_ws, K4, bl->fc2_b, xn, C, xo, C, M, C, 0, 0, gemm_workspace, gemm_workspace_bytes,
+                             stream));
+            cur = (cur + 2) % 3;
+        }
+        float* x = X[cur];
+        SW(psalm_layernorm3(x, PSALM_F32, C, outs_host[s], PSALM_F32, C, nullptr, 0, nullptr, 0, nullptr, 0, st->out_g, st->out_b, M, C, eps, stream));
+        if (s + 1 < d->num_stages) {
+            PSALM_CHECK_ARG(st->ds_w && st->ds_ws && st->ds_g && st->ds_b, "psalm_swin_forward: downsample weights missing");
+            const int M2 = (int)g.rows[s + 1], K = 4 * C, Kq = c64(K), C2 = g.C[s + 1];
+            SW(psalm_patch_merge_ln(x, PSALM_F32, cols, PSALM_F32, st->ds_g, st->ds_b, B, Hc, Wc, C, eps, stream));
+            SW(psalm_split_f16(cols, K, colsp, 2L * Kq, colsinv, M2, K, stream));
+            float* xn = X[(cur + 1) % 3];
+            SW(psalm_gemm_x3(colsp, 2L * Kq, colsinv, st->ds_w, 2L * Kq, st->ds_ws, Kq, nullptr, nullptr, 0, xn, C2, M2, C2, 0, 0, gemm_workspace,
+                             gemm_workspace_bytes, stream));
+            cur = (cur + 1) % 3;
+        }
+    }
+#undef SW
+    return 0;
+}
+
+// ================================================================================================= projector
+//   psalm_projector_forward   the conv projector (psalm/model/multimodal_projector/builder.py:365-375; BasicBlock :85-111 with eval BatchNorm
+//                             folded into the convolution weights and `conv2` applied twice, as the reference does): 3x3 s2 conv + ReLU, 3x3 conv,
+//                             1x1 s2 shortcut, 3x3 conv + shortcut + ReLU, linear.  Convolutions = im2col straight into split-f16 form + GEMM.
+struct ProjLayout { long colsA, invA, y1, colsB, invB, y2, ds, y3, y3p, y3inv, total; int ho, wo; };
+static ProjLayout proj_layout(const psalm_projector_desc* d, int B, int h, int w) {
+    ProjLayout o;
+    o.ho = (h + 2 - 3) / 2 + 1; o.wo = (w + 2 - 3) / 2 + 1;
+    const long Mi = (long)B * o.ho * o.wo, Cin = d->in_dim, Cm = d->mid_dim;
+    long p = 0;
+    o.colsA = p; p += al256(Mi * 2 * c64((int)(9 * Cin)) * 2);   // patches of res5 (3x3) -- reused for the 1x1 shortcut patches
+    o.invA = p; p += al256(Mi * 4);
+    o.y1 = p; p += al256(Mi * Cm * 4);
+    o.colsB = p; p += al256(Mi * 2 * c64((int)(9 * Cm)) * 2);
+    o.invB = p; p += al256(Mi * 4);
+    o.y2 = p; p += al256(Mi * Cm * 4);
+    o.ds = p; p += al256(Mi * Cm * 4);
+    o.y3 = p; p += al256(Mi * Cm * 4);
+    o.y3p = p; p += al256(Mi * 2 * c64((int)Cm) * 2);
+    o.y3inv = p; p += al256(Mi * 4);
+    o.total = p;
+    return o;
+}
+extern "C" long psalm_projector_forward_workspace(const psalm_projector_desc* d, int B, int h, int w) {
+    if (!d || B <= 0 || h <= 0 || w <= 0 || d->in_dim % 8 || d->mid_dim % 8) return -1;
+    return proj_layout(d, B, h, w).total;
+}
+extern "C" int psalm_projector_forward(const psalm_projector_desc* d, const float* res5, int B, int h, int w, float* out, void* workspace,
+                                       long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    PSALM_CHECK_ARG(d && res5 && out && workspace && B > 0 && d->in_dim % 8 == 0 && d->mid_dim % 8 == 0, "psalm_projector_forward: arguments (channel counts multiples of 8)");
+    const ProjLayout lo = proj_layout(d, B, h, w);
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_projector_forward: workspace of psalm_projector_forward_workspace() bytes, 256-byte aligned");
+    char* ws = (char*)workspace;
+    const int Mi = B * lo.ho * lo.wo, Cin = d->in_dim, Cm = d->mid_dim, KA = 9 * Cin, KB = 9 * Cm;
+    void* colsA = ws + lo.colsA; float* invA = (float*)(ws + lo.invA);
+    void* colsB = ws + lo.colsB; float* invB = (float*)(ws + lo.invB);
+    float* y1 = (float*)(ws + lo.y1); float* y2 = (float*)(ws + lo.y2); float* ds = (float*)(ws + lo.ds); float* y3 = (float*)(ws + lo.y3);
+    void* y3p = ws + lo.y3p; float* y3inv = (float*)(ws + lo.y3inv);
+    int rc;
+#define PJ(call) do { rc = (call); if (rc) return rc; } while (0)
+    PJ(psalm_im2col_split_f16(res5, colsA, invA, B, h, w, Cin, 3, 2, 1, stream));
+    PJ(psalm_gemm_x3(colsA, 2L * c64(KA), invA, d->c1_w, 2L * c64(KA), d->c1_ws, c64(KA), d->c1_b, nullptr, 0, y1, Cm, Mi, Cm, /*relu*/ 1, 0, gemm_workspace, gemm_workspace_bytes, stream));
+    PJ(psalm_im2col_split_f16(y1, colsB, invB, B, lo.ho, lo.wo, Cm, 3, 1, 1, stream));
+    PJ(psalm_gemm_x3(colsB, 2L * c64(KB), invB, d->c2_w, 2L * c64(KB), d->c2_ws, c64(KB), nullptr, nullptr, 0, y2, Cm, Mi, Cm, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+    PJ(psalm_im2col_split_f16(res5, colsA, invA, B, h, w, Cin, 1, 2, 0, stream));
+    PJ(psalm_gemm_x3(colsA, 2L * c64(Cin), invA, d->ds_w, 2L * c64(Cin), d->ds_ws, c64(Cin), d->ds_b, nullptr, 0, ds, Cm, Mi, Cm, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+    PJ(psalm_im2col_split_f16(y2, colsB, invB, B, lo.ho, lo.wo, Cm, 3, 1, 1, stream));
+    PJ(psalm_gemm_x3(colsB, 2L * c64(KB), invB, d->c2f_w, 2L * c64(KB), d->c2f_ws, c64(KB), d->c2f_b, ds, Cm, y3, Cm, Mi, Cm, /*relu after the residual*/ 1 | 16, 0,
+                     gemm_workspace, gemm_workspace_bytes, stream));
+    PJ(psalm_split_f16(y3, Cm, y3p, 2L * c64(Cm), y3inv, Mi, Cm, stream));
+    PJ(psalm_gemm_x3(y3p, 2L * c64(Cm), y3inv, d->fc_w, 2L * c64(Cm), d->fc_ws, c64(Cm), d->fc_b, nullptr, 0, out, d->out_dim, Mi, d->out_dim, 0, 0, gemm_workspace,
+                     gemm_workspace_bytes, stream));
+#undef PJ
+    return 0;
+}

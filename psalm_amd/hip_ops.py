@@ -123,6 +123,27 @@ class _PhiDesc(ctypes.Structure):            # psalm_phi_desc
                 ("ln_eps", c_float), ("layers", ctypes.POINTER(_PhiLayer)), ("final_g", c_void_p), ("final_b", c_void_p)]
 
 
+class _SwinBlock(ctypes.Structure):          # psalm_swin_block
+    _fields_ = [(n, c_void_p) for n in ("n1_g", "n1_b", "n2_g", "n2_b", "qkv_w", "qkv_ws", "qkv_b", "qkv_bnd", "proj_w", "proj_ws", "proj_b",
+                                         "fc1_w", "fc1_ws", "fc1_b", "fc1_bnd")] + [("fc1_paired", c_int)] + \
+               [(n, c_void_p) for n in ("fc2_w", "fc2_ws", "fc2_b", "rpb")]
+
+
+class _SwinStage(ctypes.Structure):          # psalm_swin_stage
+    _fields_ = [("depth", c_int), ("heads", c_int), ("dim", c_int), ("blocks", ctypes.POINTER(_SwinBlock)), ("out_g", c_void_p), ("out_b", c_void_p),
+                ("ds_g", c_void_p), ("ds_b", c_void_p), ("ds_w", c_void_p), ("ds_ws", c_void_p)]
+
+
+class _SwinDesc(ctypes.Structure):           # psalm_swin_desc
+    _fields_ = [("num_stages", c_int), ("patch", c_int), ("window", c_int), ("pe_kpad", c_int), ("mlp_ratio", c_int), ("pe_w", c_void_p),
+                ("pe_ws", c_void_p), ("pe_b", c_void_p), ("pe_ln_g", c_void_p), ("pe_ln_b", c_void_p), ("stages", ctypes.POINTER(_SwinStage))]
+
+
+class _ProjDesc(ctypes.Structure):           # psalm_projector_desc
+    _fields_ = [("in_dim", c_int), ("mid_dim", c_int), ("out_dim", c_int)] + \
+               [(n, c_void_p) for n in ("c1_w", "c1_ws", "c1_b", "c2_w", "c2_ws", "c2f_w", "c2f_ws", "c2f_b", "ds_w", "ds_ws", "ds_b", "fc_w", "fc_ws", "fc_b")]
+
+
 class Ops:
     # psalm_gemm_set_tile_policy code of the library's default K loop for split-f16 GEMMs on 256 x 256 tiles (2580 K-panel form, 2581 32-deep
     # slices, 2582 slices with the all-padding m-tiles left out): what tests that switch it restore afterwards.
@@ -422,6 +443,84 @@ class Ops:
                      self._p(final_g), self._p(final_b))
         d._keep = (arr, keep, final_g, final_b)
         return d
+
+    def swin_desc(self, w, depths, heads, dims, patch, window, pe_kpad, mlp_ratio, paired):
+        """psalm_swin_desc from the model's weight table `w` (names as PSALM._prepare_weights lays them out: swin{s}.{b}.qkv.w ...)."""
+        keep, stages = [], (_SwinStage * len(depths))()
+
+        def sp(name):                                # split-f16 weight -> (rows pointer, scales pointer)
+            t = w[name]
+            if not isinstance(t, SplitF16):
+                raise PsalmHipError(f"swin_desc: {name} is not in split-f16 form (precision 'f16x3')")
+            return self._p(t.t), self._p(t.inv_scale)
+        for s_, (depth, nh, dim) in enumerate(zip(depths, heads, dims)):
+            blocks = (_SwinBlock * depth)()
+            for b in range(depth):
+                q = f"swin{s_}.{b}."
+                qw, qs = sp(q + "qkv.w"); pw_, ps_ = sp(q + "proj.w"); f1w, f1s = sp(q + "fc1.w"); f2w, f2s = sp(q + "fc2.w")
+                blocks[b] = _SwinBlock(self._p(w[q + "n1.g"]), self._p(w[q + "n1.b"]), self._p(w[q + "n2.g"]), self._p(w[q + "n2.b"]), qw, qs,
+                                       self._p(w[q + "qkv.b"]), self._p(w[q + "qkv.bnd"]), pw_, ps_, self._p(w[q + "proj.b"]), f1w, f1s,
+                                       self._p(w[q + "fc1.b"]), self._p(w[q + "fc1.bnd"]), int(bool(paired.get(q + "fc1", False))), f2w, f2s,
+                                       self._p(w[q + "fc2.b"]), self._p(w[q + "rpb"]))
+            keep.append(blocks)
+            last = s_ == len(depths) - 1
+            dw, dsc = (c_void_p(0), c_void_p(0)) if last else sp(f"swin{s_}.ds.red.w")
+            stages[s_] = _SwinStage(depth, nh, dim, ctypes.cast(blocks, ctypes.POINTER(_SwinBlock)), self._p(w[f"swin.out{s_}.g"]),
+                                    self._p(w[f"swin.out{s_}.b"]), self._p(None if last else w[f"swin{s_}.ds.ln.g"]),
+                                    self._p(None if last else w[f"swin{s_}.ds.ln.b"]), dw, dsc)
+        pw0, ps0 = sp("swin.pe.w")
+        d = _SwinDesc(len(depths), patch, window, pe_kpad, mlp_ratio, pw0, ps0, self._p(w["swin.pe.b"]), self._p(w["swin.pe.ln.g"]),
+                      self._p(w["swin.pe.ln.b"]), ctypes.cast(stages, ctypes.POINTER(_SwinStage)))
+        d._keep = (keep, stages, w)
+        d._dims = list(dims)
+        return d
+
+    def swin_forward(self, desc, images):
+        """SwinTransformer.forward as ONE native call (psalm_swin_forward): images (B,3,H,W) float32 -> [(tokens (B*h*w, C) float32, h, w)] per stage."""
+        B, _, H, W = images.shape
+        self.lib.psalm_swin_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_swin_forward_workspace(ctypes.byref(desc), B, H, W)
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_swin_forward_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        outs, hc, wc = [], (H + desc.patch - 1) // desc.patch, (W + desc.patch - 1) // desc.patch
+        for C in desc._dims:
+            outs.append((self.empty(B * hc * wc, C, dtype=torch.float32), hc, wc))
+            hc, wc = (hc + 1) // 2, (wc + 1) // 2
+        ptrs = (c_void_p * len(outs))(*[t.data_ptr() for t, _, _ in outs])
+        rc = self.lib.psalm_swin_forward(ctypes.byref(desc), self._p(images), B, H, W, ptrs, c_void_p(ws.data_ptr() + off), c_long(nbytes),
+                                         self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_swin_forward")
+        return outs
+
+    def projector_desc(self, w):
+        def sp(name):
+            t = w[name]
+            if not isinstance(t, SplitF16):
+                raise PsalmHipError(f"projector_desc: {name} is not in split-f16 form")
+            return self._p(t.t), self._p(t.inv_scale)
+        c1, c2, c2f, ds, fc = sp("proj.c1.w"), sp("proj.c2.w"), sp("proj.c2f.w"), sp("proj.ds.w"), sp("proj.fc.w")
+        mid, cin = w["proj.c1.w"].t.shape[0], w["proj.ds.w"].K
+        d = _ProjDesc(cin, mid, w["proj.fc.w"].t.shape[0], c1[0], c1[1], self._p(w["proj.c1.b"]), c2[0], c2[1], c2f[0], c2f[1], self._p(w["proj.c2f.b"]),
+                      ds[0], ds[1], self._p(w["proj.ds.b"]), fc[0], fc[1], self._p(w["proj.fc.b"]))
+        d._keep = w
+        return d
+
+    def projector_forward(self, desc, res5, B, h, w_):
+        """The conv projector as ONE native call (psalm_projector_forward): res5 (B*h*w, C) float32 -> ((B*ho*wo, hidden) float32, ho*wo)."""
+        self.lib.psalm_projector_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_projector_forward_workspace(ctypes.byref(desc), B, h, w_)
+        if nbytes < 0:
+            raise PsalmHipError("psalm_projector_forward_workspace: bad descriptor / geometry")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+        out = self.empty(B * ho * wo, desc.out_dim, dtype=torch.float32)
+        rc = self.lib.psalm_projector_forward(ctypes.byref(desc), self._p(res5), B, h, w_, self._p(out), c_void_p(ws.data_ptr() + off), c_long(nbytes),
+                                              self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_projector_forward")
+        return out, ho * wo
 
     def phi_forward(self, desc, embeds, key_mask, cos, sin, B, L):
         """PhiModel.forward over inputs_embeds (B*L, hidden) float32 as ONE native call (psalm_phi_forward): returns the final-LayerNorm hidden

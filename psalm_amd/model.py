@@ -511,11 +511,21 @@ class PSALM:
         return self._cache[key]
 
     # ======================================================================================= Swin + projector
+    def _swin_dims(self):
+        return [self.cfg.swin_embed_dim * (2 ** s) for s in range(len(self.cfg.swin_depths))]
+
     def swin(self, images):
         """swin_trans.py:608-633.  images (B,3,H,W) fp32 on device -> [(tokens (B*h*w, C) adt, h, w)] x 4 (post norm_i)."""
         o, w, cfg = self.ops, self.w, self.cfg
         B, _, Hi, Wi = images.shape
         ps, ws = cfg.swin_patch, cfg.swin_window
+        if (self.c_stages and self.x3 and self.fuse_split and ws == 12 and getattr(o.lib, "records", None) is None and not (H._DEBUG_BOUNDS or o.debug_bounds)
+                and all(c % 8 == 0 and c <= 2048 and c == 32 * h for c, h in zip(self._swin_dims(), cfg.swin_heads))
+                and all((f"swin{s}.{b}.fc1.bnd" in w) and (cfg.swin_mlp_ratio * c) % 8 == 0 for s, (d_, c) in enumerate(zip(cfg.swin_depths, self._swin_dims())) for b in range(d_))):
+            key = ("swin_desc",)                       # stage-level native call (csrc/stages.hip): the tower's ~180 launches from ONE ctypes call
+            if key not in self._cache:
+                self._cache[key] = o.swin_desc(w, cfg.swin_depths, cfg.swin_heads, self._swin_dims(), ps, ws, self.pe_kpad, cfg.swin_mlp_ratio, self.paired)
+            return o.swin_forward(self._cache[key], images)
         cols = o.patch_im2col(images, ps, self.pe_kpad, out_dtype=self.adt)
         Hc, Wc = (Hi + ps - 1) // ps, (Wi + ps - 1) // ps
         x = o.gemm(cols, w["swin.pe.w"], w["swin.pe.b"], out_dtype=torch.float32)
@@ -566,6 +576,12 @@ class PSALM:
             y = o.conv2d_nhwc(y, B, ho, wo, w["proj.c2f.w"], 3, 1, 1, bias=w["proj.c2f.b"], residual=ds,
                               act=H.ACT_RELU | H.ACT_POST_RESIDUAL)
             return o.gemm(y, w["proj.fc.w"], w["proj.fc.b"], out_dtype=torch.float32), ho * wo
+        if (self.c_stages and self.x3 and res5.dtype == torch.float32 and res5.shape[-1] % 8 == 0 and w["proj.c1.w"].shape[0] % 8 == 0
+                and getattr(o.lib, "records", None) is None and all(isinstance(w[k], H.SplitF16) for k in ("proj.c1.w", "proj.c2.w", "proj.c2f.w", "proj.ds.w", "proj.fc.w"))):
+            key = ("proj_desc",)                       # stage-level native call (csrc/stages.hip)
+            if key not in self._cache:
+                self._cache[key] = o.projector_desc(w)
+            return o.projector_forward(self._cache[key], res5, B, h, w_)
         im2col = o.im2col_split if (self.x3 and res5.shape[-1] % 8 == 0) else o.im2col_nhwc   # f16x3: patches straight into split form
         c1 = im2col(res5, B, h, w_, 3, 2, 1)
         y = o.gemm(c1, w["proj.c1.w"], w["proj.c1.b"], act=H.ACT_RELU, out_dtype=self.adt)

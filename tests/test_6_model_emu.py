@@ -240,8 +240,8 @@ def test_llm_single_product_side_mode_changes_the_llm_only_and_leaves_the_defaul
 
 
 @pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3)])
-def test_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence(task, batch):
-    """psalm_phi_forward (csrc/stages.hip; SURVEY section 8(b): the stage-level C ABI behind the model API) issues the Phi decoder's launch
+def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
+    """psalm_swin_forward / psalm_phi_forward (csrc/stages.hip; SURVEY section 8(b): the stage-level C ABI behind the model API) issues the Phi decoder's launch
     sequence from native code -- ONE ctypes call instead of ~4 per layer.  Same launches, same order: the hidden states, and everything
     downstream, are bit for bit those of PSALM.llm's op-by-op Python sequence (c_stages = False), on a ragged batch too; the one-product side
     mode goes through it as well."""
@@ -259,6 +259,10 @@ def test_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence(task, batch):
         m.c_stages = False
         ob = m.forward_logits(stages=sb, **kw)
         assert torch.equal(sa["hidden_states"], sb["hidden_states"]), prods
+        assert ("swin_desc",) in m._cache and ("proj_desc",) in m._cache        # ... the Swin tower's (psalm_swin_forward) and the projector's
+        for (ta, ha, wa), (tb, hb, wb) in zip(sa["feats"], sb["feats"]):
+            assert (ha, wa) == (hb, wb) and torch.equal(ta, tb)
+        assert torch.equal(sa["image_tokens"], sb["image_tokens"])
         for a, b in zip(oa, ob):
             assert torch.equal(a["pred_masks"], b["pred_masks"])
     # the library refuses a workspace that is too small instead of writing past it
