@@ -445,6 +445,33 @@ long psalm_projector_forward_workspace(const psalm_projector_desc* d, int B, int
 int psalm_projector_forward(const psalm_projector_desc* d, const float* res5, int B, int h, int w, float* out, void* workspace, long workspace_bytes,
                             void* gemm_workspace, long gemm_workspace_bytes, void* stream);
 
+/* psalm_pixel_decoder_forward: MSDeformAttnPixelDecoder.forward_features for ONE image (msdeformattn.py:268-315; encoder layer :57-72;
+ * MSDeformAttn ops/modules/ms_deform_attn.py:82-124), precision "f16x3", 3 levels x 4 points, head dim 32.  feats_host: HOST array of the 4 DEVICE token
+ * buffers res2 .. res5 of the image ((h_i*w_i, in_dims[i]) f32), hw_host: their (h, w) pairs; lvl_pos (S, D) f32 = sine position embedding + level embedding of
+ * the level-concatenated tokens (res5 | res4 | res3; S = their total).  Outputs: mask_features (h_2*w_2, mask_dim) f32, ms_out (S, D) f32 (the encoder
+ * output, level-concatenated).  Per encoder layer: ow = [sampling_offsets ; attention_weights] stacked; l1_bnd / l1_paired as psalm_gemm_x3_split. */
+typedef struct psalm_pd_enc_layer {
+    const void* value_w; const float* value_ws; const float* value_b;
+    const void* ow_w; const float* ow_ws; const float* ow_b;
+    const void* out_w; const float* out_ws; const float* out_b;
+    const float* n1_g; const float* n1_b;
+    const void* l1_w; const float* l1_ws; const float* l1_b; const float* l1_bnd; int l1_paired;
+    const void* l2_w; const float* l2_ws; const float* l2_b;
+    const float* n2_g; const float* n2_b;
+} psalm_pd_enc_layer;
+typedef struct psalm_pd_desc {
+    int D, G, M, num_layers, ffn, mask_dim;
+    int in_dims[4];                                                  /* channels of res2, res3, res4, res5 */
+    const void* ip_w[3]; const float* ip_ws[3]; const float* ip_b[3]; const float* ip_gn_g[3]; const float* ip_gn_b[3];   /* input_proj of res5, res4, res3 */
+    const void* adapter_w; const float* adapter_ws; const float* adapter_b; const float* adapter_gn_g; const float* adapter_gn_b;
+    const void* layer_w; const float* layer_ws; const float* layer_b; const float* layer_gn_g; const float* layer_gn_b;
+    const void* mf_w; const float* mf_ws; const float* mf_b;
+    const psalm_pd_enc_layer* layers;                                /* HOST array */
+} psalm_pd_desc;
+long psalm_pixel_decoder_forward_workspace(const psalm_pd_desc* d, const int* hw_host);
+int psalm_pixel_decoder_forward(const psalm_pd_desc* d, const float* const* feats_host, const int* hw_host, const float* lvl_pos, float* mask_features,
+                                float* ms_out, void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

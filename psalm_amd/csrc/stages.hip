@@ -311,3 +311,149 @@ extern "C" int psalm_projector_forward(const psalm_projector_desc* d, const floa
 #undef PJ
     return 0;
 }
+
+// ================================================================================================= pixel decoder (one image)
+//   psalm_pixel_decoder_forward   MSDeformAttnPixelDecoder.forward_features for ONE image (Mask2Former_Simplify/modeling/pixel_decoder/
+//                                 msdeformattn.py:268-315; encoder layer :57-72, MSDeformAttn ops/modules/ms_deform_attn.py:82-124): input
+//                                 projections + GroupNorm of res5 / res4 / res3 into one level-concatenated token buffer, N encoder layers
+//                                 { value / [offsets | weights] GEMMs, fused deformable gather, output GEMM + residual + LayerNorm, FFN with the ReLU(linear1)
+//                                 rows leaving as linear2's split operand, + residual + LayerNorm }, then the FPN step on res2 (adapter + GroupNorm,
+//                                 up-sample + add, 3x3 conv + GroupNorm) and the mask-feature 1x1 convolution.  The op-by-op sequence of PSALM.pixel_decoder.
+struct PdGeom { int h[4], w[4]; long start[3], S, HW2; };
+static PdGeom pd_geom(const int* hw_host) {                    // hw_host: (h, w) of res2, res3, res4, res5
+    PdGeom g;
+    for (int i = 0; i < 4; ++i) { g.h[i] = hw_host[2 * i]; g.w[i] = hw_host[2 * i + 1]; }
+    g.start[0] = 0;                                             // level order of the encoder: res5, res4, res3
+    g.start[1] = (long)g.h[3] * g.w[3];
+    g.start[2] = g.start[1] + (long)g.h[2] * g.w[2];
+    g.S = g.start[2] + (long)g.h[1] * g.w[1];
+    g.HW2 = (long)g.h[0] * g.w[0];
+    return g;
+}
+struct PdLayout { long tokp, tokinv, t, gnws, src[2], x1, sp1, inv1, sp2, inv2, sp3, inv3, qin, value, ow, att, hdd, hddinv, lat, lat2, y, cols, colsinv, y2, total; };
+static PdLayout pd_layout(const psalm_pd_desc* d, const PdGeom& g) {
+    const long D = d->D, S = g.S, HW2 = g.HW2, KpD = c64((int)D), Kf = c64(d->ffn);
+    long mtok = 0, mrows = 0;
+    for (int i = 0; i < 4; ++i) {
+        const long r = (long)g.h[i] * g.w[i];
+        mtok = std::max(mtok, r * 2 * c64(d->in_dims[i]) * 2);
+        mrows = std::max(mrows, r);
+    }
+    mrows = std::max(mrows, S);
+    PdLayout o;
+    long p = 0;
+    o.tokp = p; p += al256(mtok);
+    o.tokinv = p; p += al256(mrows * 4);
+    o.t = p; p += al256(std::max(S, HW2) * D * 4);
+    o.gnws = p; p += al256((std::max(S, HW2) / 64 + 2) * (long)d->G * 2 * 4);
+    o.src[0] = p; p += al256(S * D * 4);
+    o.src[1] = p; p += al256(S * D * 4);
+    o.x1 = p; p += al256(S * D * 4);
+    o.sp1 = p; p += al256(S * 2 * KpD * 2); o.inv1 = p; p += al256(S * 4);       // src_s (linear1 operand) / on-the-fly splits
+    o.sp2 = p; p += al256(S * 2 * KpD * 2); o.inv2 = p; p += al256(S * 4);       // src_a (next layer's value operand)
+    o.sp3 = p; p += al256(S * 2 * KpD * 2); o.inv3 = p; p += al256(S * 4);       // qin   (next layer's offset / weight operand)
+    o.qin = p; p += al256(S * D * 4);
+    o.value = p; p += al256(S * D * 4);
+    o.ow = p; p += al256(S * (long)d->M * 3 * 4 * 3 * 4);
+    o.att = p; p += al256(S * D * 4);
+    o.hdd = p; p += al256(S * 2 * Kf * 2); o.hddinv = p; p += al256(S * 4);
+    o.lat = p; p += al256(HW2 * D * 4);
+    o.lat2 = p; p += al256(HW2 * D * 4);
+    o.y = p; p += al256(HW2 * D * 4);
+    o.cols = p; p += al256(HW2 * 2 * c64((int)(9 * D)) * 2); o.colsinv = p; p += al256(HW2 * 4);
+    o.y2 = p; p += al256(HW2 * D * 4);
+    o.total = p;
+    return o;
+}
+static int pd_check(const psalm_pd_desc* d) {
+    PSALM_CHECK_ARG(d && d->layers && d->num_layers >= 1 && d->D % 8 == 0 && d->D <= 2048 && d->D == d->M * 32 && d->ffn % 8 == 0 && d->mask_dim % 8 == 0,
+                    "psalm_pixel_decoder_forward: descriptor (D = 32 * heads, multiples of 8)");
+    for (int i = 0; i < 4; ++i) PSALM_CHECK_ARG(d->in_dims[i] % 8 == 0, "psalm_pixel_decoder_forward: input channel counts multiples of 8");
+    return 0;
+}
+extern "C" long psalm_pixel_decoder_forward_workspace(const psalm_pd_desc* d, const int* hw_host) {
+    if (pd_check(d) != 0 || !hw_host) return -1;
+    return pd_layout(d, pd_geom(hw_host)).total;
+}
+extern "C" int psalm_pixel_decoder_forward(const psalm_pd_desc* d, const float* const* feats_host, const int* hw_host, const float* lvl_pos,
+                                           float* mask_features, float* ms_out, void* workspace, long workspace_bytes, void* gemm_workspace,
+                                           long gemm_workspace_bytes, void* stream) {
+    if (pd_check(d) != 0) return -1;
+    PSALM_CHECK_ARG(feats_host && hw_host && lvl_pos && mask_features && ms_out && workspace, "psalm_pixel_decoder_forward: null argument");
+    const PdGeom g = pd_geom(hw_host);
+    const PdLayout lo = pd_layout(d, g);
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_pixel_decoder_forward: workspace of psalm_pixel_decoder_forward_workspace() bytes, 256-byte aligned");
+    char* ws = (char*)workspace;
+    const int D = d->D, S = (int)g.S, HW2 = (int)g.HW2, KpD = c64(D), F = d->ffn, Kf = c64(F), NOW = d->M * 3 * 4 * 3;
+    const float eps = 1e-5f;
+    void* tokp = ws + lo.tokp; float* tokinv = (float*)(ws + lo.tokinv);
+    float* t = (float*)(ws + lo.t); float* gnws = (float*)(ws + lo.gnws);
+    float* src[2] = {(float*)(ws + lo.src[0]), (float*)(ws + lo.src[1])};
+    float* x1 = (float*)(ws + lo.x1);
+    void* sp1 = ws + lo.sp1; float* inv1 = (float*)(ws + lo.inv1);
+    void* sp2 = ws + lo.sp2; float* inv2 = (float*)(ws + lo.inv2);
+    void* sp3 = ws + lo.sp3; float* inv3 = (float*)(ws + lo.inv3);
+    float* qin = (float*)(ws + lo.qin); float* value = (float*)(ws + lo.value); float* ow = (float*)(ws + lo.ow); float* att = (float*)(ws + lo.att);
+    void* hdd = ws + lo.hdd; float* hddinv = (float*)(ws + lo.hddinv);
+    float* lat = (float*)(ws + lo.lat); float* lat2 = (float*)(ws + lo.lat2); float* y = (float*)(ws + lo.y); float* y2 = (float*)(ws + lo.y2);
+    void* cols = ws + lo.cols; float* colsinv = (float*)(ws + lo.colsinv);
+    int rc;
+#define PD(call) do { rc = (call); if (rc) return rc; } while (0)
+    // ---- input projections of res5, res4, res3 (encoder level order) + GroupNorm, written into the level-concatenated buffer
+    float* s0 = src[0];
+    for (int l = 0; l < 3; ++l) {
+        const int fi = 3 - l, hwl = g.h[fi] * g.w[fi], Cin = d->in_dims[fi], Kp = c64(Cin);
+        PD(psalm_split_f16(feats_host[fi], Cin, tokp, 2L * Kp, tokinv, hwl, Cin, stream));
+        PD(psalm_gemm_x3(tokp, 2L * Kp, tokinv, d->ip_w[l], 2L * Kp, d->ip_ws[l], Kp, d->ip_b[l], nullptr, 0, t, D, hwl, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PD(psalm_groupnorm_nhwc(t, PSALM_F32, s0 + g.start[l] * D, PSALM_F32, d->ip_gn_g[l], d->ip_gn_b[l], gnws, 1, hwl, D, d->G, eps, 0, stream));
+    }
+    PD(psalm_add_bcast(s0, PSALM_F32, lvl_pos, PSALM_F32, qin, PSALM_F32, S, D, S, stream));
+    const int64_t shapes[6] = {g.h[3], g.w[3], g.h[2], g.w[2], g.h[1], g.w[1]};
+    const int64_t starts[3] = {g.start[0], g.start[1], g.start[2]};
+    int cur = 0;
+    for (int i = 0; i < d->num_layers; ++i) {
+        const psalm_pd_enc_layer* ly = &d->layers[i];
+        const bool more = i + 1 < d->num_layers;
+        float* sc = src[cur];
+        float* sn = src[cur ^ 1];
+        if (i == 0) {                                            // first layer: fp32 operands, split on the fly (as Ops.gemm does)
+            PD(psalm_split_f16(sc, D, sp2, 2L * KpD, inv2, S, D, stream));
+            PD(psalm_gemm_x3(sp2, 2L * KpD, inv2, ly->value_w, 2L * KpD, ly->value_ws, KpD, ly->value_b, nullptr, 0, value, D, S, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+            PD(psalm_split_f16(qin, D, sp3, 2L * KpD, inv3, S, D, stream));
+            PD(psalm_gemm_x3(sp3, 2L * KpD, inv3, ly->ow_w, 2L * KpD, ly->ow_ws, KpD, ly->ow_b, nullptr, 0, ow, NOW, S, NOW, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        } else {
+            PD(psalm_gemm_x3(sp2, 2L * KpD, inv2, ly->value_w, 2L * KpD, ly->value_ws, KpD, ly->value_b, nullptr, 0, value, D, S, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+            PD(psalm_gemm_x3(sp3, 2L * KpD, inv3, ly->ow_w, 2L * KpD, ly->ow_ws, KpD, ly->ow_b, nullptr, 0, ow, NOW, S, NOW, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        }
+        PD(psalm_msda_fused(value, PSALM_F32, shapes, starts, ow, att, PSALM_F32, 1, S, d->M, 32, 3, 4, stream));
+        PD(psalm_split_f16(att, D, sp1, 2L * KpD, inv1, S, D, stream));
+        PD(psalm_gemm_x3(sp1, 2L * KpD, inv1, ly->out_w, 2L * KpD, ly->out_ws, KpD, ly->out_b, sc, D, x1, D, S, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        // norm1: fp32 stream (-> sn) + linear1's split operand (sp1)
+        PD(psalm_layernorm_split(x1, D, sn, D, ly->n1_g, ly->n1_b, S, D, eps, sp1, inv1, nullptr, 0, nullptr, nullptr, stream));
+        if (Kf != F) PD(psalm_memset_zero(hdd, (long)S * 2 * Kf * 2, stream));
+        PD(psalm_gemm_x3_split(sp1, 2L * KpD, inv1, ly->l1_w, 2L * KpD, ly->l1_ws, KpD, ly->l1_b, nullptr, 0, S, F, /*relu*/ 1, 0, hdd, 2L * Kf, Kf, 0, 0, ly->l1_paired, hddinv,
+                               ly->l1_bnd, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PD(psalm_gemm_x3(hdd, 2L * Kf, hddinv, ly->l2_w, 2L * Kf, ly->l2_ws, Kf, ly->l2_b, sn, D, x1, D, S, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        // norm2: fp32 stream (-> sc: the layer's input buffer is free again) + the NEXT layer's operands: split(src) and split(src + pos)
+        PD(psalm_layernorm_split(x1, D, sc, D, ly->n2_g, ly->n2_b, S, D, eps, more ? sp2 : nullptr, more ? inv2 : nullptr, more ? lvl_pos : nullptr, more ? S : 0,
+                                 more ? sp3 : nullptr, more ? inv3 : nullptr, stream));
+        // (the stream stays in src[cur])
+    }
+    PD(psalm_copy_d2d(ms_out, src[cur], (long)S * D * 4, stream));
+    // ---- FPN step on res2 + mask features
+    {
+        const int C2 = d->in_dims[0], Kp2 = c64(C2), hs = g.h[1], ws_ = g.w[1], H2 = g.h[0], W2 = g.w[0], K9 = 9 * D, Kp9 = c64(K9);
+        PD(psalm_split_f16(feats_host[0], C2, tokp, 2L * Kp2, tokinv, HW2, C2, stream));
+        PD(psalm_gemm_x3(tokp, 2L * Kp2, tokinv, d->adapter_w, 2L * Kp2, d->adapter_ws, Kp2, d->adapter_b, nullptr, 0, lat, D, HW2, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PD(psalm_groupnorm_nhwc(lat, PSALM_F32, lat2, PSALM_F32, d->adapter_gn_g, d->adapter_gn_b, gnws, 1, HW2, D, d->G, eps, 1, stream));
+        PD(psalm_upsample_add_nhwc(lat2, PSALM_F32, src[cur] + g.start[2] * D, PSALM_F32, y, PSALM_F32, 1, hs, ws_, H2, W2, D, stream));
+        PD(psalm_im2col_split_f16(y, cols, colsinv, 1, H2, W2, D, 3, 1, 1, stream));
+        PD(psalm_gemm_x3(cols, 2L * Kp9, colsinv, d->layer_w, 2L * Kp9, d->layer_ws, Kp9, d->layer_b, nullptr, 0, y2, D, HW2, D, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PD(psalm_groupnorm_nhwc(y2, PSALM_F32, y, PSALM_F32, d->layer_gn_g, d->layer_gn_b, gnws, 1, HW2, D, d->G, eps, 1, stream));
+        PD(psalm_split_f16(y, D, cols, 2L * KpD, colsinv, HW2, D, stream));
+        PD(psalm_gemm_x3(cols, 2L * KpD, colsinv, d->mf_w, 2L * KpD, d->mf_ws, KpD, d->mf_b, nullptr, 0, mask_features, d->mask_dim, HW2, d->mask_dim, 0, 0, gemm_workspace,
+                         gemm_workspace_bytes, stream));
+    }
+#undef PD
+    return 0;
+}

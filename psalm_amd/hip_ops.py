@@ -144,6 +144,19 @@ class _ProjDesc(ctypes.Structure):           # psalm_projector_desc
                [(n, c_void_p) for n in ("c1_w", "c1_ws", "c1_b", "c2_w", "c2_ws", "c2f_w", "c2f_ws", "c2f_b", "ds_w", "ds_ws", "ds_b", "fc_w", "fc_ws", "fc_b")]
 
 
+class _PdEncLayer(ctypes.Structure):         # psalm_pd_enc_layer
+    _fields_ = [(n, c_void_p) for n in ("value_w", "value_ws", "value_b", "ow_w", "ow_ws", "ow_b", "out_w", "out_ws", "out_b", "n1_g", "n1_b",
+                                         "l1_w", "l1_ws", "l1_b", "l1_bnd")] + [("l1_paired", c_int)] + \
+               [(n, c_void_p) for n in ("l2_w", "l2_ws", "l2_b", "n2_g", "n2_b")]
+
+
+class _PdDesc(ctypes.Structure):             # psalm_pd_desc
+    _fields_ = [("D", c_int), ("G", c_int), ("M", c_int), ("num_layers", c_int), ("ffn", c_int), ("mask_dim", c_int), ("in_dims", c_int * 4),
+                ("ip_w", c_void_p * 3), ("ip_ws", c_void_p * 3), ("ip_b", c_void_p * 3), ("ip_gn_g", c_void_p * 3), ("ip_gn_b", c_void_p * 3)] + \
+               [(n, c_void_p) for n in ("adapter_w", "adapter_ws", "adapter_b", "adapter_gn_g", "adapter_gn_b", "layer_w", "layer_ws", "layer_b",
+                                         "layer_gn_g", "layer_gn_b", "mf_w", "mf_ws", "mf_b")] + [("layers", ctypes.POINTER(_PdEncLayer))]
+
+
 class Ops:
     # psalm_gemm_set_tile_policy code of the library's default K loop for split-f16 GEMMs on 256 x 256 tiles (2580 K-panel form, 2581 32-deep
     # slices, 2582 slices with the all-padding m-tiles left out): what tests that switch it restore afterwards.
@@ -521,6 +534,54 @@ class Ops:
                                               self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_projector_forward")
         return out, ho * wo
+
+    def pd_desc(self, w, D, G, M, num_layers, ffn, mask_dim, in_dims, paired):
+        def sp(name):
+            t = w[name]
+            if not isinstance(t, SplitF16):
+                raise PsalmHipError(f"pd_desc: {name} is not in split-f16 form")
+            return t.t.data_ptr(), t.inv_scale.data_ptr()
+
+        def P(name):
+            return w[name].data_ptr()
+        layers = (_PdEncLayer * num_layers)()
+        for i in range(num_layers):
+            q = f"pd.enc{i}."
+            v, ow, ou, l1, l2 = sp(q + "value.w"), sp(q + "ow.w"), sp(q + "out.w"), sp(q + "l1.w"), sp(q + "l2.w")
+            layers[i] = _PdEncLayer(v[0], v[1], P(q + "value.b"), ow[0], ow[1], P(q + "ow.b"), ou[0], ou[1], P(q + "out.b"), P(q + "n1.g"), P(q + "n1.b"),
+                                    l1[0], l1[1], P(q + "l1.b"), P(q + "l1.bnd"), int(bool(paired.get(q + "l1", False))), l2[0], l2[1], P(q + "l2.b"),
+                                    P(q + "n2.g"), P(q + "n2.b"))
+        ips = [sp(f"pd.ip{i}.w") for i in range(3)]
+        ad, la, mf = sp("pd.adapter.w"), sp("pd.layer.w"), sp("pd.mf.w")
+        V3 = c_void_p * 3
+        d = _PdDesc(D, G, M, num_layers, ffn, mask_dim, (c_int * 4)(*in_dims), V3(*[x[0] for x in ips]), V3(*[x[1] for x in ips]),
+                    V3(*[P(f"pd.ip{i}.b") for i in range(3)]), V3(*[P(f"pd.ip{i}.gn.g") for i in range(3)]), V3(*[P(f"pd.ip{i}.gn.b") for i in range(3)]),
+                    ad[0], ad[1], P("pd.adapter.b"), P("pd.adapter.gn.g"), P("pd.adapter.gn.b"), la[0], la[1], P("pd.layer.b"), P("pd.layer.gn.g"),
+                    P("pd.layer.gn.b"), mf[0], mf[1], P("pd.mf.b"), ctypes.cast(layers, ctypes.POINTER(_PdEncLayer)))
+        d._keep = (layers, w)
+        return d
+
+    def pixel_decoder_forward(self, desc, feats, lvl_pos):
+        """MSDeformAttn pixel decoder of ONE image as ONE native call.  feats: [(tokens (h*w, C) float32 contiguous, h, w)] res2..res5.
+        Returns (mask_features (h2*w2, mask_dim), ms (S, D) level-concatenated [res5 | res4 | res3])."""
+        hw = (c_int * 8)(*[int(v) for _, h, w_ in feats for v in (h, w_)])
+        self.lib.psalm_pixel_decoder_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_pixel_decoder_forward_workspace(ctypes.byref(desc), hw)
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_pixel_decoder_forward_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        for t, _, _ in feats:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise PsalmHipError("pixel_decoder_forward: contiguous float32 feature tokens")
+        S = sum(h * w_ for _, h, w_ in feats[1:])
+        mf = self.empty(feats[0][1] * feats[0][2], desc.mask_dim, dtype=torch.float32)
+        ms = self.empty(S, desc.D, dtype=torch.float32)
+        ptrs = (c_void_p * 4)(*[t.data_ptr() for t, _, _ in feats])
+        rc = self.lib.psalm_pixel_decoder_forward(ctypes.byref(desc), ptrs, hw, self._p(lvl_pos), self._p(mf), self._p(ms), c_void_p(ws.data_ptr() + off),
+                                                  c_long(nbytes), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_pixel_decoder_forward")
+        return mf, ms
 
     def phi_forward(self, desc, embeds, key_mask, cos, sin, B, L):
         """PhiModel.forward over inputs_embeds (B*L, hidden) float32 as ONE native call (psalm_phi_forward): returns the final-LayerNorm hidden

@@ -924,15 +924,24 @@ class PSALM:
         for h, w_ in shapes[:-1]:
             starts.append(starts[-1] + h * w_)
         S = starts[-1] + shapes[-1][0] * shapes[-1][1]
+        key = ("lvlpos", tuple(shapes))
+        if key not in self._cache:
+            self._cache[key] = torch.cat([self._pos_embed(h, w_) + w["pd.level_embed"][l][None] for l, (h, w_) in enumerate(shapes)], 0).contiguous()
+        lvl_pos = self._cache[key]
+        if (self.c_stages and self.x3 and self.fuse_split and D % 8 == 0 and D <= 2048 and D == 32 * M and cfg.md_levels == 3 and cfg.md_points == 4
+                and getattr(o.lib, "records", None) is None and not (H._DEBUG_BOUNDS or o.debug_bounds)
+                and all(t.dtype == torch.float32 and t.shape[-1] % 8 == 0 for t, _, _ in feats)
+                and all(f"pd.enc{i}.l1.bnd" in w for i in range(cfg.md_enc_layers)) and cfg.md_enc_ffn % 8 == 0 and cfg.md_mask_dim % 8 == 0):
+            dkey = ("pd_desc",)                        # stage-level native call (csrc/stages.hip): ~60 launches from ONE ctypes call
+            if dkey not in self._cache:
+                self._cache[dkey] = o.pd_desc(w, D, G, M, cfg.md_enc_layers, cfg.md_enc_ffn, cfg.md_mask_dim, [int(t.shape[-1]) for t, _, _ in feats], self.paired)
+            mf, ms_all = o.pixel_decoder_forward(self._cache[dkey], [(t.contiguous(), h, w_) for t, h, w_ in feats], lvl_pos)
+            return mf, [ms_all[starts[l]: starts[l] + h * w_] for l, (h, w_) in enumerate(shapes)], shapes, (feats[0][1], feats[0][2])
         src = o.empty(S, D, dtype=torch.float32)
         for i, (tok, h, w_) in enumerate(levels):
             t = o.gemm(tok, w[f"pd.ip{i}.w"], w[f"pd.ip{i}.b"], out_dtype=self.adt)
             # GroupNorm writes straight into this level's rows of the level-concatenated token buffer
             o.groupnorm_nhwc(t, w[f"pd.ip{i}.gn.g"], w[f"pd.ip{i}.gn.b"], 1, h * w_, G, out=src[starts[i]: starts[i] + h * w_])
-        key = ("lvlpos", tuple(shapes))
-        if key not in self._cache:
-            self._cache[key] = torch.cat([self._pos_embed(h, w_) + w["pd.level_embed"][l][None] for l, (h, w_) in enumerate(shapes)], 0).contiguous()
-        lvl_pos = self._cache[key]
         dual = self.adt == torch.bfloat16        # keep a bf16 copy of the fp32 token stream as the GEMM A operand
         if dual:                                 # bf16 copy of the GroupNorm output for the first layer's value projection
             key = ("zrow", D)

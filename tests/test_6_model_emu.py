@@ -263,6 +263,11 @@ def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
         for (ta, ha, wa), (tb, hb, wb) in zip(sa["feats"], sb["feats"]):
             assert (ha, wa) == (hb, wb) and torch.equal(ta, tb)
         assert torch.equal(sa["image_tokens"], sb["image_tokens"])
+        assert ("pd_desc",) in m._cache                              # ... the pixel decoder's (psalm_pixel_decoder_forward, one call per image)
+        for ma, mb in zip(sa["mask_features"], sb["mask_features"]):
+            assert torch.equal(ma, mb)
+        for la, lb in zip(sa["multi_scale_features"], sb["multi_scale_features"]):
+            assert all(torch.equal(x_, y_) for x_, y_ in zip(la, lb))
         for a, b in zip(oa, ob):
             assert torch.equal(a["pred_masks"], b["pred_masks"])
     # the library refuses a workspace that is too small instead of writing past it
