@@ -472,6 +472,33 @@ long psalm_pixel_decoder_forward_workspace(const psalm_pd_desc* d, const int* hw
 int psalm_pixel_decoder_forward(const psalm_pd_desc* d, const float* const* feats_host, const int* hw_host, const float* lvl_pos, float* mask_features,
                                 float* ms_out, void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
 
+/* psalm_predictor_forward: MultiScaleMaskedTransformerDecoder.forward for ONE image (mask2former_transformer_decoder.py:596-693; heads :695-762;
+ * layers :19-199), precision "f16x3", head dim 32, Q <= 128 queries, <= 3 levels.  Layer weights are plain float32 (the M = Q GEMMs run on the exact-fp32
+ * kernel); lvl_k / lvl_v: the cross-attention K / V projections of all decoder layers that read a level, stacked along N, split-f16 form.
+ * ms_host / prpos_host: HOST arrays of the per-level DEVICE buffers (h_l*w_l, D) f32 -- encoder output and (sine position + level embedding);
+ * mask_features (H2*W2, mask_dim) f32; seg_query (Q, D) f32; class_emb (n_cls, D) / seg_emb (n_seg, D) / region_emb (n_reg, D) f32 or NULL.
+ * Outputs: pred_masks (Q, H2*W2) f32; cls_logits (Q, n_cls), seg_logits (Q, n_seg), region_logits (n_reg, Q) f32 for the embeddings given.
+ * workspace: psalm_predictor_forward_workspace(d, hw_levels_host, H2, W2, n_reg) bytes. */
+typedef struct psalm_pr_layer {
+    const float* cq_w; const float* cq_b; const float* co_w; const float* co_b; const float* cn_g; const float* cn_b;
+    const float* sqk_w; const float* sqk_b; const float* sv_w; const float* sv_b; const float* so_w; const float* so_b; const float* sn_g; const float* sn_b;
+    const float* f1_w; const float* f1_b; const float* f2_w; const float* f2_b; const float* fn_g; const float* fn_b;
+} psalm_pr_layer;
+typedef struct psalm_pr_desc {
+    int D, heads, Q, num_layers, num_levels, ffn, mask_dim;
+    const void* lvl_k_w[3]; const float* lvl_k_ws[3]; const float* lvl_k_b[3];
+    const void* lvl_v_w[3]; const float* lvl_v_ws[3]; const float* lvl_v_b[3];
+    const float* level_embed; const float* query_embed; const float* dn_g; const float* dn_b;
+    const float* mask_embed_w[3]; const float* mask_embed_b[3];
+    const float* SEG_w[2]; const float* SEG_b[2]; const float* CLASS_w[2]; const float* CLASS_b[2]; const float* REGION_w[2]; const float* REGION_b[2];
+    const psalm_pr_layer* layers;                                   /* HOST array */
+} psalm_pr_desc;
+long psalm_predictor_forward_workspace(const psalm_pr_desc* d, const int* hw_levels_host, int H2, int W2, int n_extra_rows);
+int psalm_predictor_forward(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
+                            const float* mask_features, int H2, int W2, const float* seg_query, const float* class_emb, int n_cls, const float* seg_emb,
+                            int n_seg, const float* region_emb, int n_reg, float* pred_masks, float* cls_logits, float* seg_logits, float* region_logits,
+                            void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

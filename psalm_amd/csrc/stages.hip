@@ -457,3 +457,172 @@ extern "C" int psalm_pixel_decoder_forward(const psalm_pd_desc* d, const float* 
 #undef PD
     return 0;
 }
+
+// ================================================================================================= masked-attention decoder (one image)
+//   psalm_predictor_forward   MultiScaleMaskedTransformerDecoder.forward for ONE image (Mask2Former_Simplify/modeling/transformer_decoder/
+//                             mask2former_transformer_decoder.py:596-693; prediction heads :695-762; attention / FFN layers :19-199): the K / V projections
+//                             of the three levels (all decoder layers of a level stacked into one GEMM), then per layer { thresholded attention mask from the
+//                             current mask logits; masked cross-attention; self-attention; FFN; mask head: decoder norm + mask_embed MLP + the
+//                             (Q x H2*W2) mask GEMM }, and after the last layer the class / SEG / region logits.  precision "f16x3": the M = Q GEMMs run on
+//                             the exact-fp32 skinny kernel, the level projections and the mask GEMM in split-f16 arithmetic.  The op-by-op sequence of
+//                             PSALM.predictor.
+struct PrLayout { long kin, vin, sp, spinv, K[3], V[3], mfp, mfinv, dec, me0, me1, me2, mes, mesinv, masks, amask, flags, outq, qp, a, x1, out[2], qk, v, hdd, mha, t0, t1, total; };
+static PrLayout pr_layout(const psalm_pr_desc* d, const int* hwl, int H2, int W2, int n_extra) {
+    const long D = d->D, Q = d->Q, HW2 = (long)H2 * W2;
+    long mhw = 0, mmha = 0;
+    for (int l = 0; l < d->num_levels; ++l) {
+        const long hw = (long)hwl[2 * l] * hwl[2 * l + 1];
+        mhw = std::max(mhw, hw);
+        mmha = std::max(mmha, psalm_mha_attention_f32_workspace(1, d->heads, (int)Q, (int)hw));
+    }
+    mmha = std::max(mmha, psalm_mha_attention_f32_workspace(1, d->heads, (int)Q, (int)Q));
+    PrLayout o;
+    long p = 0;
+    o.kin = p; p += al256(mhw * D * 4);
+    o.vin = p; p += al256(mhw * D * 4);
+    o.sp = p; p += al256(mhw * 2 * c64((int)D) * 2); o.spinv = p; p += al256(mhw * 4);
+    for (int l = 0; l < 3; ++l) {
+        const long hw = l < d->num_levels ? (long)hwl[2 * l] * hwl[2 * l + 1] : 0;
+        const long nl_l = l < d->num_levels ? (d->num_layers - l + d->num_levels - 1) / d->num_levels : 0;
+        o.K[l] = p; p += al256(hw * nl_l * D * 4);
+        o.V[l] = p; p += al256(hw * nl_l * D * 4);
+    }
+    o.mfp = p; p += al256(HW2 * 2 * c64(d->mask_dim) * 2); o.mfinv = p; p += al256(HW2 * 4);
+    o.dec = p; p += al256(Q * D * 4);
+    o.me0 = p; p += al256(Q * D * 4); o.me1 = p; p += al256(Q * D * 4); o.me2 = p; p += al256(Q * std::max<long>(D, d->mask_dim) * 4);
+    o.mes = p; p += al256(Q * 2 * c64(d->mask_dim) * 2); o.mesinv = p; p += al256(Q * 4);
+    o.masks = p; p += al256(Q * HW2 * 4);
+    o.amask = p; p += al256(Q * mhw); o.flags = p; p += al256(Q);
+    o.outq = p; p += al256(Q * D * 4); o.qp = p; p += al256(Q * D * 4); o.a = p; p += al256(Q * D * 4); o.x1 = p; p += al256(Q * D * 4);
+    o.out[0] = p; p += al256(Q * D * 4); o.out[1] = p; p += al256(Q * D * 4);
+    o.qk = p; p += al256(Q * 2 * D * 4); o.v = p; p += al256(Q * D * 4);
+    o.hdd = p; p += al256(Q * (long)d->ffn * 4);
+    o.mha = p; p += al256(mmha);
+    o.t0 = p; p += al256(std::max<long>(Q, n_extra) * D * 4); o.t1 = p; p += al256(std::max<long>(Q, n_extra) * D * 4);
+    o.total = p;
+    return o;
+}
+static int pr_check(const psalm_pr_desc* d) {
+    PSALM_CHECK_ARG(d && d->layers && d->num_layers >= 1 && d->num_levels >= 1 && d->num_levels <= 3 && d->Q >= 1 && d->Q <= 128 && d->D == 32 * d->heads &&
+                        d->D % 8 == 0 && d->mask_dim % 8 == 0 && d->ffn % 8 == 0, "psalm_predictor_forward: descriptor (Q <= 128, D = 32 * heads, <= 3 levels)");
+    return 0;
+}
+extern "C" long psalm_predictor_forward_workspace(const psalm_pr_desc* d, const int* hw_levels_host, int H2, int W2, int n_extra_rows) {
+    if (pr_check(d) != 0 || !hw_levels_host || H2 <= 0 || W2 <= 0) return -1;
+    return pr_layout(d, hw_levels_host, H2, W2, n_extra_rows).total;
+}
+extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
+                                       const float* mask_features, int H2, int W2, const float* seg_query, const float* class_emb, int n_cls,
+                                       const float* seg_emb, int n_seg, const float* region_emb, int n_reg, float* pred_masks, float* cls_logits,
+                                       float* seg_logits, float* region_logits, void* workspace, long workspace_bytes, void* gemm_workspace,
+                                       long gemm_workspace_bytes, void* stream) {
+    if (pr_check(d) != 0) return -1;
+    PSALM_CHECK_ARG(ms_host && hw_levels_host && prpos_host && mask_features && seg_query && pred_masks && workspace, "psalm_predictor_forward: null argument");
+    const int D = d->D, Q = d->Q, nh = d->heads, nl = d->num_layers, nlev = d->num_levels, HW2 = H2 * W2, MD = d->mask_dim, F = d->ffn;
+    const PrLayout lo = pr_layout(d, hw_levels_host, H2, W2, std::max(n_reg, 0));
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_predictor_forward: workspace of psalm_predictor_forward_workspace() bytes, 256-byte aligned");
+    char* ws = (char*)workspace;
+    const float eps = 1e-5f;
+    float* kin = (float*)(ws + lo.kin); float* vin = (float*)(ws + lo.vin);
+    void* sp = ws + lo.sp; float* spinv = (float*)(ws + lo.spinv);
+    float* Kl[3]; float* Vl[3];
+    for (int l = 0; l < 3; ++l) { Kl[l] = (float*)(ws + lo.K[l]); Vl[l] = (float*)(ws + lo.V[l]); }
+    void* mfp = ws + lo.mfp; float* mfinv = (float*)(ws + lo.mfinv);
+    float* dec = (float*)(ws + lo.dec); float* me0 = (float*)(ws + lo.me0); float* me1 = (float*)(ws + lo.me1); float* me2 = (float*)(ws + lo.me2);
+    void* mes = ws + lo.mes; float* mesinv = (float*)(ws + lo.mesinv);
+    float* masks = (float*)(ws + lo.masks);
+    unsigned char* amask = (unsigned char*)(ws + lo.amask); unsigned char* flags = (unsigned char*)(ws + lo.flags);
+    float* outq = (float*)(ws + lo.outq); float* qp = (float*)(ws + lo.qp); float* a = (float*)(ws + lo.a); float* x1 = (float*)(ws + lo.x1);
+    float* outb[2] = {(float*)(ws + lo.out[0]), (float*)(ws + lo.out[1])};
+    float* qk = (float*)(ws + lo.qk); float* v = (float*)(ws + lo.v); float* hdd = (float*)(ws + lo.hdd);
+    void* mha = ws + lo.mha;
+    float* t0 = (float*)(ws + lo.t0); float* t1 = (float*)(ws + lo.t1);
+    int rc;
+#define PR(call) do { rc = (call); if (rc) return rc; } while (0)
+    // exact-fp32 GEMM of the M = Q (or a handful of prompt) rows: psalm_gemm with float32 operands (skinny kernel)
+    auto g32 = [&](const float* A, int M, int K, const float* W, const float* b, const float* res, float* C, int N, int act) -> int {
+        return psalm_gemm(A, PSALM_F32, K, W, PSALM_F32, K, b, res, res ? N : 0, C, PSALM_F32, N, M, N, K, act, 0, gemm_workspace, gemm_workspace_bytes, stream);
+    };
+    auto ln = [&](const float* x, const float* g_, const float* b_, float* y, int rows) -> int {
+        return psalm_layernorm3(x, PSALM_F32, D, y, PSALM_F32, D, nullptr, 0, nullptr, 0, nullptr, 0, g_, b_, rows, D, eps, stream);
+    };
+    const int KpD = c64(D), KpM = c64(MD);
+    // ---- K / V of the three levels: (level tokens + position + level embedding) . Wk^T, (level tokens + level embedding) . Wv^T, every decoder layer of the level in one GEMM
+    int nl_l[3] = {0, 0, 0};
+    for (int l = 0; l < nlev; ++l) {
+        const int hw = hw_levels_host[2 * l] * hw_levels_host[2 * l + 1];
+        nl_l[l] = (nl - l + nlev - 1) / nlev;
+        const int N = nl_l[l] * D;
+        PR(psalm_add_bcast(ms_host[l], PSALM_F32, prpos_host[l], PSALM_F32, kin, PSALM_F32, hw, D, hw, stream));
+        PR(psalm_add_bcast(ms_host[l], PSALM_F32, d->level_embed + (long)l * D, PSALM_F32, vin, PSALM_F32, hw, D, 1, stream));
+        PR(psalm_split_f16(kin, D, sp, 2L * KpD, spinv, hw, D, stream));
+        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_k_w[l], 2L * KpD, d->lvl_k_ws[l], KpD, d->lvl_k_b[l], nullptr, 0, Kl[l], N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PR(psalm_split_f16(vin, D, sp, 2L * KpD, spinv, hw, D, stream));
+        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_v_w[l], 2L * KpD, d->lvl_v_ws[l], KpD, d->lvl_v_b[l], nullptr, 0, Vl[l], N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+    }
+    // the mask features as the W operand of the 1 + num_layers mask GEMMs: split once when they are large (PSALM._wop: > 4096 rows), else exact fp32
+    const bool mf_split = HW2 > 4096;
+    if (mf_split) PR(psalm_split_f16(mask_features, MD, mfp, 2L * KpM, mfinv, HW2, MD, stream));
+    auto mask_head = [&](const float* out_) -> int {             // decoder_norm -> mask_embed MLP -> (Q, H2*W2) mask logits; `dec` stays for the class heads
+        int r;
+        if ((r = ln(out_, d->dn_g, d->dn_b, dec, Q))) return r;
+        if ((r = g32(dec, Q, D, d->mask_embed_w[0], d->mask_embed_b[0], nullptr, me0, D, 1))) return r;
+        if ((r = g32(me0, Q, D, d->mask_embed_w[1], d->mask_embed_b[1], nullptr, me1, D, 1))) return r;
+        if ((r = g32(me1, Q, D, d->mask_embed_w[2], d->mask_embed_b[2], nullptr, me2, MD, 0))) return r;
+        if (mf_split) {
+            if ((r = psalm_split_f16(me2, MD, mes, 2L * KpM, mesinv, Q, MD, stream))) return r;
+            return psalm_gemm_x3(mes, 2L * KpM, mesinv, mfp, 2L * KpM, mfinv, KpM, nullptr, nullptr, 0, masks, HW2, Q, HW2, 0, 0, gemm_workspace, gemm_workspace_bytes, stream);
+        }
+        return g32(me2, Q, MD, mask_features, nullptr, nullptr, masks, HW2, 0);
+    };
+    const float* out = seg_query;
+    PR(mask_head(out));
+    PR(psalm_add_bcast(out, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+    int cur = 0;
+    for (int i = 0; i < nl; ++i) {
+        const psalm_pr_layer* ly = &d->layers[i];
+        const int l = i % nlev, j = i / nlev, h = hw_levels_host[2 * l], w = hw_levels_host[2 * l + 1], hw = h * w, N = nl_l[l] * D;
+        PR(psalm_attn_mask(masks, amask, flags, Q, H2, W2, h, w, stream));
+        PR(g32(outq, Q, D, ly->cq_w, ly->cq_b, nullptr, qp, D, 0));
+        PR(psalm_mha_attention_f32(qp, D, Kl[l] + (long)j * D, N, Vl[l] + (long)j * D, N, a, D, amask, flags, mha, 1, Q, hw, nh, 32, stream));
+        PR(g32(a, Q, D, ly->co_w, ly->co_b, out, x1, D, 0));
+        float* o1 = outb[cur];
+        PR(ln(x1, ly->cn_g, ly->cn_b, o1, Q));
+        PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+        PR(g32(outq, Q, D, ly->sqk_w, ly->sqk_b, nullptr, qk, 2 * D, 0));
+        PR(g32(o1, Q, D, ly->sv_w, ly->sv_b, nullptr, v, D, 0));
+        PR(psalm_mha_attention_f32(qk, 2L * D, qk + D, 2L * D, v, D, a, D, nullptr, nullptr, mha, 1, Q, Q, nh, 32, stream));
+        PR(g32(a, Q, D, ly->so_w, ly->so_b, o1, x1, D, 0));
+        float* o2 = outb[cur ^ 1];
+        PR(ln(x1, ly->sn_g, ly->sn_b, o2, Q));
+        PR(g32(o2, Q, D, ly->f1_w, ly->f1_b, nullptr, hdd, F, 1));
+        PR(g32(hdd, Q, F, ly->f2_w, ly->f2_b, o2, x1, D, 0));
+        PR(ln(x1, ly->fn_g, ly->fn_b, o1, Q));
+        PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+        out = o1;
+        PR(mask_head(out));
+        cur ^= 1;
+    }
+    PR(psalm_copy_d2d(pred_masks, masks, (long)Q * HW2 * 4, stream));
+    // ---- prediction heads of the LAST layer (the earlier ones are auxiliary training outputs, TD:672-690)
+    if (class_emb && n_cls > 0) {
+        PSALM_CHECK_ARG(cls_logits != nullptr, "psalm_predictor_forward: cls_logits output missing");
+        PR(g32(dec, Q, D, d->CLASS_w[0], d->CLASS_b[0], nullptr, t0, D, 1));
+        PR(g32(t0, Q, D, d->CLASS_w[1], d->CLASS_b[1], nullptr, t1, D, 0));
+        PR(g32(t1, Q, D, class_emb, nullptr, nullptr, cls_logits, n_cls, 0));
+    }
+    if (seg_emb && n_seg > 0) {
+        PSALM_CHECK_ARG(seg_logits != nullptr, "psalm_predictor_forward: seg_logits output missing");
+        PR(g32(dec, Q, D, d->SEG_w[0], d->SEG_b[0], nullptr, t0, D, 1));
+        PR(g32(t0, Q, D, d->SEG_w[1], d->SEG_b[1], nullptr, t1, D, 0));
+        PR(g32(t1, Q, D, seg_emb, nullptr, nullptr, seg_logits, n_seg, 0));
+    }
+    if (region_emb && n_reg > 0) {                               // einsum 'kd,ld->kl' (TD:744): (k, Q)
+        PSALM_CHECK_ARG(region_logits != nullptr, "psalm_predictor_forward: region_logits output missing");
+        PR(g32(dec, Q, D, d->REGION_w[0], d->REGION_b[0], nullptr, t0, D, 1));
+        PR(g32(t0, Q, D, d->REGION_w[1], d->REGION_b[1], nullptr, t1, D, 0));
+        PR(g32(region_emb, n_reg, D, t1, nullptr, nullptr, region_logits, Q, 0));
+    }
+#undef PR
+    return 0;
+}

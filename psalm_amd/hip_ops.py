@@ -157,6 +157,18 @@ class _PdDesc(ctypes.Structure):             # psalm_pd_desc
                                          "layer_gn_g", "layer_gn_b", "mf_w", "mf_ws", "mf_b")] + [("layers", ctypes.POINTER(_PdEncLayer))]
 
 
+class _PrLayer(ctypes.Structure):            # psalm_pr_layer
+    _fields_ = [(n, c_void_p) for n in ("cq_w", "cq_b", "co_w", "co_b", "cn_g", "cn_b", "sqk_w", "sqk_b", "sv_w", "sv_b", "so_w", "so_b", "sn_g", "sn_b",
+                                         "f1_w", "f1_b", "f2_w", "f2_b", "fn_g", "fn_b")]
+
+
+class _PrDesc(ctypes.Structure):             # psalm_pr_desc
+    _fields_ = [(n, c_int) for n in ("D", "heads", "Q", "num_layers", "num_levels", "ffn", "mask_dim")] + \
+               [(n, c_void_p * 3) for n in ("lvl_k_w", "lvl_k_ws", "lvl_k_b", "lvl_v_w", "lvl_v_ws", "lvl_v_b")] + \
+               [(n, c_void_p) for n in ("level_embed", "query_embed", "dn_g", "dn_b")] + [("mask_embed_w", c_void_p * 3), ("mask_embed_b", c_void_p * 3)] + \
+               [(n, c_void_p * 2) for n in ("SEG_w", "SEG_b", "CLASS_w", "CLASS_b", "REGION_w", "REGION_b")] + [("layers", ctypes.POINTER(_PrLayer))]
+
+
 class Ops:
     # psalm_gemm_set_tile_policy code of the library's default K loop for split-f16 GEMMs on 256 x 256 tiles (2580 K-panel form, 2581 32-deep
     # slices, 2582 slices with the all-padding m-tiles left out): what tests that switch it restore afterwards.
@@ -582,6 +594,66 @@ class Ops:
                                                   c_long(nbytes), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_pixel_decoder_forward")
         return mf, ms
+
+    def pr_desc(self, w, D, heads, Q, num_layers, num_levels, ffn, mask_dim):
+        def P(name):
+            t = w[name]
+            if isinstance(t, SplitF16) or t.dtype != torch.float32:
+                raise PsalmHipError(f"pr_desc: {name} must be a plain float32 tensor")
+            return t.data_ptr()
+        layers = (_PrLayer * num_layers)()
+        for i in range(num_layers):
+            q = f"pr{i}."
+            layers[i] = _PrLayer(*[P(q + n) for n in ("cq.w", "cq.b", "co.w", "co.b", "cn.g", "cn.b", "sqk.w", "sqk.b", "sv.w", "sv.b", "so.w", "so.b", "sn.g",
+                                                      "sn.b", "f1.w", "f1.b", "f2.w", "f2.b", "fn.g", "fn.b")])
+        V3, V2 = c_void_p * 3, c_void_p * 2
+        ks = [w[f"pr.lvl{l}.k.w"] for l in range(num_levels)] + [None] * (3 - num_levels)
+        vs = [w[f"pr.lvl{l}.v.w"] for l in range(num_levels)] + [None] * (3 - num_levels)
+        if not all(t is None or isinstance(t, SplitF16) for t in ks + vs):
+            raise PsalmHipError("pr_desc: the level K / V projection weights must be in split-f16 form")
+        pb = lambda t, f: 0 if t is None else f(t)               # noqa: E731
+        d = _PrDesc(D, heads, Q, num_layers, num_levels, ffn, mask_dim,
+                    V3(*[pb(t, lambda x: x.t.data_ptr()) for t in ks]), V3(*[pb(t, lambda x: x.inv_scale.data_ptr()) for t in ks]),
+                    V3(*[P(f"pr.lvl{l}.k.b") if l < num_levels else 0 for l in range(3)]),
+                    V3(*[pb(t, lambda x: x.t.data_ptr()) for t in vs]), V3(*[pb(t, lambda x: x.inv_scale.data_ptr()) for t in vs]),
+                    V3(*[P(f"pr.lvl{l}.v.b") if l < num_levels else 0 for l in range(3)]),
+                    P("pr.level_embed"), P("pr.query_embed"), P("pr.dn.g"), P("pr.dn.b"),
+                    V3(*[P(f"pr.mask_embed{j}.w") for j in range(3)]), V3(*[P(f"pr.mask_embed{j}.b") for j in range(3)]),
+                    V2(*[P(f"pr.SEG_proj{j}.w") for j in range(2)]), V2(*[P(f"pr.SEG_proj{j}.b") for j in range(2)]),
+                    V2(*[P(f"pr.CLASS_proj{j}.w") for j in range(2)]), V2(*[P(f"pr.CLASS_proj{j}.b") for j in range(2)]),
+                    V2(*[P(f"pr.REGION_proj{j}.w") for j in range(2)]), V2(*[P(f"pr.REGION_proj{j}.b") for j in range(2)]),
+                    ctypes.cast(layers, ctypes.POINTER(_PrLayer)))
+        d._keep = (layers, w)
+        return d
+
+    def predictor_forward(self, desc, ms, shapes, prpos, mf, mf_size, seg_query, class_emb=None, seg_emb=None, region_emb=None):
+        """The masked-attention decoder of ONE image as ONE native call.  ms / prpos: per-level (h*w, D) float32 tensors; mf (H2*W2, mask_dim);
+        seg_query (Q, D); *_emb (n, D) float32 or None.  Returns (pred_masks (Q, H2*W2), cls_logits | None, seg_logits | None, region_logits | None)."""
+        H2, W2 = mf_size
+        Q, D = desc.Q, desc.D
+        for t in list(ms) + list(prpos) + [mf, seg_query] + [e for e in (class_emb, seg_emb, region_emb) if e is not None]:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16:
+                raise PsalmHipError("predictor_forward: contiguous, 16-byte aligned float32 tensors")
+        hw = (c_int * (2 * len(shapes)))(*[int(v) for s_ in shapes for v in s_])
+        n_reg = int(region_emb.shape[0]) if region_emb is not None else 0
+        self.lib.psalm_predictor_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_predictor_forward_workspace(ctypes.byref(desc), hw, H2, W2, n_reg)
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_predictor_forward_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        masks = self.empty(Q, H2 * W2, dtype=torch.float32)
+        cls = self.empty(Q, class_emb.shape[0], dtype=torch.float32) if class_emb is not None else None
+        seg = self.empty(Q, seg_emb.shape[0], dtype=torch.float32) if seg_emb is not None else None
+        reg = self.empty(n_reg, Q, dtype=torch.float32) if region_emb is not None else None
+        VP = c_void_p * len(shapes)
+        rc = self.lib.psalm_predictor_forward(ctypes.byref(desc), VP(*[t.data_ptr() for t in ms]), hw, VP(*[t.data_ptr() for t in prpos]), self._p(mf), H2, W2,
+                                              self._p(seg_query), self._p(class_emb), int(class_emb.shape[0]) if class_emb is not None else 0, self._p(seg_emb),
+                                              int(seg_emb.shape[0]) if seg_emb is not None else 0, self._p(region_emb), n_reg, self._p(masks), self._p(cls),
+                                              self._p(seg), self._p(reg), c_void_p(ws.data_ptr() + off), c_long(nbytes), self._p(self._gemm_ws()),
+                                              c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_predictor_forward")
+        return masks, cls, seg, reg
 
     def phi_forward(self, desc, embeds, key_mask, cos, sin, B, L):
         """PhiModel.forward over inputs_embeds (B*L, hidden) float32 as ONE native call (psalm_phi_forward): returns the final-LayerNorm hidden

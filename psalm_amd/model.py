@@ -1008,6 +1008,23 @@ class PSALM:
         # bf16 mode: attention on the matrix cores (split-KV kernel).  It takes V transposed, which the value projection
         # produces directly by swapping the GEMM operands (V^T = W_v . X^T, bias along rows).
         mfma = self.adt == torch.bfloat16 and all((h * w_) % 8 == 0 for h, w_ in shapes)
+        if (self.c_stages and self.x3 and Q <= 128 and D == 32 * nh and D % 8 == 0 and nlev <= 3 and cfg.md_mask_dim % 8 == 0 and cfg.md_dim_ff % 8 == 0
+                and getattr(o.lib, "records", None) is None and seg_query.dtype == torch.float32 and mf.dtype == torch.float32
+                and all(e is None or (e.dtype == torch.float32 and e.data_ptr() % 16 == 0) for e in (SEG_emb, class_emb, region_emb))):
+            dkey = ("pr_desc",)                        # stage-level native call (csrc/stages.hip): ~200 launches from ONE ctypes call
+            if dkey not in self._cache:
+                self._cache[dkey] = o.pr_desc(w, D, nh, Q, nl, nlev, cfg.md_dim_ff, cfg.md_mask_dim)
+            prpos = []
+            for l in range(nlev):
+                h, w_ = shapes[l]
+                key = ("prpos", l, h, w_)
+                if key not in self._cache:
+                    self._cache[key] = (self._pos_embed(h, w_) + w["pr.level_embed"][l][None]).contiguous()
+                prpos.append(self._cache[key])
+            cont = lambda t: t if t is None or t.is_contiguous() else t.contiguous()       # noqa: E731
+            masks, cls_l, seg_l, reg_l = o.predictor_forward(self._cache[dkey], [cont(t) for t in ms], shapes, prpos, cont(mf), mf_size, cont(seg_query),
+                                                             cont(class_emb), cont(SEG_emb), cont(region_emb))
+            return {"pred_masks": masks.view(Q, H2, W2), "pred_class_name_logits": cls_l, "pred_SEG_logits": seg_l, "pred_region_logits": reg_l}
         Kl, Vl = [], []
         for l in range(nlev):
             h, w_ = shapes[l]

@@ -239,7 +239,7 @@ def test_llm_single_product_side_mode_changes_the_llm_only_and_leaves_the_defaul
         PSALM(cfg, sd, ops=ops, precision="fp32", llm_products=1)
 
 
-@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3)])
+@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3), ("region", 2)])
 def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
     """psalm_swin_forward / psalm_phi_forward (csrc/stages.hip; SURVEY section 8(b): the stage-level C ABI behind the model API) issues the Phi decoder's launch
     sequence from native code -- ONE ctypes call instead of ~4 per layer.  Same launches, same order: the hidden states, and everything
@@ -254,9 +254,11 @@ def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
         m = PSALM(cfg, sd, ops=ops, precision="f16x3", llm_products=prods)
         assert m.c_stages
         sa, sb = {}, {}
+        torch.manual_seed(77)                                     # (region prompts: the point sampling draws from the global RNG)
         oa = m.forward_logits(stages=sa, **kw)
         assert ("phi_desc",) in m._cache                          # the stage-level call ran
         m.c_stages = False
+        torch.manual_seed(77)
         ob = m.forward_logits(stages=sb, **kw)
         assert torch.equal(sa["hidden_states"], sb["hidden_states"]), prods
         assert ("swin_desc",) in m._cache and ("proj_desc",) in m._cache        # ... the Swin tower's (psalm_swin_forward) and the projector's
@@ -268,8 +270,11 @@ def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
             assert torch.equal(ma, mb)
         for la, lb in zip(sa["multi_scale_features"], sb["multi_scale_features"]):
             assert all(torch.equal(x_, y_) for x_, y_ in zip(la, lb))
+        assert ("pr_desc",) in m._cache                              # ... and the masked-attention decoder's (psalm_predictor_forward)
         for a, b in zip(oa, ob):
             assert torch.equal(a["pred_masks"], b["pred_masks"])
+            for k in ("pred_class_name_logits", "pred_SEG_logits", "pred_region_logits"):
+                assert (a[k] is None) == (b[k] is None) and (a[k] is None or torch.equal(a[k], b[k])), k
     # the library refuses a workspace that is too small instead of writing past it
     import ctypes
     from ctypes import c_long, c_void_p

@@ -376,10 +376,11 @@ def test_config2_padding_tiles_left_out_is_bitwise_the_plain_slice_kernel():
     _report(test="config2_padding_tiles_left_out_bitwise", identical=True)
 
 
-def test_config2_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence():
-    """psalm_phi_forward (the stage-level C ABI of the Phi decoder, csrc/stages.hip: one native call issues the ~100 launches of the 24 layers)
-    against the op-by-op Python sequence it replaces (PSALM.c_stages = False): the whole 1024 x 1024 panoptic evaluation, every output
-    tensor, bit for bit -- eagerly and through hipGraph capture / replay."""
+def test_config2_stage_level_calls_are_bitwise_the_op_by_op_sequence():
+    """The stage-level C ABI (csrc/stages.hip: psalm_swin_forward, psalm_projector_forward, psalm_phi_forward, psalm_pixel_decoder_forward,
+    psalm_predictor_forward -- one native call issues a stage's launches: ~560 of the image's ~600) against the op-by-op Python sequence it
+    replaces (PSALM.c_stages = False): the whole 1024 x 1024 panoptic evaluation, every output tensor, bit for bit -- eagerly and through
+    hipGraph capture / replay."""
     from psalm_amd.model import PSALM
     cfg, sd = _full_model("panoptic")
     inputs = make_inputs(cfg, "panoptic", size=1024, batch=1, seed=0)
@@ -394,7 +395,7 @@ def test_config2_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence():
             outs[flag] = (r["mask_pred"].clone(), r["sem_seg"].clone(), r["panoptic_seg"][0].clone(), r["instances"].scores.clone(), list(r["panoptic_seg"][1]))
     finally:
         model.c_stages = True
-    assert ("phi_desc",) in model._cache
+    assert all((k,) in model._cache for k in ("swin_desc", "proj_desc", "phi_desc", "pd_desc", "pr_desc"))
     for a, b in zip(outs[True][:4], outs[False][:4]):
         assert torch.equal(a, b)
     assert outs[True][4] == outs[False][4]
@@ -403,7 +404,7 @@ def test_config2_stage_level_phi_forward_is_bitwise_the_op_by_op_sequence():
         g = graphed.eval_seg(**inputs)[0]
     torch.cuda.synchronize()
     assert graphed.graph_stats["captures"] == 1 and torch.equal(g["mask_pred"], outs[False][0]) and torch.equal(g["panoptic_seg"][0], outs[False][2])
-    _report(test="config2_stage_level_phi_forward_bitwise", identical=True)
+    _report(test="config2_stage_level_calls_bitwise", identical=True)
     del graphed
     torch.cuda.empty_cache()
 
