@@ -18,6 +18,33 @@ print("fp32", b["other_modes"]["fp32"].get("value"), "bf16", b["other_modes"]["b
 PY
 timeout 200 python tools/bench_attn.py --libs psalm_amd/lib/libpsalm_hip.so,tools/experiments/_build/libpsalm_hip_r04attn.so > gpurun_out/r05_bench_attn.jsonl 2>&1; cut -c1-330 gpurun_out/r05_bench_attn.jsonl
 timeout 200 python tools/bench_mha.py --libs psalm_amd/lib/libpsalm_hip.so,tools/experiments/_build/libpsalm_hip_r04attn.so > gpurun_out/r05_bench_mha.jsonl 2>&1; cut -c1-400 gpurun_out/r05_bench_mha.jsonl
+# host time to ISSUE one image's launches (no graph): stage-level native calls vs one ctypes call per launch; and the eager images/s of both
+python - > gpurun_out/r05_eager_host_issue.json <<'PY'
+import json, sys, time, torch
+sys.path.insert(0, ".")
+from psalm_amd.config import PsalmConfig
+from psalm_amd.model import PSALM
+from psalm_amd.synthetic import make_inputs, make_state_dict
+cfg = PsalmConfig(seg_task="panoptic"); sd = make_state_dict(cfg, seed=0)
+m = PSALM(cfg, sd, precision="f16x3", use_graphs=False)
+inp = make_inputs(cfg, "panoptic", size=1024, batch=1, seed=0); inp["images"] = inp["images"].cuda()
+out = {}
+for flag in (True, False, True, False):
+    m.c_stages = flag
+    for _ in range(3): m.eval_seg(**inp)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): m.eval_seg(**inp)
+    torch.cuda.synchronize(); full = (time.perf_counter() - t0) * 100
+    m._finalize = lambda r_, i_: r_
+    issue = []
+    for _ in range(10):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); m.eval_seg(**inp); issue.append((time.perf_counter() - t0) * 1e3)
+    del m._finalize
+    torch.cuda.synchronize()
+    out.setdefault("c_stages=%s" % flag, []).append({"eager_ms_per_image": round(full, 2), "host_issue_ms_per_image_median": round(sorted(issue)[5], 2)})
+print(json.dumps(out))
+PY
+cat gpurun_out/r05_eager_host_issue.json
 # the copyBuffer / ATen rows of the kernel trace: per image, or the one-off weight preparation?  Same command, 2 vs 8 timed steps (6 vs 12 images)
 cd /tmp && export TMPDIR=/tmp
 for ST in 2 8; do
