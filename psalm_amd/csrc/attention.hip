@@ -600,11 +600,20 @@ __global__ void __launch_bounds__(256) phi_rope_prep_f32_kernel(const float* __r
     if (t >= Lp) return;
     float* qd = Qr + (((long)b * heads + h) * Lp + t) * HD + c0;
     float* kd = Kr + (((long)b * heads + h) * Lp + t) * HD + c0;
-    if (h == 0 && c0 == 0) Mk[(long)b * Lp + t] = t < L ? (key_mask[(long)b * L + t] ? 1 : 0) : 0;
-    if (h == 0 && threadIdx.x == 0) {                   // Tk[b][tile]: every key of this 32-key tile is a real, un-masked token (r05: such a tile
-        bool all = true;                                 // below the diagonal needs no per-element mask work in the attention kernel)
-        for (int i = 0; i < 32; ++i) { const int tt = blockIdx.x * 32 + i; all = all && tt < L && key_mask[(long)b * L + tt] != 0; }
-        Tk[(long)b * (Lp / 32) + blockIdx.x] = all ? 1 : 0;
+    // Tk[b][tile]: every key of this 32-key tile is a real, un-masked token (r05: such a tile below the diagonal needs no per-element mask work in
+    // the attention kernel).  The block's 32 token threads (c0 == 0) each hold one key's flag: any invalid one clears the shared flag (a
+    // first form let thread 0 walk the 32 bytes alone: +3 us on this 8 us kernel, profiles/r05_kernel_stats.txt).  Blocks of head 0 only.
+    __shared__ int tile_all;
+    if (h == 0) {                                        // (block-uniform)
+        const bool valid = t < L && key_mask[(long)b * L + min(t, L - 1)] != 0;
+        if (threadIdx.x == 0) tile_all = 1;
+        __syncthreads();
+        if (c0 == 0) {
+            if (t < Lp) Mk[(long)b * Lp + t] = valid ? 1 : 0;
+            if (!valid) tile_all = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) Tk[(long)b * (Lp / 32) + blockIdx.x] = tile_all ? 1 : 0;
     }
     float q[8], k[8];
     if (t < L) {
