@@ -1,5 +1,5 @@
 """Split-f16 (X3) GEMM micro-benchmark over the shapes of the f16x3 image, per tile policy.
-    python tools/bench_gemm_x3.py [out.json]"""
+    python tools/bench_gemm_x3.py [--ring] [--lib path/to/other/libpsalm_hip.so] [out.json]"""
 import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +25,11 @@ RING_SHAPES = [(4096, 512, 2048), (4096, 2048, 512), (5184, 1536, 512), (5184, 5
 
 def main():
     ops = get_ops()
+    if "--lib" in sys.argv:                                     # A/B against a side library (tools/experiments/_build/...)
+        i = sys.argv.index("--lib")
+        from psalm_amd.hip_ops import Ops
+        ops = Ops(os.path.join(ROOT, sys.argv[i + 1]))
+        del sys.argv[i:i + 2]
     out = {}
     ring = "--ring" in sys.argv
     if ring:
