@@ -116,8 +116,14 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
 // them; every head's wavefront derives the same scale, head 0's writes 1/scale to so_inv.
 // NWV wavefronts per (window, head) share the staged V / bias and take every NWV-th query tile: a Swin-B stage-3 launch has only 36 windows x
 // 16 heads = 576 (window, head) pairs for 1024 SIMDs, each a 17 us serial chain of matrix instructions when one wavefront owns all 9 tiles.
+#ifndef PSALM_WINATTN_NWV3_MAX
+#define PSALM_WINATTN_NWV3_MAX 320          // (window, head) pairs up to which three wavefronts share a pair (A/B builds: -DPSALM_WINATTN_NWV3_MAX=...)
+#endif
+#ifndef PSALM_WINATTN_WPE
+#define PSALM_WINATTN_WPE 1
+#endif
 template <int HD, int WS, bool SO = false, int NWV = 3>
-__global__ void __launch_bounds__(64 * NWV) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
+__global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                        float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift,
                                                                        const float* __restrict__ a_inv = nullptr,
                                                                        const float* __restrict__ so_par = nullptr,
@@ -271,7 +277,7 @@ extern "C" int psalm_window_attention_split(const float* qkv, const float* bias_
     const int nwin = B * nWh * nWw;
     if (nwin == 0) return 0;
     const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float) + 288;                 // V rows + bias column + the key-index table
-    if ((long)nwin * heads <= 320)                                        // wavefronts per (window, head): as psalm_window_attention
+    if ((long)nwin * heads <= PSALM_WINATTN_NWV3_MAX)                     // wavefronts per (window, head): as psalm_window_attention
         hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 3>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream, qkv,
                            bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
     else
@@ -291,7 +297,7 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
         const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float) + (size_t)((N * 2 + 3) / 4 * 4);
         // wavefronts per (window, head): 3 only when the grid cannot give every SIMD a wavefront anyway (r02n, 1024^2 image: stage 4, 288
         // pairs: 41 -> 32 us; stage 3, 576 pairs: 48.5 -> 52.4; stage 1, 1936 pairs: 100 -> 136 -- profiles/r02n_winattn_nwv.jsonl)
-        const int nwv = (long)nwin * heads <= 320 ? 3 : 1;
+        const int nwv = (long)nwin * heads <= PSALM_WINATTN_NWV3_MAX ? 3 : 1;
         if (nwv == 1)
             hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
                                (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
