@@ -106,24 +106,23 @@ __global__ void __launch_bounds__(192) window_attention_kernel(const T* __restri
 //   statistics of a query live in the 4 lanes {q, q+16, q+32, q+48} (two xor-shuffles);
 //   O^T (16 d x 16 q)   += V_tile^T . P^T   4 MFMAs per key tile and d-tile, P straight from the score registers: step r contracts the
 //                                          keys 4 kk + r that lane (q, kk) holds in register r; V is read un-transposed from LDS.
-// Only V (+ the bias column) is staged in LDS (rows padded to 36 floats: the 4-byte V reads of a step hit 64 distinct banks); the K
-// fragments -- 32 bytes per lane, each needed once per query tile -- come straight from global / L1 (a window-head's K is 18 KB).
-// 22.8 KB of LDS per wave instead of 43.6 KB: 7 instead of 3 resident waves per CU (r02: 3 waves left one SIMD in four idle).
+// V (+ the bias column) is staged in LDS (rows padded to 36 floats: the 4-byte V reads of a step hit 64 distinct banks).  The K fragments --
+// 32 bytes per lane and key tile, the same for every query tile of a wavefront -- are loaded ONCE into 72 registers (one wavefront per pair:
+// 330 registers, one wavefront per SIMD) or, in the KLDS flavour, read from a second LDS copy (three wavefronts per pair, 119 registers, 44 KB of
+// LDS per block: three blocks per CU).  r04 fetched them from L1 / L2 once per query tile.
 // SO = true: the output leaves as the split-f16 A operand of the projection GEMM: `out` is then the f16 operand buffer (rows of 2 * so_kp:
 // hi at column h*32 + d, lo so_kp further).  One power-of-two scale per WINDOW from a magnitude bound that needs no pass over the output:
 // an output row is a convex combination of the window's v rows, |v_jd| <= a_inv[j] * par[0] + par[1] (a_inv: the row scales of the qkv
 // GEMM's split-f16 A operand, par = {2^14 max_n sum_k |w_nk| over the v rows of the qkv weight, max |b_v|}), so max_j of that bounds all of
 // them; every head's wavefront derives the same scale, head 0's writes 1/scale to so_inv.
-// NWV wavefronts per (window, head) share the staged V / bias and take every NWV-th query tile: a Swin-B stage-3 launch has only 36 windows x
-// 16 heads = 576 (window, head) pairs for 1024 SIMDs, each a 17 us serial chain of matrix instructions when one wavefront owns all 9 tiles.
-#ifndef PSALM_WINATTN_NWV3_MAX
-#define PSALM_WINATTN_NWV3_MAX 320          // (window, head) pairs up to which three wavefronts share a pair (A/B builds: -DPSALM_WINATTN_NWV3_MAX=...)
+// NWV wavefronts per (window, head) share the staged V / bias (/ K) and take every NWV-th query tile: a Swin-B stage-3 launch has only 36
+// windows x 16 heads = 576 (window, head) pairs for 1024 SIMDs, each a serial chain of matrix instructions and softmax arithmetic when one
+// wavefront owns all 9 tiles.
+#ifndef PSALM_WINATTN_KLDS_MAX
+#define PSALM_WINATTN_KLDS_MAX 640          // (window, head) pairs up to which the three-wavefront, K-through-LDS flavour runs (A/B builds: -D...)
 #endif
-#ifndef PSALM_WINATTN_WPE
-#define PSALM_WINATTN_WPE 1
-#endif
-template <int HD, int WS, bool SO = false, int NWV = 3>
-__global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
+template <int HD, int WS, bool SO = false, int NWV = 3, bool KLDS = false>
+__global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(KLDS ? 3 : 1) window_attention_f32_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                        float* __restrict__ out, int nWh, int nWw, int C, int heads, int shift,
                                                                        const float* __restrict__ a_inv = nullptr,
                                                                        const float* __restrict__ so_par = nullptr,
@@ -134,14 +133,90 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
     HIP_DYNAMIC_SHARED(float, smem)
     float* Vs = smem;                       // [N][LS]
     float* Bs = Vs + N * LS;                // [NB]
+    float* Ks = smem + (N * LS + NB + (N * 2 + 3) / 4 + 3) / 4 * 4;      // [N][LS]  (KLDS only; behind the 288-byte key-index table, 16-byte aligned)
     const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n16 = lane & 15, kk = lane >> 4;
     const long row0 = (long)win * N;
-    for (int e = tid; e < N * (HD / 4); e += 64 * NWV) {                 // 144 rows x 8 float4 per operand
-        const int r = e >> 3, c4 = (e & 7) * 4;
-        const float* p = qkv + (row0 + r) * 3 * C + h * HD + c4;
-        *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(p + 2 * C);
+    // r05: EVERY global load of the prologue -- V (first batch), K, the bias column, the operand scales, the first query fragment -- is issued
+    // before the first LDS store waits for one: the rolled loops of r04 were 18 + 9 dependent global round trips per wavefront when one
+    // wavefront stages alone (about half of a stage-3 launch), and the batched form still took them one after another.  144 rows x 8 float4 of
+    // V (and of K in the KLDS flavour), 529 bias entries.
+    constexpr int VIT = N * (HD / 4) / (64 * NWV), BIT = (NB + 64 * NWV - 1) / (64 * NWV), VB = VIT % 6 == 0 ? 6 : VIT;   // loads per batch
+    static_assert(N * (HD / 4) % (64 * NWV) == 0 && (VIT == VB || VIT == 3 * VB), "V staging: one or three whole batches");
+    static_assert(!KLDS || VIT == VB, "KLDS: one batch per operand");
+    // K fragments of ALL nine key tiles: 72 registers that every query tile of this wavefront reuses (r04: re-fetched from L1 / L2 per query
+    // tile, the first products of a tile behind that round trip).  KLDS: three wavefronts per pair AND three such blocks per CU -- a stage-3
+    // launch's 576 pairs all resident -- need <= 168 registers: the fragments then come from an LDS copy of K, 16 bytes per read.
+    f32x4 kf[KLDS ? 1 : NT][2];
+    f32x4 kt[KLDS ? VB : 1];
+    if constexpr (!KLDS) {
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+            const float* kp = qkv + (row0 + 16 * tk + n16) * 3 * C + C + h * HD + 8 * kk;
+            kf[tk][0] = reinterpret_cast<const f32x4*>(kp)[0];
+            kf[tk][1] = reinterpret_cast<const f32x4*>(kp)[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VB; ++i) {
+            const int e = tid + i * 64 * NWV, r = e >> 3, c4 = (e & 7) * 4;
+            kt[i] = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * 3 * C + h * HD + c4 + C);
+        }
     }
-    for (int e = tid; e < NB; e += 64 * NWV) Bs[e] = bias_table[(long)e * heads + h];
+    auto load_q = [&](int tq_, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        const float* p = qkv + (row0 + 16 * tq_ + n16) * 3 * C + h * HD + 8 * kk;
+        a = reinterpret_cast<const f32x4*>(p)[0];
+        b = reinterpret_cast<const f32x4*>(p)[1];
+    };
+    auto load_v = [&](int b0, f32x4 (&vt)[VB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VB; ++i) {
+            const int e = tid + (b0 + i) * 64 * NWV, r = e >> 3, c4 = (e & 7) * 4;
+            vt[i] = *reinterpret_cast<const f32x4*>(qkv + (row0 + r) * 3 * C + h * HD + c4 + 2 * C);
+        }
+    };
+    auto store_v = [&](int b0, const f32x4 (&vt)[VB], float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VB; ++i) {
+            const int e = tid + (b0 + i) * 64 * NWV, r = e >> 3, c4 = (e & 7) * 4;
+            *reinterpret_cast<f32x4*>(&dst[r * LS + c4]) = vt[i];
+        }
+    };
+    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};           // the NEXT tile's query fragment, fetched one tile ahead
+    float gmax = 0.f;
+    {
+        f32x4 vt[VB];
+        float bt[BIT];
+        load_v(0, vt);
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int e = tid + i * 64 * NWV;
+            bt[i] = e < NB ? bias_table[(long)e * heads + h] : 0.f;
+        }
+        if constexpr (SO) {
+#pragma unroll
+            for (int i = 0; i < (N + 63) / 64; ++i) gmax = fmaxf(gmax, lane + 64 * i < N ? a_inv[row0 + lane + 64 * i] : 0.f);
+        }
+        if (wave < NT) load_q(wave, qa, qb);
+        PSALM_SCHED_FENCE();
+        store_v(0, vt, Vs);
+        if constexpr (KLDS) store_v(0, kt, Ks);
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int e = tid + i * 64 * NWV;
+            if (e < NB) Bs[e] = bt[i];
+        }
+        PSALM_SCHED_FENCE();
+        if constexpr (VIT > VB) {
+            load_v(VB, vt);
+            PSALM_SCHED_FENCE();
+            store_v(VB, vt, Vs);
+            PSALM_SCHED_FENCE();
+            load_v(2 * VB, vt);
+            PSALM_SCHED_FENCE();
+            store_v(2 * VB, vt, Vs);
+            PSALM_SCHED_FENCE();
+        }
+    }
     // r05: the relative-position index of a (query, key) pair is (yi - yj + WS-1) (2 WS-1) + (xi - xj + WS-1) = c(query) - c'(key) with
     // c'(j) = (j / WS) (2 WS-1) + j % WS; the key's part, as a BYTE offset into Bs, sits in a 288-byte LDS table instead of being re-derived per
     // score element (two divisions by 12 and the index arithmetic: ~10 of the ~16 VALU instructions an element cost -- ISA of r04: 590 per query tile)
@@ -149,8 +224,6 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
     for (int e = tid; e < N; e += 64 * NWV) Ki[e] = (unsigned short)(((e / WS) * (2 * WS - 1) + e % WS) * 4);
     float so_sc = 1.f;
     if constexpr (SO) {
-        float gmax = 0.f;
-        for (int r = lane; r < N; r += 64) gmax = fmaxf(gmax, a_inv[row0 + r]);
         gmax = wave_max(gmax);
         float bound = fminf(fmaxf(gmax * so_par[0] + so_par[1], 7.888609e-31f), 1.2676506e30f);        // [2^-100, 2^100]
         const unsigned eb = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;                        // bound * scale in [2^12, 2^13)
@@ -172,34 +245,45 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
         const int lx = gx < Wp - WS ? 0 : (gx < Wp - shift ? 1 : 2);
         return ly * 3 + lx;
     };
-    int klab[NT][4];                                                     // labels of the keys this lane holds (16 tk + 4 kk + r)
-    if (shift > 0) {
+    // labels (0..8) of the 36 keys this lane holds (16 tk + 4 kk + r), one nibble each: 5 registers instead of 36 -- the kernel's register
+    // count decides how many wavefronts a SIMD holds (r05: 321 registers = ONE; the matrix instructions of a query tile then wait out its
+    // own softmax arithmetic and K fetches with nothing else to issue)
+    unsigned klab[(NT * 4 + 7) / 8] = {};
+    // (block-uniform) only the last row / column of windows of a shifted layer holds tokens of more than one region: every other window takes
+    // the copy of the tile loop without the 36 compare-and-select pairs per query tile
+    const bool masked = shift > 0 && (wh == nWh - 1 || ww == nWw - 1);
+    if (masked) {
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) klab[tk][r] = label(16 * tk + 4 * kk + r);
+            for (int r = 0; r < 4; ++r) klab[(4 * tk + r) >> 3] |= (unsigned)label(16 * tk + 4 * kk + r) << (4 * ((4 * tk + r) & 7));
     }
+    auto tiles = [&](auto MASKED) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int tq = wave; tq < NT; tq += NWV) {
         const int qi = 16 * tq + n16;                                    // this lane's query (column of S^T / O^T)
         float qf[8];
-        {
-            const float* p = qkv + (row0 + qi) * 3 * C + h * HD + 8 * kk;
-            const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], b = reinterpret_cast<const psalm_f32x4*>(p)[1];
-            qf[0] = a.x * scale; qf[1] = a.y * scale; qf[2] = a.z * scale; qf[3] = a.w * scale;
-            qf[4] = b.x * scale; qf[5] = b.y * scale; qf[6] = b.z * scale; qf[7] = b.w * scale;
-        }
+        qf[0] = qa.x * scale; qf[1] = qa.y * scale; qf[2] = qa.z * scale; qf[3] = qa.w * scale;
+        qf[4] = qb.x * scale; qf[5] = qb.y * scale; qf[6] = qb.z * scale; qf[7] = qb.w * scale;
+        if (tq + NWV < NT) load_q(tq + NWV, qa, qb);
         const int yi = qi / WS, xi = qi % WS;
         const int qc4 = ((yi + WS - 1) * (2 * WS - 1) + (xi + WS - 1)) * 4;            // byte offset of this query's part of the bias index
         const unsigned short* Kik = Ki + 4 * kk;                                        // this lane's keys: 16 tk + 4 kk + r
-        const int qlab = shift > 0 ? label(qi) : 0;
+        const int qlab = decltype(MASKED)::value ? label(qi) : 0;
         f32x4 sc[NT];
         float mx = -3.0e38f;
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* kp = qkv + (row0 + 16 * tk + n16) * 3 * C + C + h * HD + 8 * kk;
-            const psalm_f32x4 k0 = reinterpret_cast<const psalm_f32x4*>(kp)[0], k1 = reinterpret_cast<const psalm_f32x4*>(kp)[1];
+            f32x4 k0, k1;
+            if constexpr (KLDS) {
+                const float* kp = &Ks[(16 * tk + n16) * LS + 8 * kk];
+                k0 = reinterpret_cast<const f32x4*>(kp)[0];
+                k1 = reinterpret_cast<const f32x4*>(kp)[1];
+            } else {
+                k0 = kf[tk][0];
+                k1 = kf[tk][1];
+            }
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.x, qf[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.y, qf[1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0.z, qf[2], acc, 0, 0, 0);
@@ -211,11 +295,12 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[r] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bs) + (qc4 - (int)Kik[16 * tk + r]));
-                if (shift > 0 && klab[tk][r] != qlab) v += -100.0f;
+                if (decltype(MASKED)::value && (int)((klab[(4 * tk + r) >> 3] >> (4 * ((4 * tk + r) & 7))) & 15u) != qlab) v += -100.0f;
                 acc[r] = v;
                 mx = fmaxf(mx, v);
             }
             sc[tk] = acc;
+            if constexpr (KLDS) PSALM_SCHED_FENCE();              // register budget: one key tile's reads in flight, not nine
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -232,13 +317,15 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
         l += __shfl_xor(l, 32);
         f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};       // O^T d-tiles: rows d = 16 t + 4 kk + r, column q
 #pragma unroll
-        for (int tk = 0; tk < NT; ++tk)
+        for (int tk = 0; tk < NT; ++tk) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* vp = &Vs[(16 * tk + 4 * kk + r) * LS + n16];
                 o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], sc[tk][r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], sc[tk][r], o1, 0, 0, 0);
             }
+            if constexpr (KLDS) PSALM_SCHED_FENCE();
+        }
         const float inv = 1.f / l;
         if constexpr (SO) {
             unsigned short* op = reinterpret_cast<unsigned short*>(out) + (row0 + qi) * 2L * so_kp + h * HD + 4 * kk;
@@ -262,6 +349,9 @@ __global__ void __launch_bounds__(64 * NWV) PSALM_WAVES_PER_EU(PSALM_WINATTN_WPE
             *reinterpret_cast<psalm_f32x4*>(op + 16) = psalm_f32x4{o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
         }
     }
+    };
+    if (masked) tiles(std::true_type{});
+    else tiles(std::false_type{});
 }
 
 // psalm_window_attention (fp32 buffers, 12 x 12 windows) whose output leaves as the split-f16 A operand of the projection GEMM
@@ -277,9 +367,9 @@ extern "C" int psalm_window_attention_split(const float* qkv, const float* bias_
     const int nwin = B * nWh * nWw;
     if (nwin == 0) return 0;
     const size_t lds = (size_t)(144 * 36 + 23 * 23) * sizeof(float) + 288;                 // V rows + bias column + the key-index table
-    if ((long)nwin * heads <= PSALM_WINATTN_NWV3_MAX)                     // wavefronts per (window, head): as psalm_window_attention
-        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 3>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream, qkv,
-                           bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
+    if ((long)nwin * heads <= PSALM_WINATTN_KLDS_MAX)                     // flavour: as psalm_window_attention
+        hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 3, true>), dim3(nwin, heads), dim3(192), lds + 16 + 144 * 36 * sizeof(float),
+                           (hipStream_t)stream, qkv, bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
     else
         hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, true, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream, qkv,
                            bias_table, (float*)split_out, nWh, nWw, C, heads, shift, a_inv, bound_par, split_inv, split_kp);
@@ -295,14 +385,16 @@ extern "C" int psalm_window_attention(const void* qkv, const float* bias_table, 
     const int N = ws * ws;
     if (dtype == PSALM_F32 && ws == 12 && C % 4 == 0 && (uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 16 == 0) {     // fp32 matrix-core kernel
         const size_t lds = (size_t)(N * 36 + (2 * ws - 1) * (2 * ws - 1)) * sizeof(float) + (size_t)((N * 2 + 3) / 4 * 4);
-        // wavefronts per (window, head): 3 only when the grid cannot give every SIMD a wavefront anyway (r02n, 1024^2 image: stage 4, 288
-        // pairs: 41 -> 32 us; stage 3, 576 pairs: 48.5 -> 52.4; stage 1, 1936 pairs: 100 -> 136 -- profiles/r02n_winattn_nwv.jsonl)
-        const int nwv = (long)nwin * heads <= PSALM_WINATTN_NWV3_MAX ? 3 : 1;
-        if (nwv == 1)
-            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
-                               (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
+        // Two flavours (r05, kernel-trace durations of a 1024^2 image's four stages, profiles/r05q_winattn_trace_blocks.txt).  Up to 640 (window,
+        // head) pairs -- stage 3: 576, stage 4: 288 -- three wavefronts share a pair, K comes from an LDS copy and the kernel keeps to 119
+        // registers, so that three blocks fit a CU and the whole launch is resident: 47.2 -> 34.0 us and 31.0 -> 23.5 us.  Larger grids: one
+        // wavefront per pair with K resident in registers (occupancy 1): stage 1, 1936 pairs: 98 -> 78 us; stage 2, 968: 50 -> 40 (the
+        // three-wavefront flavour there: 47 us).  Both produce the r04 kernel's words.
+        if ((long)nwin * heads <= PSALM_WINATTN_KLDS_MAX)
+            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 3, true>), dim3(nwin, heads), dim3(192), lds + 16 + 144 * 36 * sizeof(float),
+                               (hipStream_t)stream, (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
         else
-            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12>), dim3(nwin, heads), dim3(192), lds, (hipStream_t)stream,
+            hipLaunchKernelGGL((window_attention_f32_mfma_kernel<32, 12, false, 1>), dim3(nwin, heads), dim3(64), lds, (hipStream_t)stream,
                                (const float*)qkv, bias_table, (float*)out, nWh, nWw, C, heads, shift);
         PSALM_LAUNCH_END("psalm_window_attention");
     }

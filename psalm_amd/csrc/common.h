@@ -91,6 +91,7 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #ifdef PSALM_EMU_BUILD
 #define PSALM_WAIT_VMCNT(N) do { } while (0)          /* the stand-in's copies are synchronous */
 #define PSALM_RAW_BARRIER() __syncthreads()
+#define PSALM_SCHED_FENCE() do { } while (0)
 #define PSALM_OPAQUE_VGPR(x) do { } while (0)
 __device__ __forceinline__ float psalm_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float psalm_exp2(float x) { return exp2f(x); }
@@ -99,6 +100,7 @@ __device__ __forceinline__ float psalm_exp2(float x) { return exp2f(x); }
 #define PSALM_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #define PSALM_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define PSALM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)       // no instruction is scheduled across this point
 __device__ __forceinline__ float psalm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     /* v_rcp_f32: 1 ulp */
 __device__ __forceinline__ float psalm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  /* v_exp_f32 (no denormal range fix-up: callers add 1) */
 #endif
