@@ -1097,17 +1097,29 @@ __global__ void __launch_bounds__(64) mha_attention_f32_mfma_kernel(const float*
     float qf[NQT][8];
     const unsigned char* mrow[NQT];
     bool qok[NQT], use_m[NQT];
+    {
+        // r05: the query fragments and the rows' all-masked flags of ALL tiles are fetched before the first one is used (the flag load sat
+        // behind a branch per tile: NQT dependent round trips before the first key tile; the flag address is always loadable)
+        f32x4 qa[NQT], qc[NQT];
+        unsigned char am[NQT];
 #pragma unroll
-    for (int t = 0; t < NQT; ++t) {
-        const int qi = 16 * t + n16;
-        qok[t] = qi < Lq;
-        const float* p = Q + ((long)b * Lq + min(qi, Lq - 1)) * ldq + h * HD + 8 * kk;
-        const psalm_f32x4 a = reinterpret_cast<const psalm_f32x4*>(p)[0], c = reinterpret_cast<const psalm_f32x4*>(p)[1];
-        qf[t][0] = a.x * scale; qf[t][1] = a.y * scale; qf[t][2] = a.z * scale; qf[t][3] = a.w * scale;
-        qf[t][4] = c.x * scale; qf[t][5] = c.y * scale; qf[t][6] = c.z * scale; qf[t][7] = c.w * scale;
-        // mask row of this lane's query (always a loadable address when a mask is given; `use_m` says whether it applies)
-        mrow[t] = mask ? mask + ((long)b * Lq + min(qi, Lq - 1)) * Lk : nullptr;
-        use_m[t] = mask && qok[t] && !(row_all_masked && row_all_masked[(long)b * Lq + min(qi, Lq - 1)]);
+        for (int t = 0; t < NQT; ++t) {
+            const int qi = 16 * t + n16;
+            const float* p = Q + ((long)b * Lq + min(qi, Lq - 1)) * ldq + h * HD + 8 * kk;
+            qa[t] = reinterpret_cast<const f32x4*>(p)[0];
+            qc[t] = reinterpret_cast<const f32x4*>(p)[1];
+            am[t] = row_all_masked ? row_all_masked[(long)b * Lq + min(qi, Lq - 1)] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            const int qi = 16 * t + n16;
+            qok[t] = qi < Lq;
+            qf[t][0] = qa[t].x * scale; qf[t][1] = qa[t].y * scale; qf[t][2] = qa[t].z * scale; qf[t][3] = qa[t].w * scale;
+            qf[t][4] = qc[t].x * scale; qf[t][5] = qc[t].y * scale; qf[t][6] = qc[t].z * scale; qf[t][7] = qc[t].w * scale;
+            // mask row of this lane's query (always a loadable address when a mask is given; `use_m` says whether it applies)
+            mrow[t] = mask ? mask + ((long)b * Lq + min(qi, Lq - 1)) * Lk : nullptr;
+            use_m[t] = mask && qok[t] && !am[t];
+        }
     }
     const bool fast_mask = mask && (Lk & 3) == 0 && (((uintptr_t)mask) & 3) == 0;
     f32x4 o0[NQT], o1[NQT];
@@ -1116,11 +1128,23 @@ __global__ void __launch_bounds__(64) mha_attention_f32_mfma_kernel(const float*
     for (int t = 0; t < NQT; ++t) { o0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; m[t] = -3.0e38f; l[t] = 0.f; }
     for (int kb = k_lo; kb < k_hi; kb += KT) {
         __syncthreads();
-        for (int e = lane; e < KT * (HD / 4); e += 64) {                  // 64 keys x 8 float4 per operand (rows past Lk: clamped, masked below)
-            const int r = e >> 3, c4 = (e & 7) * 4;
-            const long row = (long)b * Lk + min(kb + r, Lk - 1);
-            *reinterpret_cast<psalm_f32x4*>(&Ks[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(K + row * ldk + h * HD + c4);
-            *reinterpret_cast<psalm_f32x4*>(&Vs[r * LS + c4]) = *reinterpret_cast<const psalm_f32x4*>(V + row * ldv + h * HD + c4);
+        {                                                                 // 64 keys x 8 float4 per operand (rows past Lk: clamped, masked below)
+            // r05: the 16 loads of a tile are all in flight before the first LDS store waits for one (rolled: 8 dependent round trips per tile)
+            f32x4 kt_[KT * (HD / 4) / 64], vt_[KT * (HD / 4) / 64];
+#pragma unroll
+            for (int i = 0; i < KT * (HD / 4) / 64; ++i) {
+                const int e = lane + 64 * i, r = e >> 3, c4 = (e & 7) * 4;
+                const long row = (long)b * Lk + min(kb + r, Lk - 1);
+                kt_[i] = *reinterpret_cast<const f32x4*>(K + row * ldk + h * HD + c4);
+                vt_[i] = *reinterpret_cast<const f32x4*>(V + row * ldv + h * HD + c4);
+            }
+            PSALM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < KT * (HD / 4) / 64; ++i) {
+                const int e = lane + 64 * i, r = e >> 3, c4 = (e & 7) * 4;
+                *reinterpret_cast<f32x4*>(&Ks[r * LS + c4]) = kt_[i];
+                *reinterpret_cast<f32x4*>(&Vs[r * LS + c4]) = vt_[i];
+            }
         }
         __syncthreads();
         unsigned mbn[NQT];                                                // blocked flags of the NEXT key tile (byte r = key kj + r)

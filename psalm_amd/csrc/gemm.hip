@@ -510,6 +510,25 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 
     // fragment read offsets: row (lane&31) of a 32-row sub-tile, k-chunk (2*kk + hi) ^ f,  f = ((lane&31) >> SWS) & (SLOTS-1)
     const int n32 = lane & 31, hi = lane >> 5, fsw = (n32 >> SWS) & (SLOTS - 1);
+    // r05: the operands of the direct fp32 epilogue that do not depend on the K loop -- the column scales / bias of the wave's TN columns, the
+    // row scales of its first m-tile -- are fetched BEFORE the loop (20 registers on the 64 x 128 tile): behind it they were one more exposed
+    // global round trip in launches of 17..50 us.  (Not on the phased 256 x 256 kernels: no registers to spare; not for split-f16 output tiles.)
+    constexpr bool EPF = std::is_same<TC, float>::value && !PH8 && !SO && !CONV;
+    float pf_wsc[TN], pf_bias[TN], pf_asc[16];
+    if constexpr (EPF) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = min(bn + wn * (BN / WN) + j * 32 + n32, g.N - 1);
+            pf_wsc[j] = 1.f;
+            if constexpr (X3) pf_wsc[j] = fa.w_scale[col];
+            pf_bias[j] = (fa.slab == nullptr && g.bias) ? g.bias[col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pf_asc[r] = 1.f;
+            if constexpr (X3) pf_asc[r] = fa.a_scale[min(bm + wm * (BM / WM) + 4 * hi + (r & 3) + 8 * (r >> 2), g.M - 1)];
+        }
+    }
     const int a_row0 = wm * (BM / WM) + n32, b_row0 = wn * (BN / WN) + n32;
 
     // NS-deep ring, prefetch distance NS-1 tiles, ONE barrier per K step.  At the top of step kt the copies of tiles
@@ -875,9 +894,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
                 const int col = bn + wn * (BN / WN) + j * 32 + n32;
                 const bool ok = col < g.N;
                 coff[j] = ok ? (unsigned)col * 4u : PSALM_BUF_OOB;
-                wsc[j] = 1.f;
-                if constexpr (X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
-                bias_c[j] = (!split && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
+                if constexpr (EPF) {
+                    wsc[j] = pf_wsc[j];
+                    bias_c[j] = pf_bias[j];
+                } else {
+                    wsc[j] = 1.f;
+                    if constexpr (X3) wsc[j] = fa.w_scale[min(col, g.N - 1)];
+                    bias_c[j] = (!split && g.bias) ? g.bias[min(col, g.N - 1)] : 0.f;
+                }
                 actc[j] = !split && act != ACT_NONE && col >= g.act_col_start;
             }
             // Software-pipelined over the TM x TN accumulator tiles: per tile  compute 16 results -> issue the LOADS of the next tile
@@ -888,8 +912,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             float asc[16], rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                asc[r] = 1.f;
-                if constexpr (X3) asc[r] = fa.a_scale[min(bm + row_off(0, r), g.M - 1)];
+                if constexpr (EPF) asc[r] = pf_asc[r];
+                else {
+                    asc[r] = 1.f;
+                    if constexpr (X3) asc[r] = fa.a_scale[min(bm + row_off(0, r), g.M - 1)];
+                }
                 rv[r] = R ? psalm_buf_load_f32(rr, (unsigned)((long)row_off(0, r) * g.ldr * 4) + coff[0]) : 0.f;
             }
 #pragma unroll
