@@ -1635,6 +1635,16 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // r05: the bias / residual values of the element(s) this thread finishes are fetched before the K loop, not behind the LDS reduction
+    constexpr int EPT = 1024 / (64 * NWV);
+    float pbias[EPT], pres[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * 64 * NWV, r = e >> 6, ln = e & 63;
+        const int row = min(bm + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), g.M - 1), col = min(bn + (ln & 31), g.N - 1);
+        pbias[k] = g.bias ? g.bias[(g.act & ACT_BIAS_ROW) ? row : col] : 0.f;
+        pres[k] = g.res ? ldf((const TC*)g.res + (long)row * g.ldr + col) : 0.f;
+    }
     int c = c_lo;
     auto group = [&](auto NT_) {
         constexpr int NT = decltype(NT_)::value;
@@ -1656,13 +1666,15 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
     };
     while (c + 8 <= c_hi) group(std::integral_constant<int, 8>{});
     if (c + 4 <= c_hi) group(std::integral_constant<int, 4>{});
-    while (c < c_hi) group(std::integral_constant<int, 1>{});
+    if (c + 2 <= c_hi) group(std::integral_constant<int, 2>{});        // K = 256 on 16 waves: 2 chunks per wave -- one round trip, not two
+    if (c < c_hi) group(std::integral_constant<int, 1>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][r * 64 + lane] = acc[r];
     __syncthreads();
     // element e = r * 64 + lane of the accumulator layout: row (r&3) + 8(r>>2) + 4(lane>>5), column lane & 31
-    for (int e = tid; e < 1024; e += 64 * NWV) {
-        const int r = e >> 6, ln = e & 63;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * 64 * NWV, r = e >> 6, ln = e & 63;
         const int row = bm + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = bn + (ln & 31);
         float v = 0.f;
 #pragma unroll
@@ -1670,9 +1682,9 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
         if (row < g.M && col < g.N) {
             const int act = g.act & 15;
             const bool post = (g.act & ACT_POST_RESIDUAL) != 0, do_act = act != ACT_NONE && col >= g.act_col_start;
-            if (g.bias) v += g.bias[(g.act & ACT_BIAS_ROW) ? row : col];
+            if (g.bias) v += pbias[k];
             if (do_act && !post) v = apply_act(v, act);
-            if (g.res) v += ldf((const TC*)g.res + (long)row * g.ldr + col);
+            if (g.res) v += pres[k];
             if (do_act && post) v = apply_act(v, act);
             stf((TC*)g.C + (long)row * g.ldc + col, v);
         }
