@@ -239,7 +239,7 @@ def test_llm_single_product_side_mode_changes_the_llm_only_and_leaves_the_defaul
         PSALM(cfg, sd, ops=ops, precision="fp32", llm_products=1)
 
 
-@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 3), ("region", 2)])
+@pytest.mark.parametrize("task,batch", [("panoptic", 1), ("referring", 2), ("region", 1)])      # (ragged batch: referring; the GPU test runs full size)
 def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
     """psalm_swin_forward / psalm_phi_forward (csrc/stages.hip; SURVEY section 8(b): the stage-level C ABI behind the model API) issues the Phi decoder's launch
     sequence from native code -- ONE ctypes call instead of ~4 per layer.  Same launches, same order: the hidden states, and everything
@@ -250,7 +250,7 @@ def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
     inputs = make_inputs(cfg, task, size=96, batch=batch, seed=3, num_classes=9)
     kw = {k: v for k, v in inputs.items() if k != "is_thing_list"}
     ops = make_ops("emu")
-    for prods in (3, 1):
+    for prods in ((3, 1) if task == "panoptic" else (3,)):       # (the one-product side mode differs in the LLM stage only: one task covers it)
         m = PSALM(cfg, sd, ops=ops, precision="f16x3", llm_products=prods)
         assert m.c_stages
         sa, sb = {}, {}
