@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
             const int col = min(bn + wn * (BN / WN) + j * 32 + n32, g.N - 1);
             pf_wsc[j] = 1.f;
             if constexpr (X3) pf_wsc[j] = fa.w_scale[col];
-            pf_bias[j] = (fa.slab == nullptr && g.bias) ? g.bias[col] : 0.f;
+            pf_bias[j] = (fa.slab == nullptr && g.bias && !(g.act & ACT_BIAS_ROW)) ? g.bias[col] : 0.f;   // (a per-ROW bias has M entries: LDS path)
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

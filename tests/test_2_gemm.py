@@ -690,6 +690,42 @@ def test_gemm_x3_direct_epilogue_edges(ops, policy, mode):
     assert (got[M:] == 7).all() and (got[:, :8] == 7).all() and (got[:, 8 + N:] == 7).all()
 
 
+def test_gemm_x3_row_bias_is_never_read_past_its_m_entries(ops):
+    """A per-ROW bias (ACT_BIAS_ROW: the transposed projections of the mask decoder, model.py `pr.lvl*.v`) has M entries while the output has N >> M
+    columns.  The fp32 epilogue's operands are fetched before the K loop (r05); fetching `bias[column]` there for such a GEMM reads up to N - M
+    floats past the tensor.  Host emulator only: the bias sits at the very end of a page whose successor is PROT_NONE, so one stray read is a
+    segfault, not a silently unused value."""
+    if ops.device.type != "cpu":
+        pytest.skip("guard-page check: host pointers")
+    import ctypes, mmap
+    M, N, K = 128, 1024, 64
+    page = mmap.PAGESIZE
+    buf = mmap.mmap(-1, 2 * page)
+    addr = ctypes.addressof(ctypes.c_char.from_buffer(buf))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(addr + page, page, 0) == 0                # PROT_NONE behind the bias
+    try:
+        whole = torch.frombuffer(buf, dtype=torch.float32, count=page // 4)
+        g = torch.Generator().manual_seed(9)
+        bias = whole[page // 4 - M:]
+        bias.copy_(torch.randn(M, generator=g))
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.3
+        for policy in (64, 128):
+            ops.gemm_tile_policy(policy)
+            try:
+                got = ops.gemm_x3(a, w, bias, None, H.ACT_BIAS_ROW, 0)
+            finally:
+                ops.gemm_tile_policy(0)
+            y = a.double() @ w.double().t() + bias.double()[:, None]
+            assert (got.double() - y).abs().max() <= 3e-6 * y.abs().max() * K ** 0.5
+        del bias, whole
+    finally:
+        libc.mprotect(addr + page, page, 3)
+    buf.close()
+
+
 def test_split_output_bound_debug_check_heavy_tailed_weights(ops):
     """the L1 bound behind the split-output scale was validated on Gaussian weights only.  With heavy-tailed weights
     (a few outlier channels carry most of every row's L1 norm while typical activations never excite them) the bound is much looser; the
