@@ -1,4 +1,4 @@
-# r05q: window attention -- r05's two flavours against the kernel they replace (tools/experiments/_build/libpsalm_hip_r05head_winattn.so), by
+# r05q: window attention -- r05's two flavours against the kernel they replace (tools/experiments/build_side_lib.sh r05head_winattn f7a93b9 attention), by
 # KERNEL TRACE; the op tests and the e2e parity tests on hardware; a quick bench line
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
