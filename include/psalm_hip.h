@@ -28,10 +28,26 @@ const char* psalm_last_error(void);
  * integers for pointers.   4: the e4m3 cross-term ("x8") operand form and its `form` / `x8` / `split_form` arguments are gone (r04);
  * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
  * 6: psalm_gemm_x3_set_products, psalm_fuse_masks, the stage-level psalm_phi_forward (r05); psalm_causal_attention_f32_workspace grew by one
- *    byte per 32-key tile. */
-#define PSALM_ABI_VERSION 6
+ *    byte per 32-key tile.
+ * 7: psalm_set_tuning / psalm_get_tuning (r06). */
+#define PSALM_ABI_VERSION 7
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
+
+/* Process-wide tuning switches, each an atomic word (safe to flip while other host threads launch: their next launch sees the old or the new
+ * value).  Every switch chooses between kernel forms whose results are identical word for word; they exist for A/B measurements and tests.
+ *   PSALM_TUNE_GEMM_XCD_KSPLIT  1 (default): in split-K launches of the direct-to-LDS GEMM the K slice decides a block's XCD (each operand slice
+ *                               is fetched into one XCD's L2); 0: the r01-r05 placement (a run of tiles per XCD, every XCD walks the whole K range)
+ *   PSALM_TUNE_ATTN_XCD_HEADS   1 (default): psalm_causal_attention_f32* places all query-tile blocks of a head on one XCD (4 heads' K / V per L2);
+ *                               0: the r02-r05 placement (a head's blocks spread over all eight)
+ *   PSALM_TUNE_GEMM_MID         1 (default): mid-size split-f16 GEMMs take the 64 x 64 wave-tile kernel where the selection prefers it; 0: r05 kernels
+ *   PSALM_TUNE_RESERVED3..7     unused */
+#define PSALM_TUNE_GEMM_XCD_KSPLIT 0
+#define PSALM_TUNE_ATTN_XCD_HEADS 1
+#define PSALM_TUNE_GEMM_MID 2
+#define PSALM_TUNE_COUNT 8
+int psalm_set_tuning(int key, int value);
+int psalm_get_tuning(int key);
 
 /* Replaces MSDA.ms_deform_attn_forward, the reference's own native-op seam:
  *   OPS/src/vision.cpp:18-21 (pybind), OPS/src/ms_deform_attn.h:25-44 (dispatch),

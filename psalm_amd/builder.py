@@ -135,6 +135,13 @@ class ImagePreprocessor:
 
     def preprocess(self, dataset_dict, region_mask_type=None, mask_format="polygon", ignore_label=None):
         d = dict(dataset_dict)
+        # The reference's mappers turn annotation RLEs into `instances.region_masks` here (coco_instance_mapper.py:233-252: decode ->
+        # enhance_with_circles(10 | 5) -> transforms.apply_segmentation).  That annotation transform is the dataset side of the interactive task
+        # and is not done by this processor: a caller that asks for it must not get an image dict that silently lacks the region masks.
+        if region_mask_type is not None:
+            raise NotImplementedError(
+                "ImagePreprocessor.preprocess(region_mask_type=...) is not implemented: build `region_masks` with "
+                "psalm_amd.preprocess.region_masks_from_annotations(...) (or the reference's dataset mapper) and pass them in the instances")
         if "image" in d and not torch.is_tensor(d["image"]) or ("image" in d and d["image"].dtype == torch.uint8):
             img = d["image"]
         else:

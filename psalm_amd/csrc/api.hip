@@ -2,6 +2,7 @@
 #include "common.h"
 #include "psalm_hip.h"      // PSALM_ABI_VERSION (and every declaration checked against its definition in this translation unit)
 
+#include <atomic>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
@@ -11,6 +12,18 @@ extern "C" void psalm_set_error(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* psalm_last_error() { return g_err; }
+// Process-wide tuning switches (psalm_hip.h: PSALM_TUNE_*).  Atomic words: a host thread that flips one while another thread launches makes that
+// thread's NEXT launch see the old or the new value, never a torn one; every switch selects between forms with identical results.
+static std::atomic<int> g_tuning[PSALM_TUNE_COUNT] = {{1}, {1}, {1}, {1}, {0}, {0}, {0}, {0}};
+extern "C" int psalm_set_tuning(int key, int value) {
+    if (key < 0 || key >= PSALM_TUNE_COUNT) { psalm_set_error("psalm_set_tuning: unknown key"); return -1; }
+    g_tuning[key].store(value, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int psalm_get_tuning(int key) {
+    if (key < 0 || key >= PSALM_TUNE_COUNT) return 0;
+    return g_tuning[key].load(std::memory_order_relaxed);
+}
 extern "C" int psalm_abi_version() { return PSALM_ABI_VERSION; }
 // "hip-gfx950" for the product library; the host-emulation build used by the CPU tests reports "emu".
 extern "C" const char* psalm_backend() {

@@ -752,17 +752,29 @@ template <bool SO>
 __global__ void __launch_bounds__(256) PSALM_WAVES_PER_EU(3)
 causal_attention_f32_splitk_kernel(const float* __restrict__ Qr, const float* __restrict__ Kr, const unsigned char* __restrict__ Mk,
                                    const unsigned char* __restrict__ Tk, const float* __restrict__ base, long ld, int v_off, float* out, long ldo,
-                                   int o_off, int L, int Lp, int heads, const float* __restrict__ so_inv, int so_kp, int pair) {
+                                   int o_off, int L, int Lp, int heads, const float* __restrict__ so_inv, int so_kp, int pair, int xcd_heads) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int HD = 64, OS = HD + 4;
     __shared__ __attribute__((aligned(16))) float Os[4][32 * OS];         // per-wave O (q-major) for the merge
     __shared__ float Ml[4][2][32];                                        // per-wave (m, l) per query
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z, nqt = Lp / 32;
+    const int nqt = Lp / 32;
+    // Block -> (query-tile index bx, head h, batch b).  xcd_heads (r06; host: heads * B is a multiple of 8): the hardware deals linear block ids
+    // round-robin over the 8 XCDs, so with (bx, h, b) = blockIdx every head's blocks were spread over all eight and each XCD's 4 MB L2 saw the
+    // K / V of all 32 heads (15 MB: 172.9 MB fetched per launch against 30 MB compulsory, profiles/r05_pmc_hbm_traffic.json).  Here XCD x runs
+    // the heads x, x + 8, ... one after the other, all query tiles of a head on the same L2.
+    int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (xcd_heads) {
+        const int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        const int j = lin >> 3, hb = (lin & 7) + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+        h = hb % heads;
+        b = hb / heads;
+    }
     const long bh = (long)b * heads + h;
-    const int npass = pair ? ((int)(nqt - 1 - blockIdx.x) > (int)blockIdx.x ? 2 : 1) : 1;
+    const int npass = pair ? ((int)(nqt - 1 - bx) > bx ? 2 : 1) : 1;
     for (int pass = 0; pass < npass; ++pass) {
-    const int qt = pair ? (pass == 0 ? nqt - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)(gridDim.x - 1 - blockIdx.x);
+    const int qt = pair ? (pass == 0 ? nqt - 1 - bx : bx) : (int)(gridDim.x - 1 - bx);
     const int w0 = pass ? 3 - wave : wave;                                // second tile: key tiles dealt in the opposite wave order
     if (pass) __syncthreads();                                            // the first tile's merge has been read out of Os / Ml
     const int qi = qt * 32 + n32;                                         // this lane's query column (row qi < Lp of Qr)
@@ -951,12 +963,13 @@ static int causal_attention_f32_impl(const float* qkv, long ld, int q_off, int k
     const int pair = 1;                                                   // balanced pairs of query tiles per block (r02n; the one-tile form stays in the kernel)
     const int nqt = Lp / 32;
     const dim3 grid(pair ? (nqt + 1) / 2 : nqt, heads, B);
+    const int xcd_heads = ((heads * B) % 8 == 0 && psalm_get_tuning(PSALM_TUNE_ATTN_XCD_HEADS)) ? 1 : 0;
     if (so_inv)
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<true>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair);
+                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, so_inv, so_kp, pair, xcd_heads);
     else
         hipLaunchKernelGGL(causal_attention_f32_splitk_kernel<false>, grid, dim3(256), 0, s, (const float*)Qr, (const float*)Kr,
-                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair);
+                           (const unsigned char*)Mk, (const unsigned char*)Tk, qkv, ld, v_off, (float*)out, ldo, o_off, L, Lp, heads, (const float*)nullptr, 0, pair, xcd_heads);
     PSALM_LAUNCH_END(name);
 }
 extern "C" int psalm_causal_attention_f32(const float* qkv, long ld, int q_off, int k_off, int v_off, float* out, long ldo, int o_off,

@@ -178,6 +178,13 @@ __device__ __forceinline__ psalm_u32x4 psalm_buf_load_b128_s(psalm_rsrc r, unsig
 
 // ----------------------------------------------------------------------------- host side
 extern "C" void psalm_set_error(const char* msg);
+extern "C" int psalm_get_tuning(int key);          // api.hip; keys: PSALM_TUNE_* (mirrored from include/psalm_hip.h for the translation units that do not include it)
+#ifndef PSALM_TUNE_COUNT
+#define PSALM_TUNE_GEMM_XCD_KSPLIT 0
+#define PSALM_TUNE_ATTN_XCD_HEADS 1
+#define PSALM_TUNE_GEMM_MID 2
+#define PSALM_TUNE_COUNT 8
+#endif
 
 #define PSALM_CHECK_ARG(cond, msg)                                  \
     do {                                                            \

@@ -333,6 +333,11 @@ struct GemmFastArgs {
     int so_paired = 0;
     float* so_inv = nullptr;
     const float* so_par = nullptr;
+    // split-K placement (r06): 1 = the K slice, not the tile, decides a block's XCD.  The hardware deals linear block ids round-robin over the 8
+    // XCDs; with (tile, slice) = (blockIdx.x, blockIdx.y) every XCD held a run of TILES and walked their whole K range -- Phi [dense|fc2]: all 899
+    // A rows per XCD, 8 x 38 MB of operand reads from the fabric for 129 MB of compulsory traffic (profiles/r05_pmc_hbm_traffic.json: 3.6x).
+    // With slice = linear id % splits the blocks of one XCD share a K slice: each A / W slice is fetched into one XCD's L2 (two when splits = 4 ...).
+    int xcd_ksplit = 0;
 };
 // scale / inverse scale of a split-f16 row from an upper bound of its magnitudes: bound * sc in [2^12, 2^13)
 __device__ __forceinline__ void split_scale_from_bound(float bound, float& sc, float& inv) {
@@ -408,10 +413,18 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     PSALM_TL(0);
     const int wave = PH8 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;   // PH8: scalar (wave-row dependent barriers)
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    int tile, ksl;                                               // tile id, K-slice index of this block
+    if (fa.xcd_ksplit) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+        ksl = lin % (int)gridDim.y;
+        tile = lin / (int)gridDim.y;
+    } else {
+        tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+        ksl = blockIdx.y;
+    }
     const int bm = (g.row_fast ? tile % g.tiles_m : tile / g.tiles_n) * BM;
     const int bn = (g.row_fast ? tile / g.tiles_m : tile % g.tiles_n) * BN;
-    const int kbeg = blockIdx.y * fa.k_per_split;
+    const int kbeg = ksl * fa.k_per_split;
     const int kend = min(g.K, kbeg + fa.k_per_split);
     const bf16_t* A = (const bf16_t*)g.A;
     const bf16_t* W = (const bf16_t*)g.W;
@@ -880,7 +893,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         if constexpr (SO) lds_path = lds_path || (fa.so != nullptr && bn + BN > fa.so_col_start);
         if (!lds_path) {
             const bool post = (g.act & ACT_POST_RESIDUAL) != 0;
-            float* Cb = split ? fa.slab + (long)blockIdx.y * g.M * g.N : (float*)g.C;
+            float* Cb = split ? fa.slab + (long)ksl * g.M * g.N : (float*)g.C;
             const long ldo = split ? (long)g.N : g.ldc;
             const int rows_here = min(g.M - bm, BM);
             const psalm_rsrc rc = psalm_make_rsrc(Cb + (long)bm * ldo, (unsigned)min((long)rows_here * ldo * 4, 0x7ffff000L));
@@ -1142,7 +1155,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
     for (int c = 0; c < 8; ++c) bias8[c] = (!split && !brow && g.bias && col0 + c < g.N) ? g.bias[col0 + c] : 0.f;
     TC* C = (TC*)g.C;
     const TC* R = (const TC*)g.res;
-    float* P = split ? fa.slab + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* P = split ? fa.slab + (long)ksl * g.M * g.N : nullptr;
     // split-f16 output: the row-independent term of the magnitude bound and the two row-term parameters, in registers before the store loop
     // (inside it every read of so_par was a fresh global load behind the loop's own stores -- the compiler cannot prove they do not alias --
     // and the maximum over all rows of a_scale a chain of M / 64 dependent loads per wave: r03c time line, 23 us of store phase on the
@@ -1882,6 +1895,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     else fa.vec_store = (N % 8 == 0 && (uintptr_t)g.C % 16 == 0 && (g.ldc * csz) % 16 == 0 &&
                          (!g.res || ((uintptr_t)g.res % 16 == 0 && (g.ldr * csz) % 16 == 0))) ? 1 : 0;
     const dim3 grid((unsigned)tiles, splits);
+    fa.xcd_ksplit = (splits > 1 && (splits % 8 == 0 || 8 % splits == 0) && psalm_get_tuning(PSALM_TUNE_GEMM_XCD_KSPLIT)) ? 1 : 0;
     if (fa.so && fa.so_paired) {                                  // paired stores: instantiated for the kernels the automatic selection uses
         const bool ph_ = x3 && !slice && BM == 256 && g_ph8 && fa.k_per_split >= 128 && (g.K - (splits - 1) * fa.k_per_split) >= 128;
         const bool kpanel_small = x3 && !slice && BM != 256;     // K-panel form on 128 x 128 / 64 x 128 tiles (reached by the one-product mode)

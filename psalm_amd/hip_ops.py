@@ -48,7 +48,7 @@ def _dt(t: torch.Tensor) -> int:
         raise PsalmHipError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
 
 
-ABI_VERSION = 6        # == PSALM_ABI_VERSION of include/psalm_hip.h (tests/test_0_abi.py compares the two and the built library's answer)
+ABI_VERSION = 7        # == PSALM_ABI_VERSION of include/psalm_hip.h (tests/test_0_abi.py compares the two and the built library's answer)
 
 
 class _ProfiledLib:
@@ -62,7 +62,8 @@ class _ProfiledLib:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
         if not name.startswith("psalm_") or name in ("psalm_last_error", "psalm_backend", "psalm_abi_version", "psalm_gemm_last_kernel",
-                                                         "psalm_gemm_set_tile_policy", "psalm_gemm_x3_set_products") or name.endswith("_workspace"):
+                                                         "psalm_gemm_set_tile_policy", "psalm_gemm_x3_set_products", "psalm_set_tuning",
+                                                         "psalm_get_tuning") or name.endswith("_workspace"):
             return fn
 
         def call(*args):
@@ -677,6 +678,15 @@ class Ops:
         """f16 products formed per algorithmic product by this thread's split-f16 GEMMs: 3 (default, fp32-class) or 1 (hi.hi only: plain f16
         operands, a third of the matrix work -- the reduced-precision LLM side mode, not at the parity bar).  See psalm_gemm_x3_set_products."""
         self._check(self.lib.psalm_gemm_x3_set_products(int(n)), "psalm_gemm_x3_set_products")
+
+    TUNE_GEMM_XCD_KSPLIT, TUNE_ATTN_XCD_HEADS, TUNE_GEMM_MID = 0, 1, 2      # PSALM_TUNE_* of include/psalm_hip.h
+
+    def set_tuning(self, key: int, value: int):
+        """psalm_set_tuning: process-wide atomic switches between kernel forms with identical results (A/B runs, tests)."""
+        self._check(self.lib.psalm_set_tuning(int(key), int(value)), "psalm_set_tuning")
+
+    def get_tuning(self, key: int) -> int:
+        return int(self.lib.psalm_get_tuning(int(key)))
 
     def gemm_tile_policy(self, bm: int):
         """0 = automatic, 256 / 128 / 64 = force the direct-to-LDS kernel's tile height (tuning / tests)."""

@@ -13,16 +13,6 @@ from oracle import psalm_oracle as O
 DT = [torch.float32, torch.bfloat16]
 
 
-def _first_gpu_run_pending(ops):
-    """Cases added after round 5's GPU minutes were spent: they have run on the host emulator (and under its AddressSanitizer build) but never on
-    the MI355X.  The driver's round-end run is `pytest -x`; a case that has not seen the hardware once does not get to stop it.  Set
-    PSALM_RUN_NEW_GPU_CASES=1 to run them on a GPU box (the kernels themselves are covered there by the full-size tests of test_9)."""
-    import os
-    if ops.device.type != "cpu" and os.environ.get("PSALM_RUN_NEW_GPU_CASES", "0") in ("", "0"):
-        pytest.skip("new in r05 after the GPU budget was spent: emulator-verified only (PSALM_RUN_NEW_GPU_CASES=1 runs it)")
-
-
-
 def tol(dtype, scale=1.0):
     return (3e-5 if dtype == torch.float32 else 2 ** -7) * scale
 
@@ -147,7 +137,6 @@ def test_window_attention(ops, dtype, B, nWh, nWw, heads, shift):
     if nWh * nWw * heads * B > 640:
         if dtype != torch.float32:
             pytest.skip("the large grid is there for the fp32 kernel's second flavour")
-        _first_gpu_run_pending(ops)
     ws, hd = 12, 32
     C = heads * hd
     N = ws * ws
@@ -171,8 +160,6 @@ def test_window_attention(ops, dtype, B, nWh, nWw, heads, shift):
 def test_window_attention_split_output(ops, heads, shift, nWh, nWw):
     """psalm_window_attention_split == psalm_window_attention (fp32) followed by a split: one power-of-two scale per window from the bound
     max_j (a_inv[j] * par[0] + par[1]) over the window's rows (>= every |v| of the window), hi + lo reproduces the fp32 output to 22 bits."""
-    if nWh * nWw * heads > 640:
-        _first_gpu_run_pending(ops)
     B, ws, hd = 1, 12, 32
     C = heads * hd
     N, nW = ws * ws, nWh * nWw
@@ -604,7 +591,6 @@ def test_panoptic_degenerate_inputs_match_the_oracle(ops, case, Hh, Ww):
     labelled void, confident queries whose masks hold no pixel >= 0.5 -- an all-zero id map and an empty segments_info, from both arg-max kernels
     (4 pixels per thread / one pixel per thread), exactly as the oracle's restatement returns them."""
     from oracle import psalm_oracle as O
-    _first_gpu_run_pending(ops)
     Q, C = 20, 9
     g = torch.Generator().manual_seed(len(case) + Hh)
     mask = torch.randn(Q, Hh, Ww, generator=g) * 0.5 + (3.0 if case != "confident_but_empty_masks" else -6.0)
@@ -652,3 +638,28 @@ def test_panoptic_matches_oracle_inference(ops, Q, C, Hh, Ww):
     assert len(want_info) >= (3 if Q >= 24 else 1)                      # the case exercises the merge
     assert got_info == want_info
     assert torch.equal(pan.cpu(), want_pan)
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 100, 8), (2, 70, 4), (1, 300, 16)])
+def test_causal_attention_xcd_head_placement_is_bitwise_the_plain_placement(ops, B, L, heads):
+    """r06: with heads * B a multiple of 8 the fp32 causal kernel re-maps its linear block id so that every query-tile block of a head runs on
+    the same XCD (PSALM_TUNE_ATTN_XCD_HEADS).  The map is a bijection of the grid: the outputs are the same words as with blockIdx taken as is."""
+    hd, rot = 64, 32
+    H = heads * hd
+    g = torch.Generator().manual_seed(70 + heads)
+    buf = torch.randn(B * L, 3 * H, generator=g) * 0.8
+    key_mask = torch.ones(B, L, dtype=torch.uint8)
+    if B > 1:
+        key_mask[1, L - 20:] = 0
+    cos, sin = _rope_tables(L, rot)
+    outs = []
+    try:
+        for v in (0, 1):
+            ops.set_tuning(ops.TUNE_ATTN_XCD_HEADS, v)
+            out = torch.zeros(B * L, H, device=ops.device)
+            ops.causal_attention(buf.to(ops.device), 0, H, 2 * H, out, 0, *dev(ops, cos, sin, key_mask), B, L, heads, hd, rot)
+            outs.append(out.cpu())
+    finally:
+        ops.set_tuning(ops.TUNE_ATTN_XCD_HEADS, 1)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert outs[0].abs().max() > 0

@@ -790,3 +790,29 @@ def test_gemm_x3_single_product_is_the_hi_hi_term(ops, M, N, K, policy):
     assert torch.equal(again, full)                                           # the default is back
     with pytest.raises(Exception):
         ops.x3_products(2)
+
+
+@pytest.mark.parametrize("M,N,K,policy", [(270, 300, 704, 128), (300, 520, 1536, 256), (130, 260, 3072, 64)])      # 4, 8, 16 K slices
+def test_gemm_x3_split_k_xcd_placement_is_bitwise_the_plain_placement(ops, M, N, K, policy):
+    """r06: in split-K launches whose slice count divides 8 (or is a multiple of it) the K slice, not the tile, decides a block's XCD
+    (PSALM_TUNE_GEMM_XCD_KSPLIT): (tile, slice) = (lin / splits, lin % splits) of the linear block id.  A bijection of the grid -- slabs, the
+    reduce and the output are the same words as with (blockIdx.x, blockIdx.y)."""
+    g = torch.Generator().manual_seed(M + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = ops.device
+    outs, kernels = [], []
+    ops.gemm_tile_policy(policy)
+    try:
+        assert ops.gemm_describe(M, N, 3 * K, x3=True)[3] in (4, 8, 16)
+        for v in (0, 1):
+            ops.set_tuning(ops.TUNE_GEMM_XCD_KSPLIT, v)
+            outs.append(ops.gemm_x3(a.to(d), w.to(d), bias.to(d), res.to(d), H.ACT_NONE).cpu())
+            kernels.append(ops.gemm_last_kernel())
+    finally:
+        ops.set_tuning(ops.TUNE_GEMM_XCD_KSPLIT, 1)
+        ops.gemm_tile_policy(0)
+    assert "splitk_reduce" in kernels[0] and kernels[0] == kernels[1], kernels
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    want = a.double() @ w.double().T + bias.double() + res.double()
+    assert (outs[1].double() - want).abs().max() <= 2e-5 * want.abs().max()
