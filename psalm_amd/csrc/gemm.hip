@@ -23,6 +23,7 @@
 // blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (sharing the A row-panel) are placed on the
 // same XCD (block b runs on XCD b % 8) so the panel is fetched into that XCD's L2 once.
 #include "common.h"
+#include <atomic>
 #include <cstring>
 #include <type_traits>
 
@@ -382,9 +383,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // 12..48 K steps) ran their K loops at L2 latency with X3 = 1 (r02k: 100-200 TFLOP/s algorithmic on the 128^2 / 64x128 tiles).
 // SO = true (X3 == 1 only): the epilogue can emit split-f16 output (GemmFastArgs::so; psalm_gemm_x3_split).  A separate instantiation so that
 // the plain kernels' epilogue -- at the register limit on the 256 x 256 tile -- is untouched.
-template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8 = 0, int X3 = 0,
+// PH8_ = 5 (r06; generic K loop, slice form): the copies of the NEXT stage are not issued as one burst behind the barrier but one by one between
+// the groups of three matrix instructions of this stage ("ILV").  A global_load_lds costs its wave ~60 - 180 clocks of issue (MI355X_MICROARCH
+// section "constants"); the burst of 6 - 12 of them at the top of a K step was dead time of the wave's matrix pipe -- r04a time line: K steps of
+// ~2100 clocks for 768 clocks of matrix instructions on the one-block-per-CU launches.
+template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8_ = 0, int X3 = 0,
           bool SO = false, bool PAIR = false>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastArgs fa) {
+    constexpr int PH8 = (PH8_ >= 1 && PH8_ <= 4) ? PH8_ : 0;     // phased 256 x 256 schedules
+    constexpr bool ILV = PH8_ == 5;
+    static_assert(PH8_ >= 0 && PH8_ <= 5 && (!ILV || (X3 == 2 && NS == 2 && !CONV)), "ILV: slice form, two stages");
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || (X3 == 2 && BK == 32 && NS == 2), "split-f16 output: K-panel form, or 32-deep slices in two stages");
     static_assert(X3 >= 0 && X3 <= 2, "X3: 0 bf16 operands, 1 split-f16 K-panel form, 2 split-f16 slice form");
@@ -513,6 +521,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         }
     };
 
+    // copy p of the stage's (A_CH + B_CH) * 2 copies of this wave, in issue()'s order: A hi, W hi, A lo, W lo  (slice form)
+    auto issue_piece = [&](int buf, int koff, int p) __attribute__((always_inline)) {
+        if constexpr (X3 == 2 && !CONV) {
+            const int half = p / (A_CH + B_CH), q = p % (A_CH + B_CH);    // half: 0 hi images, 1 lo images
+            bf16_t* base = smem[buf] + half * (BM + BN) * BK;
+            const int kcol = koff + half * fa.x3_kp;
+            if (q < A_CH) psalm_glds16(asrc[q] + kcol, base + a_chunk(q) * RPC * BK);
+            else psalm_glds16(bsrc[q - A_CH] + kcol, base + BM * BK + b_chunk(q - A_CH) * RPC * BK);
+        }
+    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -817,7 +835,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
         }
         PSALM_RAW_BARRIER();
         if (kt == 0) PSALM_TL(2);
-        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        const bool more = kt + NS - 1 < nk;                      // (block-uniform) a tile is left to prefetch
+        if (!ILV && more) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
         // register double-buffered fragments: the ds_read_b128s of k-step kk+1 are issued BEFORE the MFMAs of k-step kk, so
@@ -857,6 +876,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_bf16_glds_kernel(GemmFastAr
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
+                        if constexpr (ILV) {                     // this group's share of the next stage's copies, behind its first product
+                            constexpr int G = (BK / 16) * TM * TN, PPG = (LPT + G - 1) / G;
+                            const int gidx = (kk * TM + i) * TN + j;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) {
+#pragma unroll
+                                for (int p = gidx * PPG; p < (gidx + 1) * PPG && p < LPT; ++p) issue_piece((kt + 1) & 1, (kt + 1) * BK, p);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
                         acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
                     }
@@ -1749,6 +1778,10 @@ extern "C" int psalm_gemm_x3_set_products(int n) {
     g_x3_products = n;
     return 0;
 }
+// r06 "mid" forms of the split-f16 slice GEMM (policy codes 4400 + v; 0 = automatic selection, see select_mid_form):
+//   1  the r05 tile, copies interleaved with the matrix instructions (ILV)        2 / 3  256 x 128 / 128 x 256 blocks of eight 64 x 64 wave tiles, ILV
+//   4 / 5  256 x 128 / 128 x 256, copies as one burst                             9  the r05 kernels whatever the automatic selection says
+static std::atomic<int> g_mid_form{0};
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm == 640 || (bm >= 642 && bm <= 644)) { g_ring64 = bm - 640; return 0; }   // 64x128, BK 64, ring depth auto / 2 / 3 / 4
@@ -1758,6 +1791,7 @@ extern "C" int psalm_gemm_set_tile_policy(int bm) {
     if (bm >= 2568 && bm <= 2570) { g_ph8 = bm - 2567; return 0; }             // 256x256 PH8 K loop variant 1 / 2 / 3
     if (bm == 2560) { g_ph8 = 0; return 0; }                                    // ... off
     if (bm >= 2580 && bm <= 2582) { g_ph8_slice = bm - 2580; return 0; }        // split-f16 on 256 x 256 tiles: K-panel form / 32-deep slices / slices with the all-padding m-tiles left out (2582: the DEFAULT since r04p)
+    if (bm >= 4400 && bm <= 4409) { g_mid_form.store(bm - 4400); return 0; }     // r06 mid-size forms (see g_mid_form)
     if (bm >= 3300 && bm <= 3308) { g_x3_slice = bm - 3300; return 0; }         // split-f16 K loop form on the 128 / 64-row tiles (7 / 8: r05 ring depths)
     if (bm == 128128) { g_ring_depth = 128; return 0; }                        // 128x128, BK 128 (K % 128 == 0 problems only)
     if (bm != 0 && bm != 256 && bm != 128 && bm != 64 && bm != 12864) { psalm_set_error("psalm_gemm_set_tile_policy: 0, 256, 128 or 64"); return -1; }
@@ -1845,6 +1879,12 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
     return 0;
 }
 
+// Automatic choice among the r06 mid forms (g_mid_form) for an un-split slice-form problem whose r05 tile height is BM: 9 = keep the r05 kernel.
+static int select_mid_form(int M, int N, int Kp, int BM, bool so) {
+    (void)M; (void)N; (void)Kp; (void)BM; (void)so;
+    return 9;
+}
+
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
 struct LnEpilogue { const float* gamma; const float* beta; float eps; void* out; int dtype; long ld; void* split_out = nullptr; float* split_inv = nullptr; };
 extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, int rows, int C,
@@ -1878,6 +1918,16 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         splits = cdiv(g.K, kps);
     }
     if (fa.so && slice != 3 && slice != 6) slice = 0;             // split-f16 output: K-panel form, form 3 or form 6
+    // r06 mid forms: only on the default slice form of the 64 / 128-row tiles (32-deep slices, two stages), never with split-K
+    int mid = 0;
+    if (x3 && slice == 3 && splits == 1 && !g_tile_policy && M > 192) {
+        mid = g_mid_form.load();
+        if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, fa.x3_kp, BM, fa.so != nullptr) : 9;
+        if (fa.so && fa.so_paired && fa.so_col_start % 256 != 0 && (mid == 3 || mid == 5)) mid = 1;      // (paired stores: no tile straddles so_col_start)
+        if (mid == 2 || mid == 4) { BM = 256; BN = 128; }
+        else if (mid == 3 || mid == 5) { BM = 128; BN = 256; }
+        if (mid == 9) mid = 0;
+    }
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
         kps = splits > 1 ? cdiv(cdiv(g.K, 64), splits) * 64 : g.K;
@@ -1929,6 +1979,20 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (slice == 6 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true, true);
         else if (slice == 6 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true);
         else if (slice == 6) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, false);
+        // r06 mid forms: ILV (PH8_ = 5) on the r05 tiles, and the eight-wave 256 x 128 / 128 x 256 blocks
+#define GO_MID(NT_, ...)                                                                                                                       \
+        do {                                                                                                                                   \
+            if (fa.so && fa.so_paired) GO(NT_, "float", float, __VA_ARGS__, 2, true, true);                                                    \
+            else if (fa.so) GO(NT_, "float", float, __VA_ARGS__, 2, true);                                                                     \
+            else GO(NT_, "float", float, __VA_ARGS__, 2, false);                                                                               \
+        } while (0)
+        else if (mid == 2) GO_MID(512, 256, 128, 4, 2, 2, false, 32, 5);
+        else if (mid == 3) GO_MID(512, 128, 256, 2, 4, 2, false, 32, 5);
+        else if (mid == 4) GO_MID(512, 256, 128, 4, 2, 2, false, 32, 0);
+        else if (mid == 5) GO_MID(512, 128, 256, 2, 4, 2, false, 32, 0);
+        else if (mid == 1 && BM == 128) GO_MID(256, 128, 128, 2, 2, 2, false, 32, 5);
+        else if (mid == 1) GO_MID(256, 64, 128, 2, 2, 2, false, 32, 5);
+#undef GO_MID
         else if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (slice == 3 && fa.so && fa.so_paired) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (BM == 128 && slice >= 3 && fa.so) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true);

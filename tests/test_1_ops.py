@@ -129,14 +129,12 @@ def test_add_gather_segment(ops):
     assert (got - want).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("dtype", DT)
 # (1, 6, 7, 16, *): 672 (window, head) pairs -- above the 640 up to which the fp32 kernel runs its three-wavefront K-through-LDS flavour: the
-# one-wavefront flavour with K resident in registers (a 1024^2 image's stages 1 - 2)
-@pytest.mark.parametrize("B,nWh,nWw,heads,shift", [(1, 1, 1, 2, 0), (1, 2, 3, 1, 6), (2, 2, 2, 2, 6), (1, 6, 7, 16, 6), (1, 6, 7, 16, 0)])
+# one-wavefront flavour with K resident in registers (a 1024^2 image's stages 1 - 2); fp32 only (the large grid is there for that flavour)
+@pytest.mark.parametrize("dtype,B,nWh,nWw,heads,shift",
+                         [(dt, *c) for dt in DT for c in [(1, 1, 1, 2, 0), (1, 2, 3, 1, 6), (2, 2, 2, 2, 6)]] +
+                         [(torch.float32, 1, 6, 7, 16, 6), (torch.float32, 1, 6, 7, 16, 0)])
 def test_window_attention(ops, dtype, B, nWh, nWw, heads, shift):
-    if nWh * nWw * heads * B > 640:
-        if dtype != torch.float32:
-            pytest.skip("the large grid is there for the fp32 kernel's second flavour")
     ws, hd = 12, 32
     C = heads * hd
     N = ws * ws
