@@ -816,3 +816,57 @@ def test_gemm_x3_split_k_xcd_placement_is_bitwise_the_plain_placement(ops, M, N,
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     want = a.double() @ w.double().T + bias.double() + res.double()
     assert (outs[1].double() - want).abs().max() <= 2e-5 * want.abs().max()
+
+
+MID_KERNELS = {1: ", 2, 2, 2, false, 32, 5, 2", 2: "256, 128, 4, 2, 2, false, 32, 5, 2", 3: "128, 256, 2, 4, 2, false, 32, 5, 2",
+               4: "256, 128, 4, 2, 2, false, 32, 0, 2", 5: "128, 256, 2, 4, 2, false, 32, 0, 2",
+               6: "256, 128, 4, 2, 3, false, 32, 6, 2", 7: "128, 256, 2, 4, 3, false, 32, 6, 2", 8: "256, 128, 4, 2, 3, false, 32, 7, 2",
+               10: "128, 128, 2, 2, 3, false, 32, 6, 2", 11: "64, 128, 2, 2, 3, false, 32, 6, 2"}
+
+
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 192), (515, 300, 64), (257, 260, 128)])
+def test_gemm_x3_mid_forms_are_bitwise_the_r05_kernels(ops, form, M, N, K):
+    """r06 mid-size forms of the split-f16 slice GEMM (policy 4400 + form): copies interleaved with the matrix instructions (ILV) and the
+    eight-wave 256 x 128 / 128 x 256 blocks of 64 x 64 wave tiles, and (6 - 11) the blocks with dedicated loader wavefronts (LW: the matrix waves
+    issue no copy; three stages).  Every output element is the same chain of matrix instructions over the same
+    32-deep slices whatever the tile: the results equal the r05 kernels' (form 9) word for word -- fp32 output with bias / ReLU / residual, and
+    split-f16 output (plain and paired stores) with GELU."""
+    g = torch.Generator().manual_seed(M + N + K + form)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = ops.device
+    asp, wsp = ops.split_f16(a.to(d)), ops.split_f16(w.to(d))
+    Ns = N // 64 * 64                                          # paired stores: a multiple of 64 columns
+    Kp_out = (Ns + 127) // 128 * 128
+    par = split_bound_par(w[:Ns], bias[:Ns]).to(d)
+    perm = H.Ops.so_pair_perm(Ns)
+    wq = ops.split_f16(w[:Ns][perm].to(d))
+    outs = {}
+    try:
+        for f in (9, form):
+            ops.gemm_tile_policy(4400 + f)
+            c = ops.gemm_x3(asp, wsp, bias.to(d), res.to(d), H.ACT_RELU | H.ACT_POST_RESIDUAL).cpu()
+            k0 = ops.gemm_last_kernel()
+            so = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
+            inv = torch.zeros(M, device=d)
+            ops.gemm_x3_split(asp, ops.split_f16(w[:Ns].to(d)), bias[:Ns].to(d), H.ACT_GELU, so, inv, par, split_col_off=0, split_col_start=0, act_col_start=0)
+            k1 = ops.gemm_last_kernel()
+            so2 = torch.zeros(M, 2 * Kp_out, dtype=torch.float16, device=d)
+            inv2 = torch.zeros(M, device=d)
+            ops.gemm_x3_split(asp, wq, bias[:Ns][perm].to(d), H.ACT_GELU, so2, inv2, par, split_col_off=0, split_col_start=0, act_col_start=0, paired=True)
+            k2 = ops.gemm_last_kernel()
+            outs[f] = (c, so.cpu(), inv.cpu(), so2.cpu(), inv2.cpu(), (k0, k1, k2))
+    finally:
+        ops.gemm_tile_policy(4400)
+    assert all(MID_KERNELS[form] in k for k in outs[form][5]), outs[form][5]
+    assert not any(", 5, 2" in k or ", 6, 2" in k or ", 7, 2" in k or "256, 128, 4, 2" in k or "128, 256, 2, 4" in k for k in outs[9][5]), outs[9][5]
+    assert torch.equal(outs[9][0].view(torch.int32), outs[form][0].view(torch.int32))
+    for i in (1, 3):
+        assert torch.equal(outs[9][i].view(torch.int16), outs[form][i].view(torch.int16))
+    for i in (2, 4):
+        assert torch.equal(outs[9][i], outs[form][i])
+    assert torch.equal(outs[form][1].view(torch.int16), outs[form][3].view(torch.int16))      # paired stores == LDS-transposed stores
+    want = torch.relu(a.double() @ w.double().T + bias.double() + res.double())
+    assert (outs[form][0].double() - want).abs().max() <= 3e-5 * want.abs().max()

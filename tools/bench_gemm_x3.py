@@ -23,6 +23,13 @@ RING_SHAPES = [(4096, 512, 2048), (4096, 2048, 512), (5184, 1536, 512), (5184, 5
                (65536, 256, 256), (69696, 128, 128), (17424, 256, 256), (4096, 512, 1024), (4096, 768, 256), (16384, 256, 512), (16384, 256, 256)]
 
 
+# r06 (--mid): the mid-size forms of the slice GEMM (psalm_gemm_set_tile_policy 4400 + form) against the r05 kernels (4409), fp32 output and -- on
+# the shapes the image runs with it -- paired split-f16 output behind GELU
+MID = [("r05", [4409]), ("ilv", [4401]), ("256x128_ilv", [4402]), ("256x128", [4404]), ("128x256", [4405]), ("256x128_lw2", [4406]), ("128x256_lw2", [4407]),
+       ("256x128_lw4", [4408]), ("128x128_lw2", [4410]), ("64x128_lw2", [4411])]
+MID_SO = {(4096, 2048, 512), (21504, 1024, 256), (65536, 512, 128), (16384, 1024, 256), (1024, 4096, 1024)}
+
+
 def main():
     ops = get_ops()
     if "--lib" in sys.argv:                                     # A/B against a side library (tools/experiments/_build/...)
@@ -34,27 +41,48 @@ def main():
     ring = "--ring" in sys.argv
     if ring:
         sys.argv.remove("--ring")
+    mid = "--mid" in sys.argv
+    if mid:
+        sys.argv.remove("--mid")
     global POLICIES
     if ring:
         POLICIES = RING
-    for M, N, K in (RING_SHAPES if ring else SHAPES):
+    if mid:
+        POLICIES = MID
+    shapes = RING_SHAPES if (ring or mid) else SHAPES
+    if mid:
+        shapes = [(M, N, K, so) for (M, N, K) in shapes if M > 192 for so in ((False, True) if (M, N, K) in MID_SO else (False,))]
+    else:
+        shapes = [(M, N, K, False) for (M, N, K) in shapes]
+    for M, N, K, so_out in shapes:
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda")
         asp, wsp = ops.split_f16(a), ops.split_f16(w)
         c = torch.empty(M, N, device="cuda")
+        if so_out:
+            bias = torch.randn(N, device="cuda")
+            so = torch.zeros(M, 2 * N, dtype=torch.float16, device="cuda")
+            so_inv = torch.empty(M, device="cuda")
+            bnd = torch.tensor([2.0 ** 14 * float(w.abs().sum(1).max()), float(bias.abs().max()), 0.0, 0.0], device="cuda")
+
+            def launch():
+                ops.gemm_x3_split(asp, wsp, bias, 2, so, so_inv, bnd, split_col_off=0, split_col_start=0, act_col_start=0, paired=True)
+        else:
+            def launch():
+                ops.gemm_x3(asp, wsp, out=c)
         row = {}
         for name, pol in POLICIES:
             for p in pol:
                 ops.gemm_tile_policy(p)
             try:
                 for _ in range(3):
-                    ops.gemm_x3(asp, wsp, out=c)
+                    launch()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 reps = 30
                 e0.record()
                 for _ in range(reps):
-                    ops.gemm_x3(asp, wsp, out=c)
+                    launch()
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / reps * 1e3
@@ -65,10 +93,11 @@ def main():
                 ops.gemm_tile_policy(1282)
                 ops.gemm_tile_policy(640)
                 ops.gemm_tile_policy(3300)
-                ops.gemm_tile_policy(2580)
+                ops.gemm_tile_policy(2582 if mid else 2580)
+                ops.gemm_tile_policy(4400)
                 ops.gemm_tile_policy(0)
-        out[f"M{M} N{N} K{K}"] = row
-        print(M, N, K, {k: v.get("us") for k, v in row.items()}, flush=True)
+        out[f"M{M} N{N} K{K}" + (" so" if so_out else "")] = row
+        print(M, N, K, "so" if so_out else "", {k: v.get("us") for k, v in row.items()}, flush=True)
         del a, w, asp, wsp, c
     if len(sys.argv) > 1:
         json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -127,6 +127,52 @@ def main():
         json.dump(out, open(sys.argv[1], "w"), indent=1)
 
 
+def ablate_mid():
+    """r06: the same switches in the GENERIC slice loop (64 x 128 / 128 x 128 tiles of r05, 256 x 128 of r06) on the mid-size shapes of the image:
+    which resource a K step of these launches waits for.  One JSON line per (shape, form, mask)."""
+    import ctypes
+    import torch
+    from psalm_amd import hip_ops as H
+    ops = H.Ops(LIB)
+    nslot = 1 << 16
+    tl = torch.zeros(nslot * 8, dtype=torch.int64, device="cuda")
+    assert ops._cdll_raw.psalm_gemm_timeline_buffer(ctypes.c_void_p(tl.data_ptr())) == 0
+    for (M, N, K) in ((4096, 2048, 512), (4096, 512, 2048), (5184, 512, 512), (21504, 256, 1024), (21504, 256, 256), (65536, 256, 256)):
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * 0.05
+        asp, wsp = ops.split_f16(a), ops.split_f16(w)
+        c = torch.empty(M, N, device="cuda")
+        for form in (4409, 4404):
+            ops.gemm_tile_policy(form)
+            try:
+                for mask in (0, 1, 2, 4, 8, 3, 5, 6, 7, 9, 15):
+                    assert ops._cdll_raw.psalm_gemm_ablate(mask) == 0
+                    for _ in range(3):
+                        ops.gemm_x3(asp, wsp, out=c)
+                    tl.zero_()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.gemm_x3(asp, wsp, out=c)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t = tl.view(nslot, 8).cpu()
+                    t = t[t[:, 0] > 0][:, :6].double()
+                    us = (t - t[:, 0].min()) / 100.0
+                    ph = us[:, 1:] - us[:, :-1]
+                    row = {"shape": [M, N, K], "form": form, "kernel": ops.gemm_last_kernel(), "ablate": mask, "blocks": int(t.shape[0]),
+                           "off": [n for b, n in ((1, "copies"), (2, "frag_reads"), (4, "mfma"), (8, "barriers")) if mask & b],
+                           "event_us": round(e0.elapsed_time(e1) * 1e3, 1), "k_loop_p50_us": round(float(ph[:, 2].quantile(.5)), 2),
+                           "k_loop_p90_us": round(float(ph[:, 2].quantile(.9)), 2), "setup_p50": round(float(ph[:, 0].quantile(.5)), 2),
+                           "first_tile_p50": round(float(ph[:, 1].quantile(.5)), 2), "epilogue_p50": round(float((ph[:, 3] + ph[:, 4]).quantile(.5)), 2),
+                           "span_us": round(float(us[:, 5].max()), 2)}
+                    print(json.dumps(row), flush=True)
+            finally:
+                ops._cdll_raw.psalm_gemm_ablate(0)
+                ops.gemm_tile_policy(4400)
+        del a, w, asp, wsp, c
+
+
 def ablate():
     """K-loop time of the slice-form phased kernel (policy 2581) with parts of the loop switched off (psalm_gemm_ablate, experiment build):
     1 copies, 2 fragment reads, 4 matrix instructions, 8 phase barriers.  One JSON line per (shape, mask)."""
@@ -179,6 +225,8 @@ def ablate():
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    elif "--ablate-mid" in sys.argv:
+        ablate_mid()
     elif "--ablate" in sys.argv:
         ablate()
     else:
