@@ -383,26 +383,24 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_le() {      // s_wai
 // 12..48 K steps) ran their K loops at L2 latency with X3 = 1 (r02k: 100-200 TFLOP/s algorithmic on the 128^2 / 64x128 tiles).
 // SO = true (X3 == 1 only): the epilogue can emit split-f16 output (GemmFastArgs::so; psalm_gemm_x3_split).  A separate instantiation so that
 // the plain kernels' epilogue -- at the register limit on the 256 x 256 tile -- is untouched.
-// PH8_ = 5 (r06; generic K loop, slice form): the copies of the NEXT stage are not issued as one burst behind the barrier but one by one between
-// the groups of three matrix instructions of this stage ("ILV").  A global_load_lds costs its wave ~60 - 180 clocks of issue (MI355X_MICROARCH
-// section "constants"); the burst of 6 - 12 of them at the top of a K step was dead time of the wave's matrix pipe -- r04a time line: K steps of
-// ~2100 clocks for 768 clocks of matrix instructions on the one-block-per-CU launches.
 // PH8_ = 6 / 7 (r06, "LW"): the block carries 2 / 4 LOADER wavefronts besides its WM x WN matrix wavefronts.  The loaders issue every
 // global -> LDS copy of the K loop (three stages, running one slice ahead of the slice being multiplied) and nothing else; the matrix waves issue
 // no vector-memory instruction inside the loop.  Why (profiles/r06c_mid_ablation.jsonl, the generic loop with parts switched off): on the
 // mid-size GEMMs the copies alone take as long as the matrix instructions alone, and the two ADD UP -- a wave that issues a global_load_lds
 // stalls in issue until the CU's one address path has taken it (~34 clocks per 1 KiB piece per CU whoever issues), every wave of the block
 // reaches its copies at the same point behind the barrier, and nothing feeds the matrix pipes meanwhile.  Interleaving the copies with the
-// matrix instructions of the same wave (PH8_ = 5) does not help: the wave still stalls per copy.  Giving the copies to waves that have
-// nothing else to do lets the matrix waves run through: a K step costs max(copies, products) instead of their sum.
+// matrix instructions of the same wave (r06b, tools/experiments/r06_ilv_copy_issue.patch) made every shape 5 - 10 % SLOWER, and eight-wave
+// 256 x 128 blocks whose waves all copy gained 0 - 9 %.  With loaders the matrix waves' loop holds no vector-memory instruction (the compiler
+// then pipelines the fragment reads with counted lgkmcnt waits by itself) and the copies of slice t + 2 run beside the products of slice t.
+// Measured (profiles/r06d_gemm_mid_sweep_loader_waves.json): 5 - 23 % on the long-K shapes whose tile count fits one round of blocks; nothing
+// on short K (Kp <= 256: prologue and epilogue outweigh the loop) -- the copy path of a CU (~30 B / clock from L2 into LDS) stays the bound.
 template <typename TC, int BM, int BN, int WM, int WN, int NS, bool CONV = false, int BK = 64, int PH8_ = 0, int X3 = 0,
           bool SO = false, bool PAIR = false>
 __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 4 : 0)))) gemm_bf16_glds_kernel(GemmFastArgs fa) {
     constexpr int PH8 = (PH8_ >= 1 && PH8_ <= 4) ? PH8_ : 0;     // phased 256 x 256 schedules
-    constexpr bool ILV = PH8_ == 5;
     constexpr int NLW = PH8_ == 6 ? 2 : (PH8_ == 7 ? 4 : 0);     // loader wavefronts
     constexpr bool LW = NLW > 0;
-    static_assert(PH8_ >= 0 && PH8_ <= 7 && (!ILV || (X3 == 2 && NS == 2 && !CONV)), "ILV: slice form, two stages");
+    static_assert(PH8_ >= 0 && PH8_ <= 7 && PH8_ != 5, "PH8_: 0 generic loop, 1 - 4 phased 256 x 256 loops, 6 / 7 loader waves");
     static_assert(!LW || (X3 == 2 && NS == 3 && BK == 32 && !CONV), "LW: slice form on 32-deep slices, three stages");
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || (X3 == 2 && BK == 32 && (NS == 2 || LW)), "split-f16 output: K-panel form, or 32-deep slices in two stages (three with loader waves)");
@@ -534,16 +532,6 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
         }
     };
 
-    // copy p of the stage's (A_CH + B_CH) * 2 copies of this wave, in issue()'s order: A hi, W hi, A lo, W lo  (slice form)
-    auto issue_piece = [&](int buf, int koff, int p) __attribute__((always_inline)) {
-        if constexpr (X3 == 2 && !CONV) {
-            const int half = p / (A_CH + B_CH), q = p % (A_CH + B_CH);    // half: 0 hi images, 1 lo images
-            bf16_t* base = smem[buf] + half * (BM + BN) * BK;
-            const int kcol = koff + half * fa.x3_kp;
-            if (q < A_CH) psalm_glds16(asrc[q] + kcol, base + a_chunk(q) * RPC * BK);
-            else psalm_glds16(bsrc[q - A_CH] + kcol, base + BM * BK + b_chunk(q - A_CH) * RPC * BK);
-        }
-    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -898,8 +886,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
         }
         if (!(PSALM_ABL() & 8)) PSALM_RAW_BARRIER();
         if (kt == 0) PSALM_TL(2);
-        const bool more = kt + NS - 1 < nk;                      // (block-uniform) a tile is left to prefetch
-        if (!ILV && more && !(PSALM_ABL() & 1)) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        if (kt + NS - 1 < nk && !(PSALM_ABL() & 1)) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
         const bf16_t* As = smem[buf];
         const bf16_t* Bs = smem[buf] + BM * BK;
         // register double-buffered fragments: the ds_read_b128s of k-step kk+1 are issued BEFORE the MFMAs of k-step kk, so
@@ -920,14 +907,11 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
         if constexpr (X3 == 2) {                                 // slice form: three products from the four images of this K slice
             const bf16_t* Al = As + (BM + BN) * BK;
             const bf16_t* Bl = Al + BM * BK;
-            // (PF: this step prefetches -- ILV only; a compile-time flag, so that the steady-state copy of the body holds its copies without a
-            //  branch around each and the last step's copy holds none)
-            auto slice_body = [&](auto PF) __attribute__((always_inline)) {
 #pragma unroll
-                for (int kk = 0; kk < BK / 16; ++kk) {
-                    const int co = ((2 * kk + hi) ^ fsw) * 8;
-                    bf16x8 ah[TM] = {}, al[TM] = {}, bh[TN] = {}, bl[TN] = {};
-                    if (!(PSALM_ABL() & 2)) {                    // (experiment build: fragment reads off)
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int co = ((2 * kk + hi) ^ fsw) * 8;
+                bf16x8 ah[TM] = {}, al[TM] = {}, bh[TN] = {}, bl[TN] = {};
+                if (!(PSALM_ABL() & 2)) {                        // (experiment build: fragment reads off)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
@@ -938,28 +922,17 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
                         bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
                         bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bl[(b_row0 + 32 * j) * BK + co]));
                     }
-                    }
-                    if (PSALM_ABL() & 4) continue;               // (experiment build: matrix instructions off)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
-                            if constexpr (ILV && decltype(PF)::value) {   // this group's share of the next stage's copies, behind its first product
-                                constexpr int G = (BK / 16) * TM * TN, PPG = (LPT + G - 1) / G;
-                                const int gidx = (kk * TM + i) * TN + j;
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int p = gidx * PPG; p < (gidx + 1) * PPG && p < LPT; ++p) issue_piece((kt + 1) & 1, (kt + 1) * BK, p);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
-                            acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
-                        }
                 }
-            };
-            if (ILV && more) slice_body(std::true_type{});
-            else slice_body(std::false_type{});
+                if (PSALM_ABL() & 4) continue;                   // (experiment build: matrix instructions off)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
+                        acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
+                    }
+            }
             continue;
         }
         constexpr bool PIN = (TM * TN <= 4);
@@ -1850,10 +1823,12 @@ extern "C" int psalm_gemm_x3_set_products(int n) {
     g_x3_products = n;
     return 0;
 }
-// r06 "mid" forms of the split-f16 slice GEMM (policy codes 4400 + v; 0 = automatic selection, see select_mid_form):
-//   1  the r05 tile, copies interleaved with the matrix instructions (ILV)        2 / 3  256 x 128 / 128 x 256 blocks of eight 64 x 64 wave tiles, ILV
-//   4 / 5  256 x 128 / 128 x 256, copies as one burst                             9  the r05 kernels whatever the automatic selection says
-//   6 / 7  256 x 128 / 128 x 256 with two loader wavefronts (LW)      8  256 x 128 with four      10 / 11  128 x 128 / 64 x 128 with two
+// r06 "mid" forms of the split-f16 slice GEMM -- blocks with loader wavefronts (LW, see the kernel comment) -- policy codes 4400 + v:
+//   0  automatic (select_mid_form)      9  the r05 kernels whatever the selection says
+//   6 / 7  256 x 128 / 128 x 256 blocks (eight 64 x 64 wave tiles) + two loaders      8  256 x 128 + four loaders
+//   10 / 11  128 x 128 / 64 x 128 blocks (four waves) + two loaders
+// (the forms 1 - 5 of the round's first sweep -- interleaved copy issue, eight-wave blocks whose waves all copy -- are gone from the product:
+//  profiles/r06b_gemm_mid_sweep_ilv_and_8wave_tiles.json, tools/experiments/r06_ilv_copy_issue.patch)
 static std::atomic<int> g_mid_form{0};
 static thread_local bool g_x3_auto_slice = false;    // set by select_fast_config (per host thread: read back by the same thread's launch): this problem takes the slice form on 64 x 128 tiles
 extern "C" int psalm_gemm_set_tile_policy(int bm) {
@@ -1917,6 +1892,23 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
     }
 }
 
+// Automatic choice among the r06 mid forms (g_mid_form) for an un-split slice-form problem: 9 = keep the r05 kernel.  Rule read off the sweep
+// profiles/r06d_gemm_mid_sweep_loader_waves.json (33 problem / output-form pairs x 10 forms, back to back on one MI355X): the loader-wave blocks
+// win where the K loop is long enough to matter (Kp >= 512: 16 slices) AND their grid is ONE round of blocks that fills most of the chip -- they
+// hold one block per CU (two for the 64 x 128 form), so 264 tiles cost two rounds (M1296 N3072 K1024 on 128 x 128: 37 -> 50 us) and 128 tiles
+// leave half the chip idle.  Largest tile first (fewest L2 -> LDS bytes per product): 256 x 128 with four loaders, 128 x 128 and 64 x 128 with two.
+// In the sweep the rule takes: M5184 N1536 K512 33.5 -> 31.5 us, M4096 N2048 K512 34.3 -> 31.9, M21504 N256 K1024 53.1 -> 43.2, M16384 N256 K1024
+// 39.9 -> 33.6, M5184 N512 K512 17.8 -> 16.9, M1296 N1024 K1024 23.5 -> 18.0, M4096 N512 K1024 24.6 -> 19.5, M1024 N4096 K1024 (split-f16 output)
+// 40.8 -> 38.3; every Kp <= 256 problem keeps its r05 kernel (LW: -3 % ... +25 % there).
+static int select_mid_form(int M, int N, int Kp) {
+    if (Kp < 512) return 9;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 128), t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 128);
+    if (t256 >= 160 && t256 <= 256) return 8;
+    if (t128 >= 160 && t128 <= 256) return 10;
+    if (t64 >= 160 && t64 <= 512) return 11;
+    return 9;
+}
+
 // Which kernel psalm_gemm launches for a problem: out[0] = path (0 register-staged, 1 direct-to-LDS, 2 skinny), out[1] = BM,
 // out[2] = BN, out[3] = split-K slices.  (bench.py uses it to attribute measured launch times to kernel instantiations.)
 extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype, long workspace_bytes, int* out4) {
@@ -1938,6 +1930,15 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
             const int kps = cdiv(cdiv(kp, 64), splits) * 64;
             splits = cdiv(kp, kps);
         }
+        // r06 mid forms (launch_fast): the default 32-deep slice form of the 64 / 128-row tiles, un-split (fp32 output: never the 64-deep auto slice form)
+        if (BM != 256 && g_x3_products == 3 && splits == 1 && !g_tile_policy && M > 192 && (g_x3_slice == 0 || g_x3_slice == 3) && !(g_x3_auto_slice && BM == 64)) {
+            int mid = g_mid_form.load();
+            if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, kp) : 9;
+            if (mid == 6 || mid == 8) { BM = 256; BN = 128; }
+            else if (mid == 7) { BM = 128; BN = 256; }
+            else if (mid == 10) { BM = 128; BN = 128; }
+            else if (mid == 11) { BM = 64; BN = 128; }
+        }
         out4[0] = 1; out4[1] = BM; out4[2] = BN; out4[3] = splits;
     } else if (a_dtype == PSALM_BF16 && w_dtype == PSALM_BF16 && K % 64 == 0 && M <= 128 && N <= g_skinny_nmax && !g_tile_policy) {
         out4[0] = 2; out4[1] = 32; out4[2] = 32; out4[3] = 1;                     // skinny kernel
@@ -1950,12 +1951,6 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
         out4[0] = 0; out4[1] = small ? 64 : 128; out4[2] = 128; out4[3] = 1;
     }
     return 0;
-}
-
-// Automatic choice among the r06 mid forms (g_mid_form) for an un-split slice-form problem whose r05 tile height is BM: 9 = keep the r05 kernel.
-static int select_mid_form(int M, int N, int Kp, int BM, bool so) {
-    (void)M; (void)N; (void)Kp; (void)BM; (void)so;
-    return 9;
 }
 
 // Launch of the direct-to-LDS kernel (plain GEMM or implicit-GEMM convolution) + split-K reduce.
@@ -1995,13 +1990,13 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     int mid = 0;
     if (x3 && slice == 3 && splits == 1 && !g_tile_policy && M > 192) {
         mid = g_mid_form.load();
-        if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, fa.x3_kp, BM, fa.so != nullptr) : 9;
-        if (fa.so && fa.so_paired && fa.so_col_start % 256 != 0 && (mid == 3 || mid == 5 || mid == 7)) mid = 9;      // (paired stores: no tile straddles so_col_start)
-        if (mid == 2 || mid == 4 || mid == 6 || mid == 8) { BM = 256; BN = 128; }
-        else if (mid == 3 || mid == 5 || mid == 7) { BM = 128; BN = 256; }
+        if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, fa.x3_kp) : 9;
+        if (fa.so && fa.so_paired && fa.so_col_start % 256 != 0 && mid == 7) mid = 9;      // (paired stores: no tile straddles so_col_start)
+        if (mid == 6 || mid == 8) { BM = 256; BN = 128; }
+        else if (mid == 7) { BM = 128; BN = 256; }
         else if (mid == 10) { BM = 128; BN = 128; }
         else if (mid == 11) { BM = 64; BN = 128; }
-        if (mid == 9) mid = 0;
+        else mid = 0;
     }
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;
@@ -2054,24 +2049,18 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else if (slice == 6 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true, true);
         else if (slice == 6 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, true);
         else if (slice == 6) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 3, 2, false);
-        // r06 mid forms: ILV (PH8_ = 5) on the r05 tiles, and the eight-wave 256 x 128 / 128 x 256 blocks
+        // r06 mid forms: blocks with loader wavefronts (three stages of 32-deep slices)
 #define GO_MID(NT_, ...)                                                                                                                       \
         do {                                                                                                                                   \
             if (fa.so && fa.so_paired) GO(NT_, "float", float, __VA_ARGS__, 2, true, true);                                                    \
             else if (fa.so) GO(NT_, "float", float, __VA_ARGS__, 2, true);                                                                     \
             else GO(NT_, "float", float, __VA_ARGS__, 2, false);                                                                               \
         } while (0)
-        else if (mid == 2) GO_MID(512, 256, 128, 4, 2, 2, false, 32, 5);
-        else if (mid == 3) GO_MID(512, 128, 256, 2, 4, 2, false, 32, 5);
-        else if (mid == 4) GO_MID(512, 256, 128, 4, 2, 2, false, 32, 0);
-        else if (mid == 5) GO_MID(512, 128, 256, 2, 4, 2, false, 32, 0);
         else if (mid == 6) GO_MID(640, 256, 128, 4, 2, 3, false, 32, 6);
         else if (mid == 7) GO_MID(640, 128, 256, 2, 4, 3, false, 32, 6);
         else if (mid == 8) GO_MID(768, 256, 128, 4, 2, 3, false, 32, 7);
         else if (mid == 10) GO_MID(384, 128, 128, 2, 2, 3, false, 32, 6);
         else if (mid == 11) GO_MID(384, 64, 128, 2, 2, 3, false, 32, 6);
-        else if (mid == 1 && BM == 128) GO_MID(256, 128, 128, 2, 2, 2, false, 32, 5);
-        else if (mid == 1) GO_MID(256, 64, 128, 2, 2, 2, false, 32, 5);
 #undef GO_MID
         else if (BM == 128 && slice >= 3 && fa.so && fa.so_paired) GO(256, "float", float, 128, 128, 2, 2, 2, false, 32, 0, 2, true, true);
         else if (slice == 3 && fa.so && fa.so_paired) GO(256, "float", float, 64, 128, 2, 2, 2, false, 32, 0, 2, true, true);
