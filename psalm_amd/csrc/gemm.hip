@@ -1826,7 +1826,7 @@ extern "C" int psalm_gemm_x3_set_products(int n) {
 // r06 "mid" forms of the split-f16 slice GEMM -- blocks with loader wavefronts (LW, see the kernel comment) -- policy codes 4400 + v:
 //   0  automatic (select_mid_form)      9  the r05 kernels whatever the selection says
 //   6 / 7  256 x 128 / 128 x 256 blocks (eight 64 x 64 wave tiles) + two loaders      8  256 x 128 + four loaders
-//   10 / 11  128 x 128 / 64 x 128 blocks (four waves) + two loaders
+//   10 / 11  128 x 128 / 64 x 128 blocks (four waves) + two loaders      12 / 13  (experiment) forms 8 / 10 with the K range split to fill the chip
 // (the forms 1 - 5 of the round's first sweep -- interleaved copy issue, eight-wave blocks whose waves all copy -- are gone from the product:
 //  profiles/r06b_gemm_mid_sweep_ilv_and_8wave_tiles.json, tools/experiments/r06_ilv_copy_issue.patch)
 static std::atomic<int> g_mid_form{0};
@@ -1900,7 +1900,15 @@ static void select_fast_config(int M, int N, int K, bool have_ws, long workspace
 // In the sweep the rule takes: M5184 N1536 K512 33.5 -> 31.5 us, M4096 N2048 K512 34.3 -> 31.9, M21504 N256 K1024 53.1 -> 43.2, M16384 N256 K1024
 // 39.9 -> 33.6, M5184 N512 K512 17.8 -> 16.9, M1296 N1024 K1024 23.5 -> 18.0, M4096 N512 K1024 24.6 -> 19.5, M1024 N4096 K1024 (split-f16 output)
 // 40.8 -> 38.3; every Kp <= 256 problem keeps its r05 kernel (LW: -3 % ... +25 % there).
-static int select_mid_form(int M, int N, int Kp) {
+// K slices for a loader-wave grid of `tiles` blocks: the largest of 8 / 4 / 2 that keeps the launch within one round of 256 blocks and leaves every
+// slice >= 8 slices of 32 (powers of two: the slice then decides the XCD, GemmFastArgs::xcd_ksplit)
+static int mid_split_count(long tiles, int Kp) {
+    int s = 1;
+    while (s < 8 && tiles * (s * 2) <= 256 && Kp / (s * 2) >= 256) s *= 2;
+    return s;
+}
+static int select_mid_form(int M, int N, int Kp, int* msplit = nullptr) {
+    if (msplit) *msplit = 1;
     if (Kp < 512) return 9;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 128), t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 128);
     if (t256 >= 160 && t256 <= 256) return 8;
@@ -1986,17 +1994,29 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         splits = cdiv(g.K, kps);
     }
     if (fa.so && slice != 3 && slice != 6) slice = 0;             // split-f16 output: K-panel form, form 3 or form 6
-    // r06 mid forms: only on the default slice form of the 64 / 128-row tiles (32-deep slices, two stages), never with split-K
+    // r06 mid forms: on the slice forms of the 64 / 128-row tiles (32-deep slices in two stages; the 64-deep "auto slice" form of the long-K,
+    // few-tile problems), un-split by select_fast_config.  A form may bring its own split-K (fp32 output only): few large tiles x K slices.
     int mid = 0;
-    if (x3 && slice == 3 && splits == 1 && !g_tile_policy && M > 192) {
+    if (x3 && (slice == 3 || slice == 1) && splits == 1 && !g_tile_policy && M > 192) {
+        int msplit = 1;
         mid = g_mid_form.load();
-        if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, fa.x3_kp) : 9;
+        if (mid == 0) mid = psalm_get_tuning(PSALM_TUNE_GEMM_MID) ? select_mid_form(M, N, fa.x3_kp, &msplit) : 9;
+        if (mid == 12 || mid == 13) {                            // experiment forms: 256 x 128 (four loaders) / 128 x 128 (two) with the K range split to fill the chip
+            const long t = mid == 12 ? (long)cdiv(M, 256) * cdiv(N, 128) : (long)cdiv(M, 128) * cdiv(N, 128);
+            msplit = mid_split_count(t, fa.x3_kp);
+            mid = mid == 12 ? 8 : 10;
+        }
         if (fa.so && fa.so_paired && fa.so_col_start % 256 != 0 && mid == 7) mid = 9;      // (paired stores: no tile straddles so_col_start)
+        if (slice == 1 && !(msplit > 1 && workspace && !fa.so)) mid = 9;                   // the 64-deep form is only left for a split-K loader form
         if (mid == 6 || mid == 8) { BM = 256; BN = 128; }
         else if (mid == 7) { BM = 128; BN = 256; }
         else if (mid == 10) { BM = 128; BN = 128; }
         else if (mid == 11) { BM = 64; BN = 128; }
         else mid = 0;
+        if (mid) {
+            slice = 3;
+            if (msplit > 1 && workspace && !fa.so && (long)msplit * M * N * 4 <= workspace_bytes) splits = msplit;
+        }
     }
     if (slice) {                                                  // slice form: the kernel's K loop runs over the true (padded) K = Kp
         g.K = fa.x3_kp;

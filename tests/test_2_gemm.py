@@ -911,3 +911,24 @@ def test_gemm_x3_mid_automatic_selection_is_bitwise_the_r05_kernel_on_gpu(M, N, 
         ops.gemm_tile_policy(4400)
     assert ", 3, false, 32, 6, 2" in ks[1] or ", 3, false, 32, 7, 2" in ks[1], ks
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+
+
+@pytest.mark.parametrize("form,M,N,K", [(12, 300, 260, 1024), (13, 300, 260, 1024), (12, 515, 130, 512)])
+def test_gemm_x3_mid_forms_with_split_k(ops, form, M, N, K):
+    """Loader-wave blocks with the K range split over the grid (fp32 slabs + reduce: bias / activation / residual in the reduce pass): the accuracy
+    contract of every split-f16 GEMM form, and the launch really is the split one."""
+    g = torch.Generator().manual_seed(M + N + K + form)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) * 0.2
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = ops.device
+    try:
+        ops.gemm_tile_policy(4400 + form)
+        got = ops.gemm_x3(a.to(d), w.to(d), bias.to(d), res.to(d), H.ACT_RELU | H.ACT_POST_RESIDUAL).cpu().double()
+        k = ops.gemm_last_kernel()
+    finally:
+        ops.gemm_tile_policy(4400)
+    assert "splitk_reduce_kernel" in k and ("32, 7, 2" in k or "32, 6, 2" in k), k
+    want = torch.relu(a.double() @ w.double().T + bias.double() + res.double())
+    mag = a.abs().double() @ w.abs().double().T
+    assert ((got - want).abs() <= 6 * 2.0 ** -22 * mag + 4e-7 * want.abs() + 1e-6).all()

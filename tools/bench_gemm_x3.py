@@ -27,6 +27,10 @@ RING_SHAPES = [(4096, 512, 2048), (4096, 2048, 512), (5184, 1536, 512), (5184, 5
 # the shapes the image runs with it -- paired split-f16 output behind GELU
 MID = [("r05", [4409]), ("ilv", [4401]), ("256x128_ilv", [4402]), ("256x128", [4404]), ("128x256", [4405]), ("256x128_lw2", [4406]), ("128x256_lw2", [4407]),
        ("256x128_lw4", [4408]), ("128x128_lw2", [4410]), ("64x128_lw2", [4411])]
+# r06 (--midsplit): loader-wave blocks + split-K (forms 12 / 13) on the long-K problems whose large tiles alone cannot fill the chip
+MIDSPLIT = [("r05", [4409]), ("auto", [4400]), ("256x128_lw4_split", [4412]), ("128x128_lw2_split", [4413])]
+MIDSPLIT_SHAPES = [(4096, 512, 2048), (4096, 512, 1024), (1296, 1024, 1024), (1024, 4096, 1024), (1296, 3072, 1024), (5184, 512, 512), (1024, 1024, 4096),
+                   (1024, 1024, 2048), (256, 2048, 2048), (256, 2048, 1024), (1024, 256, 1024), (16384, 256, 1024), (4096, 256, 512)]
 MID_SO = {(4096, 2048, 512), (21504, 1024, 256), (65536, 512, 128), (16384, 1024, 256), (1024, 4096, 1024)}
 
 
@@ -44,12 +48,17 @@ def main():
     mid = "--mid" in sys.argv
     if mid:
         sys.argv.remove("--mid")
+    midsplit = "--midsplit" in sys.argv
+    if midsplit:
+        sys.argv.remove("--midsplit")
     global POLICIES
     if ring:
         POLICIES = RING
     if mid:
         POLICIES = MID
-    shapes = RING_SHAPES if (ring or mid) else SHAPES
+    if midsplit:
+        POLICIES = MIDSPLIT
+    shapes = MIDSPLIT_SHAPES if midsplit else (RING_SHAPES if (ring or mid) else SHAPES)
     if mid:
         shapes = [(M, N, K, so) for (M, N, K) in shapes if M > 192 for so in ((False, True) if (M, N, K) in MID_SO else (False,))]
     else:
@@ -93,7 +102,7 @@ def main():
                 ops.gemm_tile_policy(1282)
                 ops.gemm_tile_policy(640)
                 ops.gemm_tile_policy(3300)
-                ops.gemm_tile_policy(2582 if mid else 2580)
+                ops.gemm_tile_policy(2582 if (mid or midsplit) else 2580)
                 ops.gemm_tile_policy(4400)
                 ops.gemm_tile_policy(0)
         out[f"M{M} N{N} K{K}" + (" so" if so_out else "")] = row
