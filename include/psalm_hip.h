@@ -29,7 +29,7 @@ const char* psalm_last_error(void);
  * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
  * 6: psalm_gemm_x3_set_products, psalm_fuse_masks, the stage-level psalm_phi_forward (r05); psalm_causal_attention_f32_workspace grew by one
  *    byte per 32-key tile.
- * 7: psalm_set_tuning / psalm_get_tuning (r06). */
+ * 7: psalm_set_tuning / psalm_get_tuning, psalm_layernorm_chain, psalm_gemm_f32_pair (r06). */
 #define PSALM_ABI_VERSION 7
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -41,10 +41,13 @@ const char* psalm_backend(void); /* "hip-gfx950" */
  *   PSALM_TUNE_ATTN_XCD_HEADS   1 (default): psalm_causal_attention_f32* places all query-tile blocks of a head on one XCD (4 heads' K / V per L2);
  *                               0: the r02-r05 placement (a head's blocks spread over all eight)
  *   PSALM_TUNE_GEMM_MID         1 (default): mid-size split-f16 GEMMs take the 64 x 64 wave-tile kernel where the selection prefers it; 0: r05 kernels
- *   PSALM_TUNE_RESERVED3..7     unused */
+ *   PSALM_TUNE_DECODER_FUSE     1 (default): psalm_predictor_forward issues the query rows' LayerNorm chains / paired projections as single launches
+ *                               (psalm_layernorm_chain, psalm_gemm_f32_pair); 0: the r05 launch sequence
+ *   4..7                        unused */
 #define PSALM_TUNE_GEMM_XCD_KSPLIT 0
 #define PSALM_TUNE_ATTN_XCD_HEADS 1
 #define PSALM_TUNE_GEMM_MID 2
+#define PSALM_TUNE_DECODER_FUSE 3
 #define PSALM_TUNE_COUNT 8
 int psalm_set_tuning(int key, int value);
 int psalm_get_tuning(int key);
@@ -256,6 +259,16 @@ int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, 
 int psalm_layernorm3(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2, const float* add,
                      long add_rows, void* y3_bf16, long ldy3, const float* gamma, const float* beta, int rows, int C, float eps,
                      void* stream);
+/* LayerNorm chain of the mask decoder's query rows, fp32 (mask2former_transformer_decoder.py:72-74 / :170-172 post-norms, :35-37 `output + query_pos`,
+ * :750 decoder_norm of forward_prediction_heads):  y1 = LN(x; g1, b1);  y2 = y1 + add[row % add_rows] (y2 may be NULL);  y3 = LN(y1; g2, b2) (y3 may be
+ * NULL).  The same words as psalm_layernorm3 + psalm_add_bcast + psalm_layernorm3.  C % 8 == 0, C <= 2048, 16-byte aligned rows. */
+int psalm_layernorm_chain(const float* x, long ldx, float* y1, long ldy1, const float* g1, const float* b1, const float* add, long add_rows,
+                          float* y2, long ldy2, const float* g2, const float* b2, float* y3, long ldy3, int rows, int C, float eps, void* stream);
+/* Two exact-fp32 skinny GEMMs C_i = act_i(A_i . W_i^T + bias_i) (contiguous rows; M <= 192, N <= 8192, K % 8 == 0, both K below 256 or both from 256) in one launch: the mask
+ * decoder's self-attention projections [q | k] = (x + pos) . Wqk^T and v = x . Wv^T (mask2former_transformer_decoder.py:24-38).  The same words as two
+ * psalm_gemm calls with float32 operands. */
+int psalm_gemm_f32_pair(const float* A0, const float* W0, const float* bias0, float* C0, int M0, int N0, int K0, int act0, const float* A1,
+                        const float* W1, const float* bias1, float* C1, int M1, int N1, int K1, int act1, void* stream);
 /* SwinTransformerBlock.forward front half (swin_trans.py:206-225): norm1 -> zero-pad to a multiple of ws ->
  * roll(-shift) -> window_partition.  x (B*H*W,C) -> out (B*nW*ws*ws, C). */
 int psalm_swin_window_gather(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,

@@ -183,6 +183,7 @@ extern "C" int psalm_get_tuning(int key);          // api.hip; keys: PSALM_TUNE_
 #define PSALM_TUNE_GEMM_XCD_KSPLIT 0
 #define PSALM_TUNE_ATTN_XCD_HEADS 1
 #define PSALM_TUNE_GEMM_MID 2
+#define PSALM_TUNE_DECODER_FUSE 3
 #define PSALM_TUNE_COUNT 8
 #endif
 

@@ -23,6 +23,7 @@
 // blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (sharing the A row-panel) are placed on the
 // same XCD (block b runs on XCD b % 8) so the panel is fetched into that XCD's L2 once.
 #include "common.h"
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <type_traits>
@@ -1709,12 +1710,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 // on v_mfma_f32_32x32x2_f32.  Lane (n, hi) contracts k = 8 c + 4 hi + i in step i of chunk c, so A and W fragments are 16-byte loads.
 // In the f16x3 mode this replaces split + split-f16 skinny GEMM (two launches, ~15 us) for these ~100 tiny GEMMs per image.
 template <typename TC, int NWV>
-__global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_skinny_body(const GemmArgs& g, float (*part)[32 * 32], int bx, int by) {
     // NWV wavefronts split K (16 for these latency-bound problems: the fp32 MFMA takes 64 cycles, a wave's serial chain of K / 2 / NWV of them
     // IS the kernel's duration -- r02k: 9 us per launch with 4 waves); the partial tiles meet in LDS and every thread finishes one element.
-    __shared__ float part[NWV][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n32 = lane & 31, hi = lane >> 5;
-    const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
+    const int bm = by * 32, bn = bx * 32;
     const float* A = (const float*)g.A + (long)min(bm + n32, g.M - 1) * g.lda + 4 * hi;
     const float* W = (const float*)g.W + (long)min(bn + n32, g.N - 1) * g.ldw + 4 * hi;
     const int chunks = g.K / 8, cpw = (chunks + NWV - 1) / NWV;
@@ -1776,6 +1776,21 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
             stf((TC*)g.C + (long)row * g.ldc + col, v);
         }
     }
+}
+template <typename TC, int NWV>
+__global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_kernel(GemmArgs g) {
+    __shared__ float part[NWV][32 * 32];
+    gemm_f32_skinny_body<TC, NWV>(g, part, blockIdx.x, blockIdx.y);
+}
+// Two independent skinny problems in ONE launch (blockIdx.z picks the problem; the grid covers the larger tile grid, the other's surplus blocks
+// leave at once): the mask decoder's self-attention projections  [q | k] = (x + pos) . Wqk^T  and  v = x . Wv^T  -- different A operands, so not
+// one GEMM -- were two dependent-looking ~6 us launches of its serial tail (mask2former_transformer_decoder.py:24-38).  Same body, same words.
+template <typename TC, int NWV>
+__global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_pair_kernel(GemmArgs g0, GemmArgs g1) {
+    __shared__ float part[NWV][32 * 32];
+    const GemmArgs& g = blockIdx.z ? g1 : g0;
+    if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M) return;      // (block-uniform)
+    gemm_f32_skinny_body<TC, NWV>(g, part, blockIdx.x, blockIdx.y);
 }
 
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
@@ -2289,6 +2304,32 @@ extern "C" int psalm_gemm(const void* A, int a_dtype, long lda, const void* W, i
     } else { psalm_set_error("psalm_gemm: bad weight dtype"); return -1; }
 #undef LAUNCH_BF16
     PSALM_LAUNCH_END("psalm_gemm");
+}
+
+// Two exact-fp32 skinny GEMMs (psalm_gemm with float32 operands, M <= 192, N <= 8192, K % 8 == 0) as one launch:
+// C_i = act_i(A_i . W_i^T + bias_i), i = 0, 1; contiguous operand rows (row strides K / N).  See gemm_f32_skinny_pair_kernel.
+extern "C" int psalm_gemm_f32_pair(const float* A0, const float* W0, const float* bias0, float* C0, int M0, int N0, int K0, int act0,
+                                   const float* A1, const float* W1, const float* bias1, float* C1, int M1, int N1, int K1, int act1, void* stream) {
+    PSALM_CHECK_ARG(A0 && W0 && C0 && A1 && W1 && C1, "psalm_gemm_f32_pair: null operand");
+    PSALM_CHECK_ARG(M0 > 0 && M1 > 0 && M0 <= 192 && M1 <= 192 && N0 > 0 && N1 > 0 && N0 <= 8192 && N1 <= 8192 && K0 > 0 && K1 > 0 && K0 % 8 == 0 && K1 % 8 == 0 &&
+                        (K0 >= 256) == (K1 >= 256),
+                    "psalm_gemm_f32_pair: M <= 192, N <= 8192, K % 8 == 0, both K below or both from 256 (psalm_gemm's 4- / 16-wave skinny kernels)");
+    PSALM_CHECK_ARG((uintptr_t)A0 % 16 == 0 && (uintptr_t)W0 % 16 == 0 && (uintptr_t)A1 % 16 == 0 && (uintptr_t)W1 % 16 == 0, "psalm_gemm_f32_pair: 16-byte aligned operands");
+    PSALM_CHECK_ARG(!((act0 | act1) & (ACT_BIAS_ROW | ACT_POST_RESIDUAL)), "psalm_gemm_f32_pair: plain activations only");
+    GemmArgs g[2];
+    const float* As[2] = {A0, A1}; const float* Ws[2] = {W0, W1}; const float* bs[2] = {bias0, bias1}; float* Cs[2] = {C0, C1};
+    const int Ms[2] = {M0, M1}, Ns[2] = {N0, N1}, Ks[2] = {K0, K1}, acts[2] = {act0, act1};
+    for (int i = 0; i < 2; ++i) {
+        g[i].A = As[i]; g[i].W = Ws[i]; g[i].bias = bs[i]; g[i].res = nullptr; g[i].C = Cs[i];
+        g[i].lda = Ks[i]; g[i].ldw = Ks[i]; g[i].ldr = 0; g[i].ldc = Ns[i];
+        g[i].M = Ms[i]; g[i].N = Ns[i]; g[i].K = Ks[i]; g[i].act = acts[i]; g[i].act_col_start = 0;
+        g[i].tiles_m = g[i].tiles_n = 0; g[i].row_fast = 0;
+    }
+    const dim3 grid(cdiv(std::max(N0, N1), 32), cdiv(std::max(M0, M1), 32), 2);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_f32_skinny_pair_kernel<float, %d>", K0 >= 256 ? 16 : 4);
+    if (K0 >= 256) hipLaunchKernelGGL((gemm_f32_skinny_pair_kernel<float, 16>), grid, dim3(1024), 0, (hipStream_t)stream, g[0], g[1]);
+    else hipLaunchKernelGGL((gemm_f32_skinny_pair_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, g[0], g[1]);
+    PSALM_LAUNCH_END("psalm_gemm_f32_pair");
 }
 
 // psalm_gemm followed by LayerNorm over the N columns of the (fp32) result:  C as psalm_gemm,  ln_out = LN(C) * gamma + beta

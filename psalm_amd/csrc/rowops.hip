@@ -141,6 +141,100 @@ extern "C" int psalm_layernorm3(const void* x, int x_dtype, long ldx, void* y, i
     PSALM_LAUNCH_END("psalm_layernorm");
 }
 
+// ---------------------------------------------------------------- LayerNorm chain of the mask decoder's query rows (fp32)
+//   y1 = LN1(x)        y2 = y1 + add[row % add_rows]   (optional)        y3 = LN2(y1)   (optional)
+// One launch for what mask2former_transformer_decoder.py runs as norm -> with_pos_embed(query, query_pos) -> decoder_norm (the cross-attention /
+// FFN post-norms at :72-74,:170-172, `output + query_pos` at :35-37, forward_prediction_heads' decoder_norm at :750) and r05 issued as
+// psalm_layernorm3 + psalm_add_bcast + psalm_layernorm3 on 100 x 256 values: three dependent ~6 us launches of the decoder's serial tail.
+// Arithmetic, reduction order and stored intermediates are those of layernorm_vec_kernel / add_bcast_kernel (y1 is consumed from the registers
+// it was stored from), so the chain returns the same words as the three launches (tests/test_1_ops.py).  C % 8 == 0, C <= 2048, 16-byte aligned rows.
+__global__ void __launch_bounds__(256) layernorm_chain_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y1, long ldy1,
+                                                              const float* __restrict__ g1, const float* __restrict__ b1,
+                                                              const float* __restrict__ add, long add_rows, float* __restrict__ y2, long ldy2,
+                                                              const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ y3,
+                                                              long ldy3, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float v[4][8];
+    auto stats = [&](float& mean, float& rstd) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[i][k];
+            }
+        }
+        mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+            }
+        }
+        rstd = rsqrtf(wave_sum(q) / C + eps);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) ld8(xr + c, v[i]);
+    }
+    float mean, rstd;
+    stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float g8[8], b8[8];
+            ld8(g1 + c, g8);
+            ld8(b1 + c, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] = (v[i][k] - mean) * rstd * g8[k] + b8[k];
+            st8(y1 + row * ldy1 + c, v[i]);
+            if (y2) {
+                float a8[8], o8[8];
+                ld8(add + (row % add_rows) * C + c, a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] = v[i][k] + a8[k];
+                st8(y2 + row * ldy2 + c, o8);
+            }
+        }
+    }
+    if (!y3) return;
+    stats(mean, rstd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            float g8[8], b8[8], o8[8];
+            ld8(g2 + c, g8);
+            ld8(b2 + c, b8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mean) * rstd * g8[k] + b8[k];
+            st8(y3 + row * ldy3 + c, o8);
+        }
+    }
+}
+extern "C" int psalm_layernorm_chain(const float* x, long ldx, float* y1, long ldy1, const float* g1, const float* b1, const float* add,
+                                     long add_rows, float* y2, long ldy2, const float* g2, const float* b2, float* y3, long ldy3, int rows,
+                                     int C, float eps, void* stream) {
+    if (rows == 0) return 0;
+    PSALM_CHECK_ARG(x && y1 && g1 && b1 && (!y2 || (add && add_rows > 0)) && (!y3 || (g2 && b2)), "psalm_layernorm_chain: null argument");
+    auto al = [](const void* p, long ld) { return (uintptr_t)p % 16 == 0 && (ld * 4) % 16 == 0; };
+    PSALM_CHECK_ARG(C % 8 == 0 && C > 0 && C <= 2048 && al(x, ldx) && al(y1, ldy1) && al(g1, 0) && al(b1, 0) && (!y2 || (al(y2, ldy2) && al(add, C))) &&
+                        (!y3 || (al(y3, ldy3) && al(g2, 0) && al(b2, 0))),
+                    "psalm_layernorm_chain: C % 8 == 0, C <= 2048, 16-byte aligned rows");
+    hipLaunchKernelGGL(layernorm_chain_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y1, ldy1, g1, b1, add, add_rows, y2, ldy2,
+                       g2, b2, y3, ldy3, rows, C, eps);
+    PSALM_LAUNCH_END("psalm_layernorm_chain");
+}
+
 extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, int y_dtype, long ldy, void* y2_bf16, long ldy2,
                                const float* gamma, const float* beta, int rows, int C, float eps, void* stream) {
     return psalm_layernorm3(x, x_dtype, ldx, y, y_dtype, ldy, y2_bf16, ldy2, nullptr, 0, nullptr, 0, gamma, beta, rows, C, eps, stream);

@@ -563,9 +563,11 @@ extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* cons
     // the mask features as the W operand of the 1 + num_layers mask GEMMs: split once when they are large (PSALM._wop: > 4096 rows), else exact fp32
     const bool mf_split = HW2 > 4096;
     if (mf_split) PR(psalm_split_f16(mask_features, MD, mfp, 2L * KpM, mfinv, HW2, MD, stream));
-    auto mask_head = [&](const float* out_) -> int {             // decoder_norm -> mask_embed MLP -> (Q, H2*W2) mask logits; `dec` stays for the class heads
+    // (fused LayerNorm chain / paired projections: D % 8 == 0, the skinny GEMM's M <= 192; PSALM_TUNE_DECODER_FUSE switches them off)
+    const bool fuse = D % 8 == 0 && D <= 2048 && Q <= 192 && psalm_get_tuning(PSALM_TUNE_DECODER_FUSE) != 0;
+    auto mask_head = [&](const float* out_, bool have_dec = false) -> int {   // decoder_norm -> mask_embed MLP -> (Q, H2*W2) mask logits; `dec` stays for the class heads
         int r;
-        if ((r = ln(out_, d->dn_g, d->dn_b, dec, Q))) return r;
+        if (!have_dec && (r = ln(out_, d->dn_g, d->dn_b, dec, Q))) return r;
         if ((r = g32(dec, Q, D, d->mask_embed_w[0], d->mask_embed_b[0], nullptr, me0, D, 1))) return r;
         if ((r = g32(me0, Q, D, d->mask_embed_w[1], d->mask_embed_b[1], nullptr, me1, D, 1))) return r;
         if ((r = g32(me1, Q, D, d->mask_embed_w[2], d->mask_embed_b[2], nullptr, me2, MD, 0))) return r;
@@ -587,20 +589,31 @@ extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* cons
         PR(psalm_mha_attention_f32(qp, D, Kl[l] + (long)j * D, N, Vl[l] + (long)j * D, N, a, D, amask, flags, mha, 1, Q, hw, nh, 32, stream));
         PR(g32(a, Q, D, ly->co_w, ly->co_b, out, x1, D, 0));
         float* o1 = outb[cur];
-        PR(ln(x1, ly->cn_g, ly->cn_b, o1, Q));
-        PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
-        PR(g32(outq, Q, D, ly->sqk_w, ly->sqk_b, nullptr, qk, 2 * D, 0));
-        PR(g32(o1, Q, D, ly->sv_w, ly->sv_b, nullptr, v, D, 0));
+        // (r06: the post-norm and `+ query_pos` as one launch; the two self-attention projections as one launch -- the same words as the r05 sequence
+        //  psalm_layernorm3, psalm_add_bcast, psalm_gemm x 2, which model.py's op-by-op path still issues and the stage test compares against)
+        if (fuse) {
+            PR(psalm_layernorm_chain(x1, D, o1, D, ly->cn_g, ly->cn_b, d->query_embed, Q, outq, D, nullptr, nullptr, nullptr, 0, Q, D, eps, stream));
+            PR(psalm_gemm_f32_pair(outq, ly->sqk_w, ly->sqk_b, qk, Q, 2 * D, D, 0, o1, ly->sv_w, ly->sv_b, v, Q, D, D, 0, stream));
+        } else {
+            PR(ln(x1, ly->cn_g, ly->cn_b, o1, Q));
+            PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+            PR(g32(outq, Q, D, ly->sqk_w, ly->sqk_b, nullptr, qk, 2 * D, 0));
+            PR(g32(o1, Q, D, ly->sv_w, ly->sv_b, nullptr, v, D, 0));
+        }
         PR(psalm_mha_attention_f32(qk, 2L * D, qk + D, 2L * D, v, D, a, D, nullptr, nullptr, mha, 1, Q, Q, nh, 32, stream));
         PR(g32(a, Q, D, ly->so_w, ly->so_b, o1, x1, D, 0));
         float* o2 = outb[cur ^ 1];
         PR(ln(x1, ly->sn_g, ly->sn_b, o2, Q));
         PR(g32(o2, Q, D, ly->f1_w, ly->f1_b, nullptr, hdd, F, 1));
         PR(g32(hdd, Q, F, ly->f2_w, ly->f2_b, o2, x1, D, 0));
-        PR(ln(x1, ly->fn_g, ly->fn_b, o1, Q));
-        PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+        if (fuse) {                                              // FFN post-norm, `+ query_pos` for the next layer and the mask head's decoder_norm: one launch
+            PR(psalm_layernorm_chain(x1, D, o1, D, ly->fn_g, ly->fn_b, d->query_embed, Q, outq, D, d->dn_g, d->dn_b, dec, D, Q, D, eps, stream));
+        } else {
+            PR(ln(x1, ly->fn_g, ly->fn_b, o1, Q));
+            PR(psalm_add_bcast(o1, PSALM_F32, d->query_embed, PSALM_F32, outq, PSALM_F32, Q, D, Q, stream));
+        }
         out = o1;
-        PR(mask_head(out));
+        PR(mask_head(out, fuse));
         cur ^= 1;
     }
     PR(psalm_copy_d2d(pred_masks, masks, (long)Q * HW2 * 4, stream));

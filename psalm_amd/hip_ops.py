@@ -679,7 +679,7 @@ class Ops:
         operands, a third of the matrix work -- the reduced-precision LLM side mode, not at the parity bar).  See psalm_gemm_x3_set_products."""
         self._check(self.lib.psalm_gemm_x3_set_products(int(n)), "psalm_gemm_x3_set_products")
 
-    TUNE_GEMM_XCD_KSPLIT, TUNE_ATTN_XCD_HEADS, TUNE_GEMM_MID = 0, 1, 2      # PSALM_TUNE_* of include/psalm_hip.h
+    TUNE_GEMM_XCD_KSPLIT, TUNE_ATTN_XCD_HEADS, TUNE_GEMM_MID, TUNE_DECODER_FUSE = 0, 1, 2, 3      # PSALM_TUNE_* of include/psalm_hip.h
 
     def set_tuning(self, key: int, value: int):
         """psalm_set_tuning: process-wide atomic switches between kernel forms with identical results (A/B runs, tests)."""
@@ -811,6 +811,27 @@ class Ops:
                                            B, HW, C, groups, c_float(eps), int(relu), self._stream())
         self._check(rc, "psalm_groupnorm_nhwc")
         return out
+
+    def layernorm_chain(self, x, g1, b1, add=None, g2=None, b2=None, eps=1e-5):
+        """(y1, y2 | None, y3 | None) = (LN(x; g1, b1), y1 + add[row % add_rows], LN(y1; g2, b2)) in one launch (psalm_layernorm_chain, fp32)."""
+        rows, C = x.shape
+        y1 = self.empty(rows, C, dtype=torch.float32)
+        y2 = self.empty(rows, C, dtype=torch.float32) if add is not None else None
+        y3 = self.empty(rows, C, dtype=torch.float32) if g2 is not None else None
+        rc = self.lib.psalm_layernorm_chain(self._p(x), c_long(x.stride(0)), self._p(y1), c_long(C), self._p(g1), self._p(b1), self._pv(add),
+                                            c_long(add.shape[0] if add is not None else 0), self._pv(y2), c_long(C), self._pv(g2), self._pv(b2),
+                                            self._pv(y3), c_long(C), rows, C, c_float(eps), self._stream())
+        self._check(rc, "psalm_layernorm_chain")
+        return y1, y2, y3
+
+    def gemm_f32_pair(self, a0, w0, bias0, a1, w1, bias1, act0=ACT_NONE, act1=ACT_NONE):
+        """two exact-fp32 skinny GEMMs in one launch (psalm_gemm_f32_pair): returns (a0 . w0^T + bias0, a1 . w1^T + bias1)"""
+        c0 = self.empty(a0.shape[0], w0.shape[0], dtype=torch.float32)
+        c1 = self.empty(a1.shape[0], w1.shape[0], dtype=torch.float32)
+        rc = self.lib.psalm_gemm_f32_pair(self._p(a0), self._p(w0), self._pv(bias0), self._p(c0), a0.shape[0], w0.shape[0], a0.shape[1], act0,
+                                          self._p(a1), self._p(w1), self._pv(bias1), self._p(c1), a1.shape[0], w1.shape[0], a1.shape[1], act1, self._stream())
+        self._check(rc, "psalm_gemm_f32_pair")
+        return c0, c1
 
     def add_bcast(self, a, b, out_dtype=None):
         """out[r] = a[r] + b[r % b_rows]   (a (rows,C), b (b_rows,C))."""

@@ -661,3 +661,40 @@ def test_causal_attention_xcd_head_placement_is_bitwise_the_plain_placement(ops,
         ops.set_tuning(ops.TUNE_ATTN_XCD_HEADS, 1)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert outs[0].abs().max() > 0
+
+
+@pytest.mark.parametrize("rows,C,with_add,with_ln2", [(100, 256, True, True), (100, 256, True, False), (7, 64, False, True), (33, 520, True, True)])
+def test_layernorm_chain_is_bitwise_the_three_launches(ops, rows, C, with_add, with_ln2):
+    """psalm_layernorm_chain (r06: the mask decoder's post-norm -> + query_pos -> decoder_norm as ONE launch) returns the words of
+    psalm_layernorm3, psalm_add_bcast, psalm_layernorm3."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 0.7
+    g1, b1, g2, b2 = (torch.randn(C, generator=g) for _ in range(4))
+    add = torch.randn(rows, C, generator=g)
+    d = ops.device
+    y1 = ops.layernorm(x.to(d), g1.to(d), b1.to(d))
+    y2 = ops.add_bcast(y1, add.to(d)) if with_add else None
+    y3 = ops.layernorm(y1, g2.to(d), b2.to(d)) if with_ln2 else None
+    c1, c2, c3 = ops.layernorm_chain(x.to(d), g1.to(d), b1.to(d), add.to(d) if with_add else None, g2.to(d) if with_ln2 else None,
+                                     b2.to(d) if with_ln2 else None)
+    assert torch.equal(c1.cpu().view(torch.int32), y1.cpu().view(torch.int32))
+    assert (c2 is None) == (y2 is None) and (c2 is None or torch.equal(c2.cpu().view(torch.int32), y2.cpu().view(torch.int32)))
+    assert (c3 is None) == (y3 is None) and (c3 is None or torch.equal(c3.cpu().view(torch.int32), y3.cpu().view(torch.int32)))
+    want = F.layer_norm(x, (C,), g1, b1, 1e-5)
+    assert (c1.cpu() - want).abs().max() < 3e-5 * want.abs().max()
+
+
+def test_gemm_f32_pair_is_bitwise_two_skinny_gemms(ops):
+    """psalm_gemm_f32_pair: [q | k] = (x + pos) . Wqk^T and v = x . Wv^T of the mask decoder's self-attention in one launch -- the same words as the
+    two exact-fp32 skinny GEMMs."""
+    Q, D = 100, 256
+    g = torch.Generator().manual_seed(5)
+    a0, a1 = torch.randn(Q, D, generator=g), torch.randn(Q, D, generator=g)
+    w0, w1 = torch.randn(2 * D, D, generator=g) * 0.1, torch.randn(D, D, generator=g) * 0.1
+    b0, b1 = torch.randn(2 * D, generator=g), torch.randn(D, generator=g)
+    d = ops.device
+    r0 = ops.gemm(a0.to(d), w0.to(d), b0.to(d))
+    r1 = ops.gemm(a1.to(d), w1.to(d), b1.to(d))
+    c0, c1 = ops.gemm_f32_pair(a0.to(d), w0.to(d), b0.to(d), a1.to(d), w1.to(d), b1.to(d))
+    assert torch.equal(c0.cpu().view(torch.int32), r0.cpu().view(torch.int32)) and torch.equal(c1.cpu().view(torch.int32), r1.cpu().view(torch.int32))
+    assert (c0.cpu().double() - (a0.double() @ w0.double().T + b0.double())).abs().max() < 1e-4
