@@ -29,7 +29,7 @@ const char* psalm_last_error(void);
  * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
  * 6: psalm_gemm_x3_set_products, psalm_fuse_masks, the stage-level psalm_phi_forward (r05); psalm_causal_attention_f32_workspace grew by one
  *    byte per 32-key tile.
- * 7: psalm_set_tuning / psalm_get_tuning, psalm_layernorm_chain, psalm_gemm_f32_pair (r06). */
+ * 7: psalm_set_tuning / psalm_get_tuning, psalm_layernorm_chain, psalm_gemm_f32_pair, psalm_postprocess* (r06). */
 #define PSALM_ABI_VERSION 7
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -527,6 +527,50 @@ int psalm_predictor_forward(const psalm_pr_desc* d, const float* const* ms_host,
                             const float* mask_features, int H2, int W2, const float* seg_query, const float* class_emb, int n_cls, const float* seg_emb,
                             int n_seg, const float* region_emb, int n_reg, float* pred_masks, float* cls_logits, float* seg_logits, float* region_logits,
                             void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+
+
+/* psalm_postprocess: llava_phi.py:1401-1466 for ONE image from native code -- the mask logits up-sampled to the padded image size (LP:1401-1406),
+ * cropped to the un-padded box and resized to the original size (sem_seg_postprocess, LP:1418-1429), then the task's inference function:
+ *   PSALM_POST_SEMANTIC   class_name_semantic_inference on the padded-size masks, THEN crop / resize of the class map (LP:301,402-406,1437-1440)
+ *   PSALM_POST_INSTANCE   class_name_instance_inference, no thing filter (LP:407-447)
+ *   PSALM_POST_PANOPTIC   semantic + instance (thing filter) + class_name_panoptic_inference (LP:325-386)
+ *   PSALM_POST_REFERRING  SEG_instance_inference (LP:308-324)
+ *   PSALM_POST_REGION     region_inference (LP:387-400)
+ * through the op-level entries above in psalm_amd/model.py's order -- the same words (tests/test_6_model_emu.py, tests/test_9_e2e_gpu.py).  The caller
+ * owns every buffer (outputs at their maximum sizes, one workspace of psalm_postprocess_workspace() bytes); nothing is allocated, nothing
+ * synchronises; the data-dependent counts stay on the device (`counts`) for the caller's one read-back.  precision "f16x3" / "fp32"; Q <= 128 and at most
+ * 160 classes for the tasks that form the class map (the fused split-f16 pass; wider vocabularies: the op-level calls).
+ *
+ * io (device pointers unless noted; unused ones NULL):
+ *   in   pred_masks (Q,h,w) f32 | mask_up (Q,Hpad,Wpad) f32 or NULL (the up-sampled logits if the caller already formed them -- the captured graph of
+ *        model.py does; NULL: formed here, in `mask_pred` when no crop / resize follows, else in the workspace) | cls_logits (Q,C1) | seg_logits (Q,1)
+ *        | region_logits (k,Q) | is_thing (C1-1) i32
+ *   out  mask_pred (Q,out_h,out_w) f32: the masks the task's function saw (semantic: (Q,Hpad,Wpad), written only when mask_up is NULL) | sem_seg (C1-1,out_h,out_w) f32 |
+ *        scores (Q [, k for region: (Q,k)]) f32 | classes (Q) i64 | query (Q) i64 | inst_masks (Q,out_h,out_w) f32 | boxes (Q,4) f32 zeros |
+ *        pan (out_h,out_w) i32 | counts i32: [0] instances kept, [1] segments, [2..2+3Q) segments_info rows (id, isthing, category)
+ *   mask_pred_is (HOST int*, may be NULL): 0 = `mask_pred` holds the returned masks, 1 = they are `mask_up` itself (no crop / resize was needed, or the
+ *        semantic task, whose `mask_pred` is the padded-size tensor). */
+#define PSALM_POST_SEMANTIC 0
+#define PSALM_POST_INSTANCE 1
+#define PSALM_POST_PANOPTIC 2
+#define PSALM_POST_REFERRING 3
+#define PSALM_POST_REGION 4
+typedef struct psalm_post_desc {
+    int task, Q, h, w, Hpad, Wpad, crop_h, crop_w, out_h, out_w, C1, n_region;
+    float obj_thr, overlap_thr;
+} psalm_post_desc;
+typedef struct psalm_post_io {
+    const float* pred_masks; const float* mask_up; const float* cls_logits; const float* seg_logits; const float* region_logits; const int* is_thing;
+    float* mask_pred; float* sem_seg; float* scores; long long* classes; long long* query; float* inst_masks; float* boxes; int* pan; int* counts;
+} psalm_post_io;
+long psalm_postprocess_workspace(const psalm_post_desc* d, int have_mask_up);
+int psalm_postprocess(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
+/* The five names of SURVEY.md section 8(b): psalm_postprocess with d->task checked against the name. */
+int psalm_postprocess_semantic(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
+int psalm_postprocess_instance(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
+int psalm_postprocess_panoptic(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
+int psalm_postprocess_referring(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
+int psalm_postprocess_region(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

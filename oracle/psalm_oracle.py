@@ -51,6 +51,16 @@ def _ln(sd, name, x, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
 
 
+# Control switch for the noise-floor experiments (tools/exp_referring_controls.py): True = the three attention forms below (Swin window, Phi causal,
+# mask-decoder multi-head) form their scores, softmax and value products in float64 and round ONCE to fp32 -- an evaluation at least as exact as
+# the reference's, in another summation order.  False (always, outside that tool): the reference's fp32 arithmetic, bit for bit.
+ATTN_FLOAT64 = False
+
+
+def _att_up(*ts):
+    return tuple(t.double() for t in ts) if ATTN_FLOAT64 else ts
+
+
 # ------------------------------------------------------------------------------------------ Swin
 def _window_partition(x, ws):                                   # SW:37-49
     B, H, W, C = x.shape
@@ -90,7 +100,7 @@ def _swin_block(sd, p, x, H, W, ws, shift, heads, attn_mask):    # SW:194-253 + 
     B_, N, _ = xw.shape
     hd = C // heads
     qkv = _lin(sd, p + "attn.qkv", xw).reshape(B_, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    q, k, v = _att_up(qkv[0] * hd ** -0.5, qkv[1], qkv[2])
     attn = q @ k.transpose(-2, -1)
     table = sd[p + "attn.relative_position_bias_table"]
     idx = sd[p + "attn.relative_position_index"].view(-1)
@@ -100,7 +110,7 @@ def _swin_block(sd, p, x, H, W, ws, shift, heads, attn_mask):    # SW:194-253 + 
         attn = attn.view(B_ // nW, nW, heads, N, N) + attn_mask.unsqueeze(1).unsqueeze(0)
         attn = attn.view(-1, heads, N, N)
     attn = attn.softmax(-1)
-    xw = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    xw = (attn @ v).float().transpose(1, 2).reshape(B_, N, C)
     xw = _lin(sd, p + "attn.proj", xw)
     x = _window_reverse(xw.view(-1, ws, ws, C), ws, Hp, Wp)
     if shift > 0:
@@ -299,9 +309,10 @@ def phi_forward(sd, cfg, inputs_embeds, attention_mask, prefix="model."):
         qr, kr = q[..., :rd], k[..., :rd]
         q = torch.cat((qr * cos + rot_half(qr) * sin, q[..., rd:]), -1)
         k = torch.cat((kr * cos + rot_half(kr) * sin, k[..., rd:]), -1)
+        q, k, v = _att_up(q, k, v)
         w = torch.matmul(q, k.transpose(2, 3)) * hd ** -0.5 + bias
-        w = F.softmax(w, dim=-1, dtype=torch.float32)
-        a = torch.matmul(w, v).transpose(1, 2).reshape(B, L, H)
+        w = F.softmax(w, dim=-1, dtype=w.dtype)                                    # (fp32: PHI:150 `softmax(..., dtype=torch.float32)`)
+        a = torch.matmul(w, v).float().transpose(1, 2).reshape(B, L, H)
         a = _lin(sd, p + "self_attn.dense", a)
         m = _lin(sd, p + "mlp.fc2", gelu_new(_lin(sd, p + "mlp.fc1", x)))
         h = a + m + h
@@ -474,11 +485,12 @@ def _mha(sd, name, q, k, v, heads, mask=None):
     qq = qq.view(B, Lq, heads, hd).transpose(1, 2) * hd ** -0.5
     kk = kk.view(B, -1, heads, hd).transpose(1, 2)
     vv = vv.view(B, -1, heads, hd).transpose(1, 2)
+    qq, kk, vv = _att_up(qq, kk, vv)
     a = qq @ kk.transpose(-2, -1)
     if mask is not None:
         a = a.masked_fill(mask, float("-inf"))
     a = a.softmax(-1)
-    o = (a @ vv).transpose(1, 2).reshape(B, Lq, D)
+    o = (a @ vv).float().transpose(1, 2).reshape(B, Lq, D)
     return _lin(sd, name + ".out_proj", o)
 
 

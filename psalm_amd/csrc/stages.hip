@@ -639,3 +639,153 @@ extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* cons
 #undef PR
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------ post-processing
+// psalm_postprocess: llava_phi.py:1401-1466 for one image (see psalm_hip.h), the launch sequence of PSALM._post_head + PSALM._post_tail.
+struct PostLayout { long up, semp, probs, probsT, score, label, mscore, msws, cl, qq, argq, pcnt, fid, total; };
+static PostLayout post_layout(const psalm_post_desc* d, bool have_up) {
+    PostLayout o;
+    const long Q = d->Q, HWp = (long)d->Hpad * d->Wpad, HWo = (long)d->out_h * d->out_w, C1 = std::max(d->C1, 1);
+    const bool resize_after = !(d->crop_h == d->Hpad && d->crop_w == d->Wpad && d->out_h == d->Hpad && d->out_w == d->Wpad);
+    long p = 0;
+    o.up = p; if (!have_up && resize_after && d->task != PSALM_POST_SEMANTIC) p += al256(Q * HWp * 4);          // up-sampled logits in front of the crop / resize
+    o.semp = p; if (resize_after && d->task == PSALM_POST_SEMANTIC) p += al256((C1 - 1) * HWp * 4);              // semantic: the class map at the padded size
+    o.probs = p; p += al256(Q * C1 * 4);
+    o.probsT = p; p += al256(C1 * 128 * 4);
+    o.score = p; p += al256(Q * 4);
+    o.label = p; p += al256(Q * 4);
+    o.mscore = p; p += al256(Q * 4);
+    o.msws = p; p += al256(Q * 512 * 2 * 4);
+    o.cl = p; p += al256(Q * 4);
+    o.qq = p; p += al256(Q * 4);
+    o.argq = p; p += al256(std::max(HWo, HWp) * 4);
+    o.pcnt = p; p += al256(Q * 3 * 4);
+    o.fid = p; p += al256((Q + C1 + 1) * 4);
+    o.total = p;
+    return o;
+}
+static int post_check(const psalm_post_desc* d) {
+    PSALM_CHECK_ARG(d && d->task >= PSALM_POST_SEMANTIC && d->task <= PSALM_POST_REGION, "psalm_postprocess: descriptor / task code");
+    PSALM_CHECK_ARG(d->Q > 0 && d->Q <= 128 && d->h > 0 && d->w > 0 && d->Hpad > 0 && d->Wpad > 0 && d->crop_h > 0 && d->crop_w > 0 && d->crop_h <= d->Hpad &&
+                        d->crop_w <= d->Wpad && d->out_h > 0 && d->out_w > 0,
+                    "psalm_postprocess: Q <= 128, positive geometry, crop box inside the padded image");
+    if (d->task <= PSALM_POST_PANOPTIC)
+        PSALM_CHECK_ARG(d->C1 >= 2 && (d->task == PSALM_POST_INSTANCE || d->C1 - 1 <= 160),
+                        "psalm_postprocess: class logits of C1 >= 2 columns; at most 160 classes where the class map is formed (op-level calls beyond)");
+    if (d->task == PSALM_POST_REGION) PSALM_CHECK_ARG(d->n_region > 0, "psalm_postprocess: region task needs n_region > 0");
+    return 0;
+}
+extern "C" long psalm_postprocess_workspace(const psalm_post_desc* d, int have_mask_up) {
+    if (post_check(d) != 0) return -1;
+    return post_layout(d, have_mask_up != 0).total;
+}
+extern "C" int psalm_postprocess(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace, long workspace_bytes, void* stream) {
+    if (post_check(d) != 0) return -1;
+    PSALM_CHECK_ARG(io && (io->pred_masks || io->mask_up) && workspace, "psalm_postprocess: null argument");
+    const bool have_up = io->mask_up != nullptr;
+    const PostLayout lo = post_layout(d, have_up);
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_postprocess: workspace of psalm_postprocess_workspace() bytes, 256-byte aligned");
+    char* ws = (char*)workspace;
+    const int Q = d->Q, C1 = d->C1, task = d->task, Kpad = (Q + 63) / 64 * 64;
+    const long HWp = (long)d->Hpad * d->Wpad, HWo = (long)d->out_h * d->out_w;
+    const bool resize_after = !(d->crop_h == d->Hpad && d->crop_w == d->Wpad && d->out_h == d->Hpad && d->out_w == d->Wpad);
+    int rc;
+#define PO(call) do { rc = (call); if (rc) return rc; } while (0)
+    // ---- PSALM._post_head: the mask logits at the padded image size, the class softmax
+    const float* up = io->mask_up;
+    if (!up) {
+        const bool to_out = !resize_after || task == PSALM_POST_SEMANTIC;        // (semantic: `mask_pred` is the padded-size tensor, LP:1437-1440)
+        PSALM_CHECK_ARG(!to_out || io->mask_pred, "psalm_postprocess: mask_pred buffer missing");
+        float* dst = to_out ? io->mask_pred : (float*)(ws + lo.up);
+        PO(psalm_resize_planes(io->pred_masks, PSALM_F32, dst, PSALM_F32, Q, d->h, d->w, d->h, d->w, d->Hpad, d->Wpad, stream));      // LP:1401-1406
+        up = dst;
+    }
+    float* probs = (float*)(ws + lo.probs); float* probsT = (float*)(ws + lo.probsT); float* score = (float*)(ws + lo.score);
+    int* label = (int*)(ws + lo.label);
+    if (task <= PSALM_POST_PANOPTIC) {
+        PSALM_CHECK_ARG(io->cls_logits, "psalm_postprocess: cls_logits missing");
+        PO(psalm_memset_zero(probsT, (long)(C1 - 1) * Kpad * 4, stream));
+        PO(psalm_class_softmax(io->cls_logits, probs, probsT, PSALM_F32, score, label, Q, C1, Kpad, stream));
+    }
+    // ---- PSALM._post_tail
+    const float* mp = up;
+    long HW = HWp;
+    int mh = d->Hpad, mw = d->Wpad;
+    if (resize_after && task != PSALM_POST_SEMANTIC) {                                  // sem_seg_postprocess (LP:1427-1429)
+        PSALM_CHECK_ARG(io->mask_pred, "psalm_postprocess: mask_pred buffer missing");
+        PO(psalm_resize_planes(up, PSALM_F32, io->mask_pred, PSALM_F32, Q, d->Hpad, d->Wpad, d->crop_h, d->crop_w, d->out_h, d->out_w, stream));
+        mp = io->mask_pred; HW = HWo; mh = d->out_h; mw = d->out_w;
+    }
+    if (mask_pred_is) *mask_pred_is = (mp == io->mask_up && io->mask_up) ? 1 : 0;
+    float* mscore = (float*)(ws + lo.mscore); float* msws = (float*)(ws + lo.msws);
+    int* cl = (int*)(ws + lo.cl); int* qq = (int*)(ws + lo.qq);
+    auto zero_topk = [&]() -> int {
+        int r;
+        if ((r = psalm_memset_zero(io->scores, (long)Q * 4, stream))) return r;
+        if ((r = psalm_memset_zero(cl, (long)Q * 4, stream))) return r;
+        return psalm_memset_zero(qq, (long)Q * 4, stream);
+    };
+    if (task == PSALM_POST_SEMANTIC) {                                                  // on the padded-size masks, post-processed AFTER inference (LP:301,1437-1440)
+        PSALM_CHECK_ARG(io->sem_seg && Kpad == 128, "psalm_postprocess: sem_seg buffer; Q in (64, 128]");
+        float* sem = resize_after ? (float*)(ws + lo.semp) : io->sem_seg;
+        PO(psalm_semantic_from_masks_x3(mp, probsT, sem, nullptr, nullptr, Q, C1 - 1, HW, Kpad, stream));                  // LP:402-406
+        if (resize_after)
+            PO(psalm_resize_planes(sem, PSALM_F32, io->sem_seg, PSALM_F32, C1 - 1, d->Hpad, d->Wpad, d->crop_h, d->crop_w, d->out_h, d->out_w, stream));
+        if (mask_pred_is) *mask_pred_is = io->mask_up ? 1 : 0;
+        return 0;
+    }
+    PSALM_CHECK_ARG(io->scores && io->inst_masks && io->boxes && io->counts, "psalm_postprocess: scores / inst_masks / boxes / counts buffers");
+    if (task == PSALM_POST_INSTANCE) {
+        PSALM_CHECK_ARG(io->classes && io->query, "psalm_postprocess: classes / query buffers");
+        PO(psalm_mask_scores(mp, mscore, msws, Q, HW, stream));
+        PO(zero_topk());
+        PO(psalm_memset_zero(io->counts, 4, stream));
+        PO(psalm_topk_select(probs, Q, C1 - 1, C1, Q, nullptr, mscore, io->scores, cl, qq, io->counts, 0, stream));
+        PO(psalm_cast_i32_i64(cl, io->classes, Q, stream));
+        PO(psalm_cast_i32_i64(qq, io->query, Q, stream));
+        PO(psalm_binarize_gather(mp, qq, io->counts, io->inst_masks, Q, HW, stream));
+        PO(psalm_memset_zero(io->boxes, (long)Q * 4 * 4, stream));
+    } else if (task == PSALM_POST_PANOPTIC) {
+        PSALM_CHECK_ARG(io->classes && io->query && io->sem_seg && io->pan && io->is_thing && Kpad == 128, "psalm_postprocess: panoptic buffers; Q in (64, 128]");
+        PO(psalm_semantic_from_masks_x3(mp, probsT, io->sem_seg, mscore, msws, Q, C1 - 1, HW, Kpad, stream));          // LP:402-406, 443-444
+        PO(psalm_memset_zero(io->counts, (long)(2 + 3 * Q) * 4, stream));
+        PO(zero_topk());
+        PO(psalm_topk_select(probs, Q, C1 - 1, C1, Q, io->is_thing, mscore, io->scores, cl, qq, io->counts, 0, stream));   // LP:407-447
+        PO(psalm_binarize_gather(mp, qq, io->counts, io->inst_masks, Q, HW, stream));
+        PO(psalm_panoptic(mp, score, label, io->is_thing, (int*)(ws + lo.argq), (int*)(ws + lo.pcnt), (int*)(ws + lo.fid), io->pan, io->counts + 2,
+                          io->counts + 1, Q, HW, C1 - 1, d->obj_thr, d->overlap_thr, stream));
+        PO(psalm_cast_i32_i64(cl, io->classes, Q, stream));
+        PO(psalm_cast_i32_i64(qq, io->query, Q, stream));
+        PO(psalm_memset_zero(io->boxes, (long)Q * 4 * 4, stream));
+    } else if (task == PSALM_POST_REFERRING) {
+        PSALM_CHECK_ARG(io->seg_logits && io->query, "psalm_postprocess: seg_logits / query");
+        PO(psalm_mask_scores(mp, mscore, msws, Q, HW, stream));
+        PO(zero_topk());
+        PO(psalm_memset_zero(io->counts, 4, stream));
+        PO(psalm_topk_select(io->seg_logits, Q, 1, 1, Q, nullptr, mscore, io->scores, cl, qq, io->counts, 1, stream));     // LP:308-324
+        PO(psalm_binarize_gather(mp, qq, io->counts, io->inst_masks, Q, HW, stream));
+        PO(psalm_cast_i32_i64(qq, io->query, Q, stream));
+        PO(psalm_memset_zero(io->boxes, (long)Q * 4 * 4, stream));
+    } else {                                                                            // region
+        PSALM_CHECK_ARG(io->region_logits, "psalm_postprocess: region_logits");
+        PO(psalm_mask_scores(mp, mscore, msws, Q, HW, stream));
+        PO(psalm_region_scores(io->region_logits, mscore, io->scores, d->n_region, Q, stream));                            // LP:387-400
+        PO(psalm_binarize_gather(mp, nullptr, nullptr, io->inst_masks, Q, HW, stream));
+        PO(psalm_memset_zero(io->boxes, (long)Q * 4 * 4, stream));
+    }
+    (void)mh; (void)mw;
+#undef PO
+    return 0;
+}
+#define PSALM_POST_NAMED(name_, code_)                                                                                                             \
+    extern "C" int psalm_postprocess_##name_(const psalm_post_desc* d, const psalm_post_io* io, int* mask_pred_is, void* workspace,               \
+                                             long workspace_bytes, void* stream) {                                                                 \
+        PSALM_CHECK_ARG(d && d->task == code_, "psalm_postprocess_" #name_ ": descriptor of another task");                                         \
+        return psalm_postprocess(d, io, mask_pred_is, workspace, workspace_bytes, stream);                                                         \
+    }
+PSALM_POST_NAMED(semantic, PSALM_POST_SEMANTIC)
+PSALM_POST_NAMED(instance, PSALM_POST_INSTANCE)
+PSALM_POST_NAMED(panoptic, PSALM_POST_PANOPTIC)
+PSALM_POST_NAMED(referring, PSALM_POST_REFERRING)
+PSALM_POST_NAMED(region, PSALM_POST_REGION)

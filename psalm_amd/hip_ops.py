@@ -114,6 +114,16 @@ class SplitF16:
         return torch.float32                      # the values it stands for
 
 
+class _PostDesc(ctypes.Structure):           # psalm_post_desc of include/psalm_hip.h
+    _fields_ = [(n, c_int) for n in ("task", "Q", "h", "w", "Hpad", "Wpad", "crop_h", "crop_w", "out_h", "out_w", "C1", "n_region")] + \
+               [("obj_thr", c_float), ("overlap_thr", c_float)]
+
+
+class _PostIO(ctypes.Structure):             # psalm_post_io
+    _fields_ = [(n, c_void_p) for n in ("pred_masks", "mask_up", "cls_logits", "seg_logits", "region_logits", "is_thing", "mask_pred", "sem_seg", "scores",
+                                        "classes", "query", "inst_masks", "boxes", "pan", "counts")]
+
+
 class _PhiLayer(ctypes.Structure):           # psalm_phi_layer of include/psalm_hip.h
     _fields_ = [("w1", c_void_p), ("w1_scale", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("w2_scale", c_void_p), ("b2", c_void_p),
                 ("ln_g", c_void_p), ("ln_b", c_void_p), ("bnd", c_void_p), ("paired", c_int)]
@@ -655,6 +665,62 @@ class Ops:
                                               c_long(self.GEMM_WS_BYTES), self._stream())
         self._check(rc, "psalm_predictor_forward")
         return masks, cls, seg, reg
+
+    POST_TASKS = {"semantic": 0, "instance": 1, "panoptic": 2, "referring": 3, "region": 4}
+
+    def postprocess(self, task, sizes, pred_masks=None, mask_up=None, cls_logits=None, seg_logits=None, region_logits=None, is_thing=None,
+                    obj_thr=0.8, overlap_thr=0.8):
+        """llava_phi.py:1401-1466 for one image as ONE native call (psalm_postprocess_<task>): sizes = (Hpad, Wpad, crop_h, crop_w, out_h, out_w);
+        pred_masks (Q,h,w) and / or mask_up (Q,Hpad,Wpad) float32.  Returns a dict of the result tensors at their maximum sizes (the caller slices by
+        `counts` after its one read-back): mask_pred, sem_seg, scores, classes, query, inst_masks, boxes, pan, counts -- those the task has."""
+        Hpad, Wpad, oh, ow, height, width = [int(v) for v in sizes]
+        src = pred_masks if pred_masks is not None else mask_up
+        Q = int(src.shape[0])
+        h_, w_ = (int(pred_masks.shape[1]), int(pred_masks.shape[2])) if pred_masks is not None else (Hpad, Wpad)
+        C1 = int(cls_logits.shape[1]) if cls_logits is not None else 0
+        k = int(region_logits.shape[0]) if region_logits is not None else 0
+        code = self.POST_TASKS[task]
+        d = _PostDesc(code, Q, h_, w_, Hpad, Wpad, oh, ow, height, width, C1, k, float(obj_thr), float(overlap_thr))
+        self.lib.psalm_postprocess_workspace.restype = c_long
+        nbytes = self.lib.psalm_postprocess_workspace(ctypes.byref(d), 1 if mask_up is not None else 0)
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_postprocess_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-ws.data_ptr()) % 256
+        resize_after = (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad)
+        out = {}
+        if task == "semantic":
+            if mask_up is None:
+                out["mask_pred"] = self.empty(Q, Hpad, Wpad)
+            out["sem_seg"] = self.empty(C1 - 1, height, width)
+        else:
+            if resize_after or mask_up is None:
+                out["mask_pred"] = self.empty(Q, height, width)
+            out["scores"] = self.empty(Q, k) if task == "region" else self.empty(Q)
+            out["inst_masks"] = self.empty(Q, height, width)
+            out["boxes"] = self.empty(Q, 4)
+            out["counts"] = self.empty(2 + 3 * Q, dtype=torch.int32)
+            if task in ("instance", "panoptic"):
+                out["classes"] = self.empty(Q, dtype=torch.int64)
+            if task != "region":
+                out["query"] = self.empty(Q, dtype=torch.int64)
+            if task == "panoptic":
+                out["sem_seg"] = self.empty(C1 - 1, height, width)
+                out["pan"] = self.empty(height, width, dtype=torch.int32)
+        io = _PostIO(*[self._pi(t) for t in (pred_masks, mask_up, cls_logits, seg_logits, region_logits, is_thing, out.get("mask_pred"), out.get("sem_seg"),
+                                             out.get("scores"), out.get("classes"), out.get("query"), out.get("inst_masks"), out.get("boxes"), out.get("pan"),
+                                             out.get("counts"))])
+        which = c_int(0)
+        fn = getattr(self.lib, "psalm_postprocess_" + task)
+        rc = fn(ctypes.byref(d), ctypes.byref(io), ctypes.byref(which), c_void_p(ws.data_ptr() + off), c_long(nbytes), self._stream())
+        self._check(rc, "psalm_postprocess_" + task)
+        if which.value == 1:
+            out["mask_pred"] = mask_up
+        return out
+
+    @staticmethod
+    def _pi(t):
+        return None if t is None else t.data_ptr()
 
     def phi_forward(self, desc, embeds, key_mask, cos, sin, B, L):
         """PhiModel.forward over inputs_embeds (B*L, hidden) float32 as ONE native call (psalm_phi_forward): returns the final-LayerNorm hidden

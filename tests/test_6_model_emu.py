@@ -290,3 +290,57 @@ def test_stage_level_calls_are_bitwise_the_op_by_op_sequence(task, batch):
     rc = ops.lib.psalm_phi_forward(ctypes.byref(d), c_void_p(x.data_ptr()), c_void_p(km.data_ptr()), c_void_p(cos.data_ptr()), c_void_p(sin.data_ptr()),
                                    1, 64, c_void_p(x.data_ptr()), c_void_p(ws.data_ptr() + off), c_long(need - 1), None, c_long(0), None)
     assert rc != 0 and b"workspace" in ops.lib.psalm_last_error()
+
+
+def _flatten_result(r):
+    """every tensor of one eval_seg result, by name (Instances fields, the panoptic pair, plain tensors)"""
+    out = {}
+    for k, v in r.items():
+        if torch.is_tensor(v):
+            out[k] = v
+        elif isinstance(v, tuple):                                   # panoptic_seg: (id map, segments_info)
+            out[k + ".map"] = v[0]
+            out[k + ".info"] = v[1]
+        elif hasattr(v, "_fields") or hasattr(v, "__dict__"):
+            for f, t in vars(v).items():
+                if torch.is_tensor(t):
+                    out[f"{k}.{f}"] = t
+                elif isinstance(t, dict):
+                    for f2, t2 in t.items():
+                        if torch.is_tensor(t2):
+                            out[f"{k}.{f2}"] = t2
+    return out
+
+
+@pytest.mark.parametrize("task,pad", [("panoptic", 0), ("panoptic", 11), ("semantic", 0), ("semantic", 11), ("instance", 11), ("referring", 0), ("referring", 11),
+                                      ("region", 11)])
+def test_native_postprocess_is_bitwise_the_op_sequence(task, pad):
+    """psalm_postprocess_<task> (csrc/stages.hip): llava_phi.py:1401-1466 for one image as ONE native call -- the results of
+    eval_seg are word for word those of PSALM._post_tail_ops, the same op-level entries issued from Python; with and without a crop / resize to the
+    original size.  72 queries: the class-map tasks take the fused split-f16 pass (Q in (64, 128]), as the 100-query model does."""
+    import dataclasses
+    cfg = dataclasses.replace(PsalmConfig.tiny(task), md_queries=72)
+    sd = make_state_dict(cfg, seed=21)
+    inputs = make_inputs(cfg, task, size=96, batch=1, seed=6, num_classes=9, pad=pad)
+    ops = make_ops("emu")
+    m = PSALM(cfg, sd, ops=ops, precision="f16x3")
+    calls = []
+    real = ops.postprocess
+    ops.postprocess = lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1]
+    try:
+        torch.manual_seed(3)
+        got = m.eval_seg(**inputs)
+        assert calls == [task], calls                                    # the native entry ran
+        m._post_native_ok = lambda h: False
+        torch.manual_seed(3)
+        want = m.eval_seg(**inputs)
+        assert calls == [task]
+    finally:
+        ops.postprocess = real
+    fa, fb = _flatten_result(got[0]), _flatten_result(want[0])
+    assert set(fa) == set(fb) and len(fa) >= 1, (sorted(fa), sorted(fb))
+    for k in fa:
+        if torch.is_tensor(fa[k]):
+            assert fa[k].shape == fb[k].shape and fa[k].dtype == fb[k].dtype and torch.equal(fa[k], fb[k]), k
+        else:
+            assert fa[k] == fb[k], k
