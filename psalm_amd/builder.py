@@ -135,13 +135,6 @@ class ImagePreprocessor:
 
     def preprocess(self, dataset_dict, region_mask_type=None, mask_format="polygon", ignore_label=None):
         d = dict(dataset_dict)
-        # The reference's mappers turn annotation RLEs into `instances.region_masks` here (coco_instance_mapper.py:233-252: decode ->
-        # enhance_with_circles(10 | 5) -> transforms.apply_segmentation).  That annotation transform is the dataset side of the interactive task
-        # and is not done by this processor: a caller that asks for it must not get an image dict that silently lacks the region masks.
-        if region_mask_type is not None:
-            raise NotImplementedError(
-                "ImagePreprocessor.preprocess(region_mask_type=...) is not implemented: build `region_masks` with "
-                "psalm_amd.preprocess.region_masks_from_annotations(...) (or the reference's dataset mapper) and pass them in the instances")
         if "image" in d and not torch.is_tensor(d["image"]) or ("image" in d and d["image"].dtype == torch.uint8):
             img = d["image"]
         else:
@@ -156,6 +149,31 @@ class ImagePreprocessor:
         d.update(image=r["image"], padding_mask=r["padding_mask"], transforms=r["transforms"])
         d.setdefault("height", r["height"])
         d.setdefault("width", r["width"])
+        # Interactive task: the annotations' visual-prompt RLEs -> `instances.region_masks` (coco_instance_mapper.py:233-252: decode ->
+        # enhance_with_circles(10 | 5) -> transforms.apply_segmentation) and the kept objects' ground-truth masks -> `instances.gt_masks`
+        # (eval_seg's region branch reads both, llava_phi.py:792,1458).  Bitmask (RLE) ground truth only: polygon rasterisation is pycocotools'
+        # frPyObjects, the dataset side this processor does not restate.
+        annos = [a for a in d.get("annotations", []) if a.get("iscrowd", 0) == 0]
+        has_prompts = bool(annos) and "point_visual_prompt_mask" in annos[0]
+        if region_mask_type is not None and not has_prompts:
+            raise ValueError("preprocess(region_mask_type=...): the dataset dict carries no annotations with visual-prompt masks "
+                             "(`point_visual_prompt_mask` ... of coco_instance_mapper.py:233-238)")
+        if has_prompts:
+            from .preprocess import apply_segmentation, region_masks_from_annotations, rle_to_mask
+            from .synthetic import RegionInstances
+            rm, kept = region_masks_from_annotations(annos, r["transforms"], region_mask_type)
+            if not kept:
+                raise ValueError("preprocess: no annotation of this image has a non-empty visual prompt of the requested kinds")
+            gts = []
+            for i in kept:
+                seg = annos[i].get("segmentation")
+                if not isinstance(seg, dict):
+                    raise NotImplementedError("preprocess: region prompts need bitmask (RLE dict) ground truth -- mask_format='bitmask', as the "
+                                              "reference's interactive / DAVIS evaluation passes (eval_davis.py:317); polygons are not rasterised here")
+                gts.append(apply_segmentation(rle_to_mask(seg), r["transforms"]))
+            import numpy as np
+            d["instances"] = RegionInstances(torch.from_numpy(rm.astype(bool)), torch.from_numpy(np.stack(gts).astype(np.float32)))
+            d["region_annotation_indices"] = kept
         return d
 
 
