@@ -155,9 +155,8 @@ class ImagePreprocessor:
         # frPyObjects, the dataset side this processor does not restate.
         annos = [a for a in d.get("annotations", []) if a.get("iscrowd", 0) == 0]
         has_prompts = bool(annos) and "point_visual_prompt_mask" in annos[0]
-        if region_mask_type is not None and not has_prompts:
-            raise ValueError("preprocess(region_mask_type=...): the dataset dict carries no annotations with visual-prompt masks "
-                             "(`point_visual_prompt_mask` ... of coco_instance_mapper.py:233-238)")
+        # (a dict without annotations, or whose annotations carry no prompt keys, comes back without `instances` whatever `region_mask_type` says:
+        #  the reference consults it only inside `if 'point_visual_prompt_mask' in annos[0]`, coco_instance_mapper.py:218,233)
         if has_prompts:
             from .preprocess import apply_segmentation, region_masks_from_annotations, rle_to_mask
             from .synthetic import RegionInstances

@@ -103,8 +103,8 @@ def test_rle_to_mask_both_count_forms_and_the_runs_order():
 def test_preprocess_builds_region_masks_from_prompt_annotations():
     """ImagePreprocessor.preprocess(dataset_dict, region_mask_type=...) for the interactive task (coco_instance_mapper.py:233-252): one region mask
     per object -- prompt RLE decoded, points widened to radius-10 discs, NEAREST-resized and zero-padded to the (S, S) canvas exactly as the image's
-    own geometry -- plus the kept objects' ground-truth masks; crowd objects and objects without a prompt of the requested kind are left out; a
-    request that cannot be honoured raises instead of returning a dict without region masks."""
+    own geometry -- plus the kept objects' ground-truth masks; crowd objects and objects without a prompt of the requested kind are left out; prompt
+    annotations none of which is usable raise instead of returning `instances` without region masks."""
     import numpy as np
     from PIL import Image
     from oracle import evalout_ref as E
@@ -147,7 +147,6 @@ def test_preprocess_builds_region_masks_from_prompt_annotations():
     # box prompts: no widening; the kind is drawn per object from those that are present
     d2 = proc.preprocess({"image": img, "annotations": annos}, region_mask_type=["box_visual_prompt_mask"])
     assert d2["region_annotation_indices"] == [0, 2] and int(d2["instances"].region_masks.tensor[0].sum()) > 0
-    with pytest.raises(ValueError):
-        proc.preprocess({"image": img}, region_mask_type=["point_visual_prompt_mask"])                         # no annotations to take prompts from
+    assert "instances" not in proc.preprocess({"image": img}, region_mask_type=["point_visual_prompt_mask"])    # no annotations: as the reference, nothing to do
     with pytest.raises(ValueError):
         proc.preprocess({"image": img, "annotations": annos}, region_mask_type=["scribble_visual_prompt_mask"])  # nothing non-empty of that kind
