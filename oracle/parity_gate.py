@@ -62,9 +62,10 @@ def knife_edge_inputs():
         return json.load(f)["inputs"]
 
 
-def knife_edge_entry(task, size, inputs_seed, weights_seed=0, batch=1):
+def knife_edge_entry(task, size, inputs_seed, weights_seed=0, batch=1, image=0):
+    """The list entry of image `image` of the seeded input, or None.  (An entry without an "image" key is image 0 of its batch.)"""
     for e in knife_edge_inputs():
-        if (e["task"], e["size"], e["inputs_seed"], e["weights_seed"], e.get("batch", 1)) == (task, size, inputs_seed, weights_seed, batch):
+        if (e["task"], e["size"], e["inputs_seed"], e["weights_seed"], e.get("batch", 1), e.get("image", 0)) == (task, size, inputs_seed, weights_seed, batch, image):
             return e
     return None
 
@@ -124,7 +125,7 @@ def judge(p, g=None, w_=None, entry=None):
         sym = len(flipped_set(g, w_) ^ control)
         p["knife_edge_symmetric_difference_vs_control"] = sym
         if sym <= KNIFE_EDGE_PIXELS:
-            ok, side = True, "float64_control"
+            ok, side = True, entry.get("control_side", "float64_control")
     if entry is not None:
         p["on_knife_edge_list"] = True
     p["passes_gate"], p["side"] = ok, side

@@ -170,9 +170,13 @@ extern "C" int psalm_iou_counts(const void* pred, int pred_is_u8, const unsigned
 }
 
 // ---------------------------------------------------------------- gRefCOCO: the fused prediction of compute_metric (eval_grefcoco.py:113-131)
-// out[p] = OR over the candidates i with scores[i] > thr of (masks[i][p] != 0); when NO candidate passes the threshold, the single candidate
-// with the largest score (torch.topk(scores, 1): the first maximal element) -- the reference's "no candidate -> top-1" fall-back.  The
-// selection is re-derived by every block from the <= 1024 scores (one thread, a few hundred compares) instead of a host round trip.
+// out[p] = OR over the candidates i with scores[i] > thr of [masks[i][p] set]; when NO candidate passes the threshold, the single candidate
+// with the largest score -- the reference's "no candidate -> top-1" fall-back.  The selection is re-derived by every block from the <= 1024
+// scores (one thread, a few hundred compares) instead of a host round trip.
+//   "set": a uint8 mask element != 0; a float mask element after the reference's `preds.astype(np.uint8)` (compute_metric, eval_grefcoco.py:116):
+//   truncated toward zero first, so fractional values in (-1, 1) are NOT set (`!= 0.f` counted them); non-finite values are not set.
+//   Ties / NaN in the fall-back: the FIRST maximal score wins (strict `>` walk from index 0; torch.topk does not promise an order among equal
+//   scores); a NaN score never compares greater, so all-NaN scores select candidate 0.
 __global__ void __launch_bounds__(256) fuse_masks_kernel(const void* __restrict__ masks, int is_u8, const float* __restrict__ scores, int n, long HW,
                                                          float thr, unsigned char* __restrict__ out) {
     __shared__ int sel[1024];
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(256) fuse_masks_kernel(const void* __restrict_
         unsigned v = 0;
         for (int k = 0; k < nsel; ++k) {
             const long idx = (long)sel[k] * HW + p;
-            v |= is_u8 ? (unsigned)(reinterpret_cast<const unsigned char*>(masks)[idx] != 0) : (unsigned)(reinterpret_cast<const float*>(masks)[idx] != 0.f);
+            v |= is_u8 ? (unsigned)(reinterpret_cast<const unsigned char*>(masks)[idx] != 0) : (unsigned)(((int)reinterpret_cast<const float*>(masks)[idx] & 0xff) != 0 && fabsf(reinterpret_cast<const float*>(masks)[idx]) < 3.0e38f);
         }
         out[p] = (unsigned char)v;
     }

@@ -242,6 +242,19 @@ class Ops:
         if rc != 0:
             raise PsalmHipError(f"{name} failed (rc={rc}): {self.lib.psalm_last_error().decode()}")
 
+    def _stage_ws(self, name, nbytes):
+        """Workspace of a stage-level call: ONE buffer per (stage, launch stream), grown on demand and kept for the life of the binding (a
+        fresh hundreds-of-MB torch.empty per call left the buffer's lifetime to the caching allocator's stream-ordered reuse and churned the allocator
+        in eager mode).  A stage's successive calls on one stream are stream-ordered, so they may share it; calls on different streams get their own.
+        While a hipGraph is being captured the buffer must belong to the capture's own pool: a fresh allocation then, as before."""
+        if self.is_emu or torch.cuda.is_current_stream_capturing():
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        key = ("stage_ws", name, torch.cuda.current_stream().cuda_stream)
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return t
+
     GEMM_WS_BYTES = 96 << 20
 
     def _gemm_ws(self):
@@ -518,7 +531,7 @@ class Ops:
         nbytes = self.lib.psalm_swin_forward_workspace(ctypes.byref(desc), B, H, W)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_swin_forward_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("swin", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         outs, hc, wc = [], (H + desc.patch - 1) // desc.patch, (W + desc.patch - 1) // desc.patch
         for C in desc._dims:
@@ -549,7 +562,7 @@ class Ops:
         nbytes = self.lib.psalm_projector_forward_workspace(ctypes.byref(desc), B, h, w_)
         if nbytes < 0:
             raise PsalmHipError("psalm_projector_forward_workspace: bad descriptor / geometry")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("projector", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         ho, wo = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         out = self.empty(B * ho * wo, desc.out_dim, dtype=torch.float32)
@@ -592,7 +605,7 @@ class Ops:
         nbytes = self.lib.psalm_pixel_decoder_forward_workspace(ctypes.byref(desc), hw)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_pixel_decoder_forward_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("pixel_decoder", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         for t, _, _ in feats:
             if t.dtype != torch.float32 or not t.is_contiguous():
@@ -651,7 +664,7 @@ class Ops:
         nbytes = self.lib.psalm_predictor_forward_workspace(ctypes.byref(desc), hw, H2, W2, n_reg)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_predictor_forward_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("predictor", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         masks = self.empty(Q, H2 * W2, dtype=torch.float32)
         cls = self.empty(Q, class_emb.shape[0], dtype=torch.float32) if class_emb is not None else None
@@ -685,7 +698,7 @@ class Ops:
         nbytes = self.lib.psalm_postprocess_workspace(ctypes.byref(d), 1 if mask_up is not None else 0)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_postprocess_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("postprocess", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         resize_after = (oh, ow, height, width) != (Hpad, Wpad, Hpad, Wpad)
         out = {}
@@ -731,7 +744,7 @@ class Ops:
         nbytes = self.lib.psalm_phi_forward_workspace(ctypes.byref(desc), B, L)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_phi_forward_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        ws = self._stage_ws("phi", nbytes + 256)
         off = (-ws.data_ptr()) % 256
         out = self.empty(B * L, desc.hidden, dtype=torch.float32)
         rc = self.lib.psalm_phi_forward(ctypes.byref(desc), self._p(embeds), self._p(key_mask), self._p(cos), self._p(sin), B, L, self._p(out),

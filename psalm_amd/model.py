@@ -1272,6 +1272,15 @@ class PSALM:
         c0 = r0 = 0
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                # the pixel decoder's outputs were allocated on the side stream and are read by the predictor on this one: tell the caching
+                # allocator.  (Their blocks could only be re-issued to the NEXT image's side-stream work, which starts behind
+                # `side.wait_stream(main)` -- ordered already; this makes it hold without that argument.)
+                for po in pd_out:
+                    if po is not None:
+                        for t in [po[0]] + list(po[1]):
+                            if torch.is_tensor(t):
+                                t.record_stream(torch.cuda.current_stream())
         for b in range(B):
             if pd_out[b] is None:
                 pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])

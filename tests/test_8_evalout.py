@@ -213,3 +213,19 @@ def test_device_grefcoco_fusion_matches_reference_golden(ops, dtype):
     assert np.allclose(meters.sum[4:6].numpy(), G["meters/acc_iou_sum"], rtol=0, atol=1e-12) and int(meters.sum[6]) == int(G["meters/count"])
     with pytest.raises(Exception):
         E.fuse_masks_by_score(torch.zeros(2, 4, 4), torch.zeros(3), ops=ops)
+
+
+def test_device_fusion_truncates_float_masks_like_astype_uint8(ops):
+    """compute_metric casts the candidate masks with `preds.astype(np.uint8)` before fusing (eval_grefcoco.py:116): a float element counts as set
+    after truncation toward zero -- 0.5 and -0.9 do not, 1.7 and -1.0 (-> 255) do; the fall-back without a confident candidate takes the FIRST
+    maximal score."""
+    vals = torch.tensor([0.0, 0.5, 0.999, 1.0, 1.7, -0.9, -1.0, 2.0])
+    masks = torch.zeros(3, 2, 4)
+    masks[0] = vals.view(2, 4)
+    scores = torch.tensor([0.9, 0.1, 0.1])
+    fused = E.fuse_masks_by_score(masks.to(ops.device), scores.to(ops.device), 0.6, ops=ops).cpu().numpy().reshape(-1)
+    want = (vals.numpy().astype(np.int64).astype(np.uint8) != 0).astype(np.uint8)
+    assert np.array_equal(fused, want) and want.tolist() == [0, 0, 0, 1, 1, 0, 1, 1]
+    masks[1, 0, 0], masks[2, 0, 1] = 1.0, 1.0
+    tie = E.fuse_masks_by_score(masks.to(ops.device), torch.tensor([0.2, 0.5, 0.5]).to(ops.device), 0.6, ops=ops).cpu().numpy().reshape(-1)
+    assert tie[0] == 1 and tie[1] == 0                                   # candidate 1 (the first of the two maximal scores), not candidate 2

@@ -535,6 +535,30 @@ def test_config3_referring_640_input_that_moved_the_r03_fast_form():
         assert float(iou.mean()) >= 0.999 and rel < 1e-4, (b, float(iou.mean()), rel)
 
 
+def test_config3_referring_640_seed11_image_on_the_knife_edge_list():
+    """The referring input r04 / r05's wide runs left outside the flip margin in BOTH GPU arithmetics by the same 214 pixels (640x640 batch 4, inputs
+    seed 11, image 1; 7.578e-3 of the logit range).  r06 (tools/exp_referring_controls.py, profiles/r06_referring_controls_seeds_10_11.jsonl): the
+    fp32 CPU oracle tips AGAINST ITSELF on that image, to those same pixels, when it merely runs on ONE host thread (another BLAS summation order) or
+    with its attention in float64 -- the reference's fp32 result is within rounding of a decision of the thresholded attention-mask feedback
+    (TD:754-760) there.  It is on the committed knife-edge list with the one-thread control's flipped set as fixture
+    (tests/golden/make_referring_seed11_control.py): the product must land on the oracle-as-run's side (flip-margin property) or within 16 pixels of
+    the control's side -- which of the two the oracle itself takes depends on the host's thread count -- and nowhere else; images 0, 2, 3 of the
+    batch must meet the plain property."""
+    from oracle import parity_gate as PG
+    cfg, sd = _full_model("referring")
+    inputs = make_inputs(cfg, "referring", size=640, batch=4, seed=11)
+    want = O.eval_seg(sd, cfg, **inputs)
+    got = _full_psalm("referring", "f16x3").eval_seg(**inputs)
+    torch.cuda.synchronize()
+    for b in range(4):
+        entry = PG.knife_edge_entry("referring", 640, 11, 0, batch=4, image=b)
+        assert (entry is not None) == (b == 1)
+        p = PG.parity_of(got[b], want[b])
+        ok, side = PG.judge(p, got[b], want[b], entry)
+        _report(test="config3_referring_640_seed11_knife_edge", image=b, oracle_threads=torch.get_num_threads(), **p)
+        assert ok and side in (("oracle", "one_thread_control") if b == 1 else ("oracle",)), (b, p)
+
+
 def test_config5_region_1024_batch2():
     """BASELINE.json configs[4]: interactive (point-prompt discs) 1024x1024 batch 2 with 1 and 3 <region> prompts.  f16x3 at the north-star
     bar vs the oracle.  (The configuration's "fp8 MFMA LLM path": no fp8 form meets the parity bar on this network -- whole-operand e4m3 and

@@ -9,6 +9,10 @@ image 2 and seed 11 image 1 -- under CONTROLS of the oracle itself (VERDICT r05 
     ln64       every LayerNorm in float64, rounded once
     attn64     the three attention forms (Swin windows, Phi causal, mask-decoder multi-head): scores, softmax and value products in float64
     full64     all64 + ln64 + attn64: the float64 control of the whole transformer arithmetic
+    threadsN   N host threads (N = 2, 4, ...)
+    conv64 / gn64 / interp64   F.conv2d / F.group_norm / F.interpolate (the thresholded attention-mask resize of TD:754-760 among them) in float64
+    msda_grid  the oracle's second restatement of the deformable-attention gather (F.grid_sample per level instead of explicit corner taps)
+    every64    full64 + conv64 + gn64 + interp64
 -> one JSON line per (seed, image, variant): flipped pixels, the oracle's |logit| at the flips relative to the logit range (oracle/parity_gate.py's
 margin property), mask IoU.  An input that tips under these controls is one on which the REFERENCE's fp32 result is itself within rounding of a
 decision of the thresholded attention-mask feedback (mask2former_transformer_decoder.py:754-760); one that does not tip under any of them while the
@@ -73,17 +77,38 @@ def main():
         m2[:, :L] = am
         return real_phi(sd_, cfg_, e2, m2, prefix)[:, :L]
 
+    real_F = O.F
+
+    class FProxy:
+        """torch.nn.functional with some entries evaluated in float64 (the oracle reaches them as `F.<name>`)"""
+        def __init__(self, names):
+            self._names = set(names)
+
+        def __getattr__(self, name):
+            fn = getattr(real_F, name)
+            if name not in self._names:
+                return fn
+
+            def f64(x, *a, **k):
+                a = [t.double() if torch.is_tensor(t) and t.is_floating_point() else t for t in a]
+                k = {kk: (t.double() if torch.is_tensor(t) and t.is_floating_point() else t) for kk, t in k.items()}
+                return fn(x.double(), *a, **k).float()
+            return f64
+
     def setup(var):
-        O._lin, O._ln, O.phi_forward, O.ATTN_FLOAT64 = real_lin, real_ln, real_phi, False
-        torch.set_num_threads(1 if var == "threads1" else nthr)
-        if var in ("all64", "full64"):
+        O._lin, O._ln, O.phi_forward, O.ATTN_FLOAT64, O.F = real_lin, real_ln, real_phi, False, real_F
+        torch.set_num_threads(int(var[7:]) if var.startswith("threads") else nthr)
+        if var in ("all64", "full64", "every64"):
             O._lin = lin64
-        if var in ("ln64", "full64"):
+        if var in ("ln64", "full64", "every64"):
             O._ln = ln64
-        if var in ("attn64", "full64"):
+        if var in ("attn64", "full64", "every64"):
             O.ATTN_FLOAT64 = True
         if var == "padL":
             O.phi_forward = phi_pad
+        f64names = {"conv64": ["conv2d"], "gn64": ["group_norm"], "interp64": ["interpolate"], "every64": ["conv2d", "group_norm", "interpolate"]}.get(var)
+        if f64names:
+            O.F = FProxy(f64names)
 
     for seed in seeds:
         inputs = make_inputs(cfg, task, size=size, batch=batch, seed=seed)
@@ -97,7 +122,7 @@ def main():
             try:
                 torch.manual_seed(1234)
                 t1 = time.perf_counter()
-                got = O.eval_seg(sd, cfg, **inputs)
+                got = O.eval_seg(sd, cfg, **inputs, **({"msda_fn": (lambda v_, sh_, st_, loc_, w_: O.msda_core_grid_sample(v_, sh_, loc_, w_))} if var == "msda_grid" else {}))
                 vsecs = time.perf_counter() - t1
             finally:
                 setup("none")
