@@ -1793,21 +1793,23 @@ __global__ void __launch_bounds__(64 * NWV) gemm_f32_skinny_pair_kernel(GemmArgs
     gemm_f32_skinny_body<TC, NWV>(g, part, blockIdx.x, blockIdx.y);
 }
 
+// (r06: the process-wide tuning words below are atomics -- a test or `--gemm-policy` flipping one while another host thread (PSALM.replica) launches
+//  gives that thread's next launch the old or the new value, never a torn one)
 // Tuning / test knob: 0 = automatic tile selection (default), 256 / 128 / 64 = force that BM for the direct-to-LDS path
 // (A/B measurements in tools/bench_gemm.py, and the CPU tests reach the 256^2 configuration at small sizes with it).
-static int g_tile_policy = 0;
+static std::atomic<int> g_tile_policy{0};
 static thread_local char g_last_kernel[192] = "";    // template instantiation of the calling thread's last direct-to-LDS launch
 extern "C" const char* psalm_gemm_last_kernel() { return g_last_kernel; }
-static long g_skinny_nmax = 4096;    // skinny kernel for M <= 128 and N <= this
-static int g_ring_depth = 2;      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
+static std::atomic<long> g_skinny_nmax{4096};    // skinny kernel for M <= 128 and N <= this
+static std::atomic<int> g_ring_depth{2};      // operand-ring depth of the 128x128 configuration (2 or 3), see psalm_gemm_set_tile_policy
 // operand-ring depth of the 64x128 configuration: 0 = automatic (3 when the K range of a block is >= 1024: with <= 1 block per CU the
 // 2-deep loop is one exposed copy round trip per K step -- r01 A/B: Swin fc2 M4096 N512 K2048 25.4 -> 22.7 us; short-K problems lose
 // to the longer prologue), 2 / 3 / 4 = forced (policy codes 642 / 643 / 644; 640 = automatic)
-static int g_ring64 = 0;
+static std::atomic<int> g_ring64{0};
 // 256x256 plain-GEMM tiles run the 4-phases-per-K-tile (PH8) K loop, variant 3 (r01 A/B on MI355X, tools/bench_gemm.py --ph8: Phi w1
 // 74.9 -> 69.4 us, 4096^3 1007 -> 1091 TF/s, 8192^3 1053 -> 1191; bitwise equal to the 2-buffer loop on 360 / 360 repetitions);
 // 0 = the plain 2-buffer loop, 1 / 2 = the other copy placements (psalm_gemm_set_tile_policy 2560 / 2568..2570)
-static int g_ph8 = 3;
+static std::atomic<int> g_ph8{3};
 // split-f16 GEMMs on the 128x128 / 64x128 tiles, K loop form (psalm_gemm_set_tile_policy 3300 + v):
 //   v = 0  automatic (below)                    1  "slice" K loop: 4 operand images per 64-deep slice, 3 products per barrier
 //   2  32-deep slices in a 4-deep ring          3 / 4  32-deep slices in a 2- / 3-deep ring       5  the K-panel form (3 Kp-long loop)
@@ -1817,7 +1819,7 @@ static int g_ph8 = 3;
 // r03 sweep (profiles/r03h_gemm_x3_sweep_slice32.json): form 3 keeps the K-panel form's LDS footprint (64 KB on 128^2: two blocks per CU)
 // with 1.5x the matrix work per copy round trip and 2/3 of the copies: 3-17 % faster on 17 of 21 shapes of the image (M5184 N512 K512
 // 22.0 -> 18.3 us, M21504 N256 K1024 60.3 -> 52.6, M65536 N128 K512 43.4 -> 38.1), equal within noise on the rest: the automatic choice.
-static int g_x3_slice = 0;
+static std::atomic<int> g_x3_slice{0};
 // split-f16 GEMMs on the 256 x 256 tile: 1 = the phased K loop walks 32-deep SLICES (four operand images per stage, three products per
 // phase: 2/3 of the L2 -> LDS bytes, fragment reads and barriers of the K-panel form, W hi fetched once), 0 = the K-panel form (3 Kp-long
 // loop over 64-deep tiles).  psalm_gemm_set_tile_policy(2580 / 2581).  r04a on MI355X (profiles/r04a_gemm_x3_sweep.json, back to back): Phi
@@ -1826,7 +1828,7 @@ static int g_x3_slice = 0;
 // and fragment reads of all-padding m-tiles left out (<.., 32, 4, 2, ..>): the launch is clock-limited (1.76 GHz, r04j SQ counters), the
 // left-out work is power.  r04p on MI355X (profiles/r04p_skip_pad.json, back to back, identical output words): M899 N14336 K2048 150.3 ->
 // 141.1 us, M899 N2048 K10240 123.3 -> 117.4, M1024 N14336 K2048 (nothing to leave out) 150.3 -> 149.9: the default.
-static int g_ph8_slice = 2;
+static std::atomic<int> g_ph8_slice{2};
 // Products per algorithmic product of the split-f16 GEMMs launched by THIS host thread: 3 (default) = hi.hi + lo.hi + hi.lo -- the fp32-class
 // arithmetic of precision "f16x3"; 1 = hi.hi only -- plain f16 operands (11-bit mantissas under the same per-row power-of-two scales), one
 // third of the matrix work.  The reduced-precision LLM side mode of BASELINE.json configs[4] (PSALM(llm_products=1)): NOT at the parity
@@ -1949,7 +1951,7 @@ extern "C" int psalm_gemm_describe(int M, int N, int K, int a_dtype, int w_dtype
             const int kps_ = splits > 1 ? cdiv(cdiv(kp, 64), splits) * 64 : kp, sp_ = cdiv(kp, kps_);
             slice = kps_ >= 64 && kp - (sp_ - 1) * kps_ >= 64;
         }
-        if (slice && g_x3_products == 3 && splits > 1) {
+        if ((slice || g_x3_products == 1) && splits > 1) {        // slice forms AND the one-product mode walk Kp, not 3 Kp (launch_fast's `p1`)
             const int kps = cdiv(cdiv(kp, 64), splits) * 64;
             splits = cdiv(kp, kps);
         }
@@ -1991,7 +1993,8 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     select_fast_config(M, N, K, workspace != nullptr, workspace_bytes, BM, BN, splits, x3);
     if (fa.so) splits = 1;                                        // split-f16 output is written by the GEMM epilogue itself: no split-K
     int kps = splits > 1 ? cdiv(cdiv(K, 64), splits) * 64 : K;
-    int slice = !x3 || BM == 256 ? 0 : (g_x3_slice == 5 ? 0 : g_x3_slice ? g_x3_slice : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
+    const int x3s = g_x3_slice.load();
+    int slice = !x3 || BM == 256 ? 0 : (x3s == 5 ? 0 : x3s ? x3s : (g_x3_auto_slice && BM == 64 && !fa.so ? 1 : 3));
     // r05 ring depths (one block per CU by LDS: for grids that put <= 1 block on a CU anyway, the stages that a second block would have used
     // buy prefetch distance instead): 7 = 64 x 128, 64-deep slices, 3 stages (144 KB);  8 = 128 x 128, 32-deep slices, 3 stages (96 KB)
     if (slice == 7 && BM != 64) slice = 3;
@@ -2112,7 +2115,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
         else GO(256, "float", float, 64, 128, 2, 2, 2, false, 64, 0, 2, false);
     } else if (x3) {                                              // split-f16 variant: fp32 output (or fp32 split-K slabs) only
         const bool ph = BM == 256 && g_ph8 && fa.k_per_split >= 128 && (g.K - (splits - 1) * fa.k_per_split) >= 128;
-        const int ring64 = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
+        const int r64 = g_ring64.load(), ring64 = r64 ? r64 : (fa.k_per_split >= 1024 ? 3 : 2);
 #define GO_X3(NT_, ...) do { if (fa.so) GO(NT_, "float", float, __VA_ARGS__, true); else GO(NT_, "float", float, __VA_ARGS__, false); } while (0)
         if (ph && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 64, 3, 1, true, true);
         else if (fa.so && fa.so_paired && BM == 128) GO(256, "float", float, 128, 128, 2, 2, 2, false, 64, 0, 1, true, true);
@@ -2145,7 +2148,7 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
             else GO_T(256, 128, 128, 2, 2, 2, false, 64, 0, 0, false);
         }
         else {
-            const int ring = g_ring64 ? g_ring64 : (fa.k_per_split >= 1024 ? 3 : 2);
+            const int r64 = g_ring64.load(), ring = r64 ? r64 : (fa.k_per_split >= 1024 ? 3 : 2);
             if (ring == 4) GO_T(256, 64, 128, 2, 2, 4, false, 64, 0, 0, false);
             else if (ring == 3) GO_T(256, 64, 128, 2, 2, 3, false, 64, 0, 0, false);
             else GO_T(256, 64, 128, 2, 2, 2, false, 64, 0, 0, false);

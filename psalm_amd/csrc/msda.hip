@@ -21,6 +21,7 @@
 //     sampling locations in-kernel (ops/modules/ms_deform_attn.py:101-110), so the (B,Lq,M,L,P,2)
 //     location and (B,Lq,M,L,P) weight tensors are never materialised in HBM.
 #include "common.h"
+#include <atomic>
 
 struct alignas(16) f32x4_s { float x, y, z, w; };
 struct alignas(8) bf16x4_s { bf16_t x, y, z, w; };
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const TV* __restrict__ 
 }
 
 // A/B knob of the r04 measurement pass (tools/bench_msda.py): 1 = quad-shared taps (default), 0 = every lane computes all samples (r01 - r03)
-static int g_msda_quad = 1;
+static std::atomic<int> g_msda_quad{1};
 extern "C" int psalm_msda_set_policy(int v) {
     if (v != 0 && v != 1) { psalm_set_error("psalm_msda_set_policy: 0 / 1 (quad-shared taps off / on)"); return -1; }
     g_msda_quad = v;

@@ -535,28 +535,31 @@ def test_config3_referring_640_input_that_moved_the_r03_fast_form():
         assert float(iou.mean()) >= 0.999 and rel < 1e-4, (b, float(iou.mean()), rel)
 
 
-def test_config3_referring_640_seed11_image_on_the_knife_edge_list():
-    """The referring input r04 / r05's wide runs left outside the flip margin in BOTH GPU arithmetics by the same 214 pixels (640x640 batch 4, inputs
-    seed 11, image 1; 7.578e-3 of the logit range).  r06 (tools/exp_referring_controls.py, profiles/r06_referring_controls_seeds_10_11.jsonl): the
-    fp32 CPU oracle tips AGAINST ITSELF on that image, to those same pixels, when it merely runs on ONE host thread (another BLAS summation order) or
-    with its attention in float64 -- the reference's fp32 result is within rounding of a decision of the thresholded attention-mask feedback
-    (TD:754-760) there.  It is on the committed knife-edge list with the one-thread control's flipped set as fixture
-    (tests/golden/make_referring_seed11_control.py): the product must land on the oracle-as-run's side (flip-margin property) or within 16 pixels of
-    the control's side -- which of the two the oracle itself takes depends on the host's thread count -- and nowhere else; images 0, 2, 3 of the
-    batch must meet the plain property."""
+@pytest.mark.parametrize("seed,image,sides", [(11, 1, ("oracle", "one_thread_control")), (10, 2, ("oracle", "float64_groupnorm_control"))])
+def test_config3_referring_640_images_on_the_knife_edge_list(seed, image, sides):
+    """The two referring inputs r04 / r05's wide runs left outside the flip margin (640x640 batch 4; seed 11 image 1: 214 pixels / 7.6e-3 in BOTH GPU
+    arithmetics; seed 10 image 2: 58 pixels / 2.2e-3).  r06 closed them with controls of the CPU oracle itself (tools/exp_referring_controls.py,
+    profiles/r06_referring_controls_seeds_10_11.jsonl): the fp32 oracle tips AGAINST ITSELF to the product's pixels when it merely runs on ONE host
+    thread or with float64 attention (seed 11), resp. with its GroupNorms in float64 (seed 10) -- evaluations at least as exact as the reference's --
+    and returns to its fp32 side with ALL arithmetic in float64; for seed 10 the oracle's own predictor, fed the product's stage outputs, returns the
+    product's result (profiles/r06_referring_seed10_stage_bisect.jsonl).  The reference's fp32 result is within rounding of a decision of the
+    thresholded attention-mask feedback (TD:754-760) on these images: they are on the committed knife-edge list with their control's flipped set
+    as fixture (tests/golden/make_referring_seed1{0,1}_control.py).  The product must land on the oracle-as-run's side (flip-margin property) or
+    within 16 pixels of the control's side -- which of the two the oracle itself takes depends on the host (thread count, BLAS) -- and nowhere else;
+    the other three images of the batch must meet the plain property."""
     from oracle import parity_gate as PG
     cfg, sd = _full_model("referring")
-    inputs = make_inputs(cfg, "referring", size=640, batch=4, seed=11)
+    inputs = make_inputs(cfg, "referring", size=640, batch=4, seed=seed)
     want = O.eval_seg(sd, cfg, **inputs)
     got = _full_psalm("referring", "f16x3").eval_seg(**inputs)
     torch.cuda.synchronize()
     for b in range(4):
-        entry = PG.knife_edge_entry("referring", 640, 11, 0, batch=4, image=b)
-        assert (entry is not None) == (b == 1)
+        entry = PG.knife_edge_entry("referring", 640, seed, 0, batch=4, image=b)
+        assert (entry is not None) == (b == image)
         p = PG.parity_of(got[b], want[b])
         ok, side = PG.judge(p, got[b], want[b], entry)
-        _report(test="config3_referring_640_seed11_knife_edge", image=b, oracle_threads=torch.get_num_threads(), **p)
-        assert ok and side in (("oracle", "one_thread_control") if b == 1 else ("oracle",)), (b, p)
+        _report(test="config3_referring_640_knife_edge", seed=seed, image=b, oracle_threads=torch.get_num_threads(), **p)
+        assert ok and side in (sides if b == image else ("oracle",)), (b, p)
 
 
 def test_config5_region_1024_batch2():

@@ -13,6 +13,9 @@ image 2 and seed 11 image 1 -- under CONTROLS of the oracle itself (VERDICT r05 
     conv64 / gn64 / interp64   F.conv2d / F.group_norm / F.interpolate (the thresholded attention-mask resize of TD:754-760 among them) in float64
     msda_grid  the oracle's second restatement of the deformable-attention gather (F.grid_sample per level instead of explicit corner taps)
     every64    full64 + conv64 + gn64 + interp64
+    splitkN    Phi's residual projections  dense(attn) + fc2(gelu(fc1))  formed as the product forms them: ONE product over the concatenated K range
+               (2048 + 8192) summed in N slices of ceil(K / 64 / N) * 64 columns, fp32 -- the split-K order of the fused [dense | fc2] GEMM (N = 8 at
+               these sizes), another fp32 summation order of the same numbers
 -> one JSON line per (seed, image, variant): flipped pixels, the oracle's |logit| at the flips relative to the logit range (oracle/parity_gate.py's
 margin property), mask IoU.  An input that tips under these controls is one on which the REFERENCE's fp32 result is itself within rounding of a
 decision of the thresholded attention-mask feedback (mask2former_transformer_decoder.py:754-760); one that does not tip under any of them while the
@@ -95,8 +98,31 @@ def main():
                 return fn(x.double(), *a, **k).float()
             return f64
 
+    def lin_splitk(nsl):
+        stash = {}
+
+        def lin(sd_, name, x, bias=True):
+            if name.startswith("model.layers.") and name.endswith("self_attn.dense"):
+                stash["a"] = (name, x)
+                return torch.zeros(x.shape[:-1] + (sd_[name + ".weight"].shape[0],))
+            if name.startswith("model.layers.") and name.endswith("mlp.fc2"):
+                na, xa = stash.pop("a")
+                X = torch.cat([xa, x], -1)
+                W = torch.cat([sd_[na + ".weight"], sd_[name + ".weight"]], 1)
+                K = X.shape[-1]
+                ks = -(-(-(-K // 64)) // nsl) * 64
+                out = None
+                for k0 in range(0, K, ks):
+                    part = X[..., k0:k0 + ks] @ W[:, k0:k0 + ks].t()
+                    out = part if out is None else out + part
+                return out + (sd_[na + ".bias"] + sd_[name + ".bias"])
+            return real_lin(sd_, name, x, bias)
+        return lin
+
     def setup(var):
         O._lin, O._ln, O.phi_forward, O.ATTN_FLOAT64, O.F = real_lin, real_ln, real_phi, False, real_F
+        if var.startswith("splitk"):
+            O._lin = lin_splitk(int(var[6:]))
         torch.set_num_threads(int(var[7:]) if var.startswith("threads") else nthr)
         if var in ("all64", "full64", "every64"):
             O._lin = lin64

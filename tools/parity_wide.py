@@ -80,6 +80,9 @@ def oracle_worker(wid, threads, jobs, results, wseed, done):
         results.put((job, slim, secs))
 
 
+from oracle import parity_gate as PG  # noqa: E402
+
+
 @torch.no_grad()
 def compare_dev(g, w_):
     """GPU result dict vs slim oracle dict, computed on the device"""
@@ -195,6 +198,18 @@ def main():
                     r = {"task": task, "size": size, "batch": batch, "weights_seed": args.weights_seed, "inputs_seed": s, "image": b, "mode": m,
                          **compare_dev(got[b], want[b]), "oracle_seconds": round(secs, 1), "oracle_threads": threads}
                     r["gates"] = gates(r)
+                    # r06: images on the committed knife-edge list (oracle/parity_gate.py; per-image entries): outside the margin they pass within 16
+                    # pixels of their control's flipped set, as in bench.py / tests/test_9_e2e_gpu.py
+                    entry = PG.knife_edge_entry(task, size, s, args.weights_seed, batch=batch, image=b)
+                    if entry is not None:
+                        r["on_knife_edge_list"] = True
+                        if not r["gates"]["v4"]:
+                            import numpy as np
+                            ctl = {tuple(int(v) for v in q) for q in np.load(os.path.join(ROOT, entry["control"]))["flipped_qyx"].tolist()}
+                            mine = {tuple(int(v) for v in q) for q in torch.nonzero((got[b]["mask_pred"] > 0).cpu() != (want[b]["mask_pred"] > 0)).tolist()}
+                            r["knife_edge_symmetric_difference_vs_control"] = len(mine ^ ctl)
+                            r["gates"]["v4_with_knife_edge_list"] = len(mine ^ ctl) <= PG.KNIFE_EDGE_PIXELS
+                            r["side"] = entry.get("control_side", "float64_control") if r["gates"]["v4_with_knife_edge_list"] else None
                     rows.append(r)
                     f.write(json.dumps(r) + "\n")
                     f.flush()
@@ -212,6 +227,7 @@ def main():
                     "flips_within_margin": sum(r["gates"]["flips_within_margin"] for r in rs), "at_gate_v4": sum(r["gates"]["v4"] for r in rs),
                     "flip_margin_rel_max_over_inputs_within_margin": max((r["flip_margin_rel_max"] for r in rs if r["gates"]["flips_within_margin"]), default=0.0),
                     "inputs_outside_margin": [[r["inputs_seed"], r["image"], r["flip_margin_rel_max"], r["mask_logit_rel_err"], r["flipped_pixels"]] for r in rs if not r["gates"]["flips_within_margin"]],
+                    "inputs_outside_margin_and_not_within_16_pixels_of_a_listed_control": [[r["inputs_seed"], r["image"]] for r in rs if not r["gates"]["flips_within_margin"] and not r["gates"].get("v4_with_knife_edge_list", False)],
                     "mask_iou_mean_min": min(r["mask_iou_mean"] for r in rs), "mask_iou_pooled_min": min(r["mask_iou_pooled"] for r in rs),
                     "mask_iou_mean_area_ge_64_min": min((r["mask_iou_mean_area_ge_64"] for r in rs if r["mask_iou_mean_area_ge_64"] is not None), default=None),
                     "mask_logit_rel_err_max": max(r["mask_logit_rel_err"] for r in rs), "flipped_pixels_max": max(r["flipped_pixels"] for r in rs),
