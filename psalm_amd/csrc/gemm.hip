@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
     constexpr int NLW = PH8_ == 6 ? 2 : (PH8_ == 7 ? 4 : 0);     // loader wavefronts
     constexpr bool LW = NLW > 0;
     static_assert(PH8_ >= 0 && PH8_ <= 7 && PH8_ != 5, "PH8_: 0 generic loop, 1 - 4 phased 256 x 256 loops, 6 / 7 loader waves");
-    static_assert(!LW || (X3 == 2 && NS == 3 && BK == 32 && !CONV), "LW: slice form on 32-deep slices, three stages");
+    static_assert(!LW || (X3 == 2 && (NS == 3 || NS == 2) && BK == 32 && !CONV), "LW: slice form on 32-deep slices, three (or two) stages");
     static_assert(!PAIR || SO, "paired stores: a form of the split-f16 output");
     static_assert(!SO || X3 == 1 || (X3 == 2 && BK == 32 && (NS == 2 || LW)), "split-f16 output: K-panel form, or 32-deep slices in two stages (three with loader waves)");
     static_assert(X3 >= 0 && X3 <= 2, "X3: 0 bf16 operands, 1 split-f16 K-panel form, 2 split-f16 slice form");
@@ -574,20 +574,26 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
         // ---- loader / matrix wavefronts (see the kernel comment).  Stage t % 3 holds slice t.  Barrier B(t), reached by every wave once per
         // slice:  loaders arrive when slice t has LANDED (counted vmcnt: slice t + 1 may still be in flight), matrix waves when they are done
         // READING slice t - 1 (lgkmcnt(0)).  After B(t) the loaders refill stage (t + 2) % 3 = (t - 1) % 3 -- whose last reads retired before B(t)
-        // -- with slice t + 2 while the matrix waves multiply slice t.
+        // -- with slice t + 2 while the matrix waves multiply slice t.  (Two stages, the 256 x 256 block: the refill after B(t) is slice t + 1 into the
+        // stage slice t - 1 was read from, and the loaders wait for ALL of it before B(t + 1).)
         if (wave >= NW) {
-            issue(0, 0);
-            if (nk > 1) issue(1, BK);
+#pragma unroll
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nk) issue(p, p * BK);
             PSALM_TL(1);
 #pragma unroll 1
             for (int kt = 0; kt < nk; ++kt) {
-                if (kt + 1 < nk) wait_vmcnt_le<LPT>(); else wait_vmcnt_le<0>();
+                if (NS == 3 && kt + 1 < nk) wait_vmcnt_le<LPT>(); else wait_vmcnt_le<0>();     // (two stages: nothing else is in flight)
                 __builtin_amdgcn_s_barrier();
-                if (kt + 2 < nk && !(PSALM_ABL() & 1)) issue((kt + 2) % 3, (kt + 2) * BK);
+                if (kt + NS - 1 < nk && !(PSALM_ABL() & 1)) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
             }
             return;                                              // (every copy has landed: the last wait was vmcnt(0))
         }
+        // a matrix wave whose rows all lie in the padding below row M (Phi's M = 899 on 256-row tiles) keeps the barriers and leaves out its reads and
+        // products: those rows are never stored (the phased kernel's PH8 = 4 idea, per wave here)
+        const bool idle = __builtin_amdgcn_readfirstlane((int)(bm + wm * (BM / WM) >= g.M)) != 0;
         const bf16_t* As = smem[0];
+        int stg = 0;
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
             PSALM_RAW_BARRIER();
@@ -595,30 +601,48 @@ __global__ void __launch_bounds__(64 * (WM * WN + (PH8_ == 6 ? 2 : (PH8_ == 7 ? 
             const bf16_t* Bs = As + BM * BK;
             const bf16_t* Al = As + (BM + BN) * BK;
             const bf16_t* Bl = Al + BM * BK;
+            if (!idle) {
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
                 const int co = ((2 * kk + hi) ^ fsw) * 8;
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+                bf16x8 ah[TM], al[TM];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&As[(a_row0 + 32 * i) * BK + co]));
                     al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Al[(a_row0 + 32 * i) * BK + co]));
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
-                    bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bl[(b_row0 + 32 * j) * BK + co]));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                if constexpr (TN <= 2) {
+                    bf16x8 bh[TN], bl[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
-                        acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
-                        acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
+                        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+                        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bl[(b_row0 + 32 * j) * BK + co]));
                     }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = mma16(ah[i], bh[j], acc[i][j]);
+                            acc[i][j] = mma16(al[i], bh[j], acc[i][j]);
+                            acc[i][j] = mma16(ah[i], bl[j], acc[i][j]);
+                        }
+                } else {                                         // wide wave tiles: the W fragments of one n-tile at a time (register budget of three waves per SIMD)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bs[(b_row0 + 32 * j) * BK + co]));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_s*>(&Bl[(b_row0 + 32 * j) * BK + co]));
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            acc[i][j] = mma16(ah[i], bh, acc[i][j]);
+                            acc[i][j] = mma16(al[i], bh, acc[i][j]);
+                            acc[i][j] = mma16(ah[i], bl, acc[i][j]);
+                        }
+                    }
+                }
             }
-            As = (kt % 3 == 2) ? smem[0] : As + (BM + BN) * BK * XS;      // next stage
+            }
+            stg = stg + 1 == NS ? 0 : stg + 1;
+            As = smem[stg];                                      // next stage
         }
     } else if constexpr (PHS) {
         // ---- PH8 schedule on 32-deep SLICES of the split-f16 operands (r04).  A stage holds the FOUR images of one slice of the true K range
@@ -2081,6 +2105,9 @@ static int launch_fast(GemmArgs g, GemmFastArgs fa, bool conv, int c_dtype, void
     if (slice) {                                                  // split-f16 slice form (see the kernel comment): K loop over the true K range
         // 3 / 4: 32-deep slices in a 2- / 3-deep ring -- the stage of the K-panel form (64 KB on 128^2: two blocks per CU stay resident)
         // with 1.5x the matrix work per copy round trip
+        // (r06 experiment, measured and taken out again: the 256 x 256 tile as eight 32 x 256 matrix waves + four loader waves on two stages
+        //  -- `GO(768, "float", float, 256, 256, 8, 1, 2, false, 32, 7, 2, false)`, 168 registers + 328 bytes of scratch -- returns the phased loop's
+        //  words 25 - 50 % slower: Phi [k|v|q|fc1] 144 -> 202 us, [dense|fc2] 122 -> 185, 4096^3 321 -> 399; profiles/r06j_phi_lw256.txt)
         if (slice == 6 && g_ph8_slice == 2 && fa.so && fa.so_paired) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, true, true);
         else if (slice == 6 && g_ph8_slice == 2 && fa.so) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, true);
         else if (slice == 6 && g_ph8_slice == 2) GO(512, "float", float, 256, 256, 2, 4, 2, false, 32, 4, 2, false);
