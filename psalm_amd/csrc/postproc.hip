@@ -702,19 +702,33 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
             }
             __syncthreads();
         }
-    if (tid == 0) {
-        int nkept = 0;
-        for (int r = 0; r < kk; ++r) {
-            const int idx = TOPK_IDX_MAX - (int)(sel_key[r] & (unsigned long long)TOPK_IDX_MAX);
-            const int lab = idx % C, qq = idx / C;
-            if (!is_thing || is_thing[lab]) {
-                out_score[nkept] = sel_val[r] * (mask_score ? mask_score[qq] : 1.f);
-                out_class[nkept] = lab;
-                out_query[nkept] = qq;
-                nkept++;
-            }
+    // The reference's filter (LP:417-446) in pick order.  r06: one thread per pick -- its thing flag and mask score fetched in parallel, its output
+    // slot = the number of kept picks in front of it (128 flags in LDS) -- instead of thread 0 walking the <= 128 picks behind two dependent
+    // global loads each (most of this kernel's 73 us, profiles/r05_kernel_stats.txt).  Same triples in the same order.
+    __shared__ int keep_s[128];
+    int lab = 0, qq = 0;
+    float sc = 0.f;
+    if (tid < 128) {
+        bool keep = false;
+        if (tid < kk) {
+            const int idx = TOPK_IDX_MAX - (int)(sel_key[tid] & (unsigned long long)TOPK_IDX_MAX);
+            lab = idx % C;
+            qq = idx / C;
+            keep = !is_thing || is_thing[lab];
+            sc = sel_val[tid] * (mask_score ? mask_score[qq] : 1.f);
         }
-        count[0] = nkept;
+        keep_s[tid] = keep ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        int pos = 0;
+        for (int j = 0; j < tid; ++j) pos += keep_s[j];
+        if (keep_s[tid]) {
+            out_score[pos] = sc;
+            out_class[pos] = lab;
+            out_query[pos] = qq;
+        }
+        if (tid == 127) count[0] = pos + keep_s[127];
     }
 }
 
@@ -793,7 +807,18 @@ __global__ void __launch_bounds__(256) panoptic_argmax_vec4_kernel(const float* 
     int* kq = sm + 4 * Q;                // their query indices (ascending)
     __shared__ int nk_s;
     for (int i = threadIdx.x; i < 3 * Q; i += 256) lc[i] = 0;
-    if (threadIdx.x == 0) {              // (Q <= a few hundred: a serial scan keeps the order without a prefix sum)
+    if (Q <= 256) {                      // r06: thread q tests query q; its slot = the kept queries in front of it (flags in LDS: kq doubles as the flag array)
+        const int q = threadIdx.x;       // (every block re-derives the list: thread 0 walking Q label / score pairs was each block's first ~10 us)
+        const float sc = q < Q ? score[q] : 0.f;
+        const bool keep = q < Q && label[q] != void_label && sc > thr;
+        __shared__ int flag_s[256];
+        flag_s[q] = keep ? 1 : 0;
+        __syncthreads();
+        int pos = 0;
+        for (int j = 0; j < q; ++j) pos += flag_s[j];
+        if (keep) { ksc[pos] = sc; kq[pos] = q; }
+        if (q == 255) nk_s = pos + flag_s[255];
+    } else if (threadIdx.x == 0) {       // (serial scan: keeps the order without a prefix sum)
         int n = 0;
         for (int q = 0; q < Q; ++q)
             if (label[q] != void_label && score[q] > thr) { ksc[n] = score[q]; kq[n] = q; ++n; }
@@ -882,6 +907,46 @@ __global__ void panoptic_merge_kernel(const float* __restrict__ score, const int
     ninfo[0] = n;
 }
 
+// stage b for Q <= 128 (r06): the same merge with one thread per query.  What is sequential in the loop above is only (i) "the first kept query of a
+// stuff class opens the segment, later ones join it" and (ii) the running segment number -- a first-occurrence search and a prefix count over <= 128
+// flags in LDS; every global operand (label, score, the three counts, the thing flag) is fetched by all queries at once instead of one after the
+// other behind thread 0 (27 us for 100 queries, profiles/r05_kernel_stats.txt).  final_id, info and ninfo are word for word the loop's.
+__global__ void __launch_bounds__(128) panoptic_merge_par_kernel(const float* __restrict__ score, const int* __restrict__ label,
+                                                                 const int* __restrict__ counts, const int* __restrict__ is_thing,
+                                                                 int* __restrict__ final_id, int* __restrict__ info, int* __restrict__ ninfo, int Q,
+                                                                 int void_label, float thr, float overlap_thr) {
+    __shared__ int s_lab[128], s_new[128], s_id[128];
+    const int q = threadIdx.x;
+    bool valid = false, thing = false;
+    int pc = -1;
+    if (q < Q) {
+        pc = label[q];
+        const int area = counts[3 * q], orig = counts[3 * q + 1], inter = counts[3 * q + 2];
+        valid = pc != void_label && score[q] > thr && area > 0 && orig > 0 && inter > 0;
+        if (valid && (float)area / (float)orig < overlap_thr) valid = false;
+        if (valid) thing = is_thing[pc] != 0;
+    }
+    s_lab[q] = (valid && !thing) ? pc : -1;                    // kept stuff queries by class (-1: not one)
+    __syncthreads();
+    int jfirst = q;
+    if (valid && !thing) {
+        for (int j = q - 1; j >= 0; --j)
+            if (s_lab[j] == pc) jfirst = j;                     // the smallest j wins
+    }
+    const bool isnew = valid && (thing || jfirst == q);
+    s_new[q] = isnew ? 1 : 0;
+    __syncthreads();
+    int before = 0;
+    for (int j = 0; j < q; ++j) before += s_new[j];
+    s_id[q] = isnew ? before + 1 : 0;
+    __syncthreads();
+    if (q < Q) {
+        final_id[q] = isnew ? before + 1 : (valid ? s_id[jfirst] : 0);
+        if (isnew) { info[3 * before] = before + 1; info[3 * before + 1] = thing ? 1 : 0; info[3 * before + 2] = pc; }
+    }
+    if (q == 127) ninfo[0] = before + s_new[127];
+}
+
 // stage c: pan[p] = final_id[argq[p]] where sigmoid(mask[argq[p], p]) >= 0.5, else 0
 __global__ void __launch_bounds__(256) panoptic_write_kernel(const float* __restrict__ mask, const int* __restrict__ argq,
                                                              const int* __restrict__ final_id, int* __restrict__ pan, long HW) {
@@ -911,8 +976,12 @@ extern "C" int psalm_panoptic(const float* mask, const float* score, const int* 
         hipLaunchKernelGGL(panoptic_argmax_kernel, dim3(grid), dim3(256), shmem, s, mask, score, label, argq, counts, Q, HW, num_classes,
                            obj_thr);
     }
-    hipLaunchKernelGGL(panoptic_merge_kernel, dim3(1), dim3(64), 0, s, score, label, counts, is_thing, final_id, info, ninfo, Q,
-                       num_classes, obj_thr, overlap_thr, num_classes);
+    if (Q <= 128)
+        hipLaunchKernelGGL(panoptic_merge_par_kernel, dim3(1), dim3(128), 0, s, score, label, counts, is_thing, final_id, info, ninfo, Q, num_classes, obj_thr,
+                           overlap_thr);
+    else
+        hipLaunchKernelGGL(panoptic_merge_kernel, dim3(1), dim3(64), 0, s, score, label, counts, is_thing, final_id, info, ninfo, Q,
+                           num_classes, obj_thr, overlap_thr, num_classes);
     hipLaunchKernelGGL(panoptic_write_kernel, dim3(grid), dim3(256), 0, s, mask, argq, final_id, pan, HW);
     PSALM_LAUNCH_END("psalm_panoptic");
 }

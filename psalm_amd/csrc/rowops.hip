@@ -3,6 +3,7 @@
 // HBM-bound streaming kernels: one 64-lane wave owns one row, lanes stride the channel dimension
 // (coalesced 256 B / 128 B per wave-load), reductions by __shfl_xor butterflies (no LDS).
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------- LayerNorm core (one wave, one row)
 // Two-pass (mean, then centred variance) like torch.nn.functional.layer_norm; the row is re-read from L1/L2.
@@ -816,6 +817,35 @@ __global__ void __launch_bounds__(256) segment_mean_kernel(const TI* __restrict_
     if (s >= nseg) return;
     const int i0 = off[s], i1 = off[s + 1];
     const float inv = i1 > i0 ? 1.f / (i1 - i0) : 0.f;
+    // r06: fp32 rows of C % 256 == 0 columns (the LLM states: 2048) take every column of a row with four 16-byte loads per lane, all in flight, and
+    // fetch the row index ONCE per row -- the loop below re-read rows[i] in front of every 4-byte load of every column step (a chain of
+    // 2 * C / 64 * (i1 - i0) dependent global loads per wave: 38 us per launch for a 100-segment call, profiles/r05_bench_breakdown.json).  Same sums
+    // in the same order: acc_c = ((0 + x_i0,c) + x_i0+1,c) + ..., then * inv.
+    if constexpr (std::is_same<TI, float>::value) {
+        if (C % 256 == 0 && C <= 4096 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0) {
+            float acc[16][4];
+            const int nv = C / 256;                              // 16-byte vectors per lane (<= 16)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.f;
+            for (int i = i0; i < i1; ++i) {
+                const float* xr = x + (long)rows[i] * ldx + lane * 4;
+                psalm_f32x4 t[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (v < nv) t[v] = *reinterpret_cast<const psalm_f32x4*>(xr + v * 256);
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (v < nv) { acc[v][0] += t[v].x; acc[v][1] += t[v].y; acc[v][2] += t[v].z; acc[v][3] += t[v].w; }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                if (v < nv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) stf(out + (long)s * C + v * 256 + lane * 4 + k, acc[v][k] * inv);
+                }
+            return;
+        }
+    }
     for (int c = lane; c < C; c += 64) {
         float acc = 0.f;
         for (int i = i0; i < i1; ++i) acc += ldf(x + (long)rows[i] * ldx + c);

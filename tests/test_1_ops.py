@@ -698,3 +698,24 @@ def test_gemm_f32_pair_is_bitwise_two_skinny_gemms(ops):
     c0, c1 = ops.gemm_f32_pair(a0.to(d), w0.to(d), b0.to(d), a1.to(d), w1.to(d), b1.to(d))
     assert torch.equal(c0.cpu().view(torch.int32), r0.cpu().view(torch.int32)) and torch.equal(c1.cpu().view(torch.int32), r1.cpu().view(torch.int32))
     assert (c0.cpu().double() - (a0.double() @ w0.double().T + b0.double())).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("C", [256, 2048, 512 + 256])
+def test_segment_mean_vector_path_is_the_scalar_sum_in_the_same_order(ops, C):
+    """psalm_segment_mean on fp32 rows of C % 256 == 0 columns (the LLM states) reads whole rows with 16-byte loads and the row index once per row
+    (r06); same sums in the same order as the column-at-a-time loop -- compared word for word with a sequential fp32 sum -- incl. an empty segment
+    and row strides wider than C."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(40, C + 64, generator=g)[:, :C]                    # row stride C + 64
+    off = torch.tensor([0, 1, 4, 4, 11], dtype=torch.int32)
+    rows = torch.tensor([3, 7, 39, 0, 5, 6, 8, 9, 30, 31, 2], dtype=torch.int32)
+    d = ops.device
+    got = ops.segment_mean(x.to(d), off.to(d), rows.to(d)).cpu()
+    want = torch.zeros(4, C)
+    for s_ in range(4):
+        i0, i1 = int(off[s_]), int(off[s_ + 1])
+        acc = torch.zeros(C)
+        for i in range(i0, i1):
+            acc = acc + x[int(rows[i])]
+        want[s_] = acc * (torch.tensor(1.0) / (i1 - i0) if i1 > i0 else 0.0)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
