@@ -647,6 +647,42 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
     };
     if (tid == 0) { prefix_s = 0ull; remaining_s = kk; nsel = 0; }
     __syncthreads();
+    if (n <= 16 * 1024) {
+        // r06, up to 16 candidates per thread (100 queries x 133 classes: 13): the keys stay in REGISTERS and the kk-th largest one is found by
+        // bisection on its 49 bits -- T <- T | bit whenever at least kk keys are >= T | bit -- one block-wide count per bit.  The digit histograms below cost one LDS atomic per candidate and pass, and scores crowd into a few bins of the
+        // leading digits: ~13 k serialised atomics x 7 passes were ~45 of this kernel's 57 us.  Same threshold (the keys are distinct), same picks.
+        unsigned long long key[16];
+        float val[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tid + 1024 * e;
+            val[e] = i < n ? value(i) : 0.f;
+            key[e] = i < n ? topk_key(val[e], i) : 0ull;                       // (0 is below every real key: real keys have index bits > 0 or value bits > 0)
+        }
+        // one bit per step; the count of a step = sum over the 16 registers of popcount(ballot(key >= candidate)) -- the compare's own lane mask, scalar
+        // arithmetic, no shuffles -- and one LDS atomic per wavefront into the step's own counter (49 counters, zeroed once: no reset race)
+        __shared__ int cnt_s[49];
+        if (tid < 49) cnt_s[tid] = 0;
+        __syncthreads();
+        unsigned long long T = 0ull;
+        for (int bit = 48; bit >= 0 && kk > 0; --bit) {
+            const unsigned long long cand = T | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c += __builtin_popcountll(__ballot(key[e] >= cand));
+            if ((tid & 63) == 0) atomicAdd(&cnt_s[bit], c);
+            __syncthreads();
+            if (cnt_s[bit] >= kk) T = cand;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (kk > 0 && tid + 1024 * e < n && key[e] >= T) {
+                const int slot = atomicAdd(&nsel, 1);
+                sel_key[slot] = key[e];
+                sel_val[slot] = val[e];
+            }
+        __syncthreads();
+    } else {
     // 7 passes over 8-bit digits, most significant first (bits 55..0 cover the 49-bit key)
     for (int shift = 48; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
@@ -685,51 +721,66 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
         }
     }
     __syncthreads();
+    }
     for (int e = nsel + tid; e < 128; e += 1024) { sel_key[e] = 0ull; sel_val[e] = 0.f; }
     __syncthreads();
-    // bitonic sort of 128 (key, value) pairs, descending by key
-    for (int size = 2; size <= 128; size <<= 1)
+    // ---- the <= 128 survivors: sorted (descending by key = value descending, index ascending) and filtered by ONE wavefront in registers -- two
+    // (key, value) pairs per lane, a bitonic network of shuffles, the output slots from two ballots.  r06: the LDS form spent 28 block-wide barriers
+    // of 16 waves on the sort and walked the picks behind one thread (most of what was left of this kernel's 57 us once the selection was cheap).
+    if (tid >= 64) return;
+    const int lane = tid;
+    unsigned long long k2[2] = {sel_key[lane], sel_key[64 + lane]};
+    float v2[2] = {sel_val[lane], sel_val[64 + lane]};
+    auto shfl64 = [&](unsigned long long x, int m) -> unsigned long long {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(x & 0xffffffffull), m), hi_ = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), m);
+        return ((unsigned long long)hi_ << 32) | lo;
+    };
+#pragma unroll
+    for (int size = 2; size <= 128; size <<= 1) {
+#pragma unroll
         for (int st = size >> 1; st > 0; st >>= 1) {
-            if (tid < 64) {
-                const int lo = 2 * tid - (tid & (st - 1));            // index pairs (lo, lo + st)
-                const int hi_ = lo + st;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = sel_key[lo], b = sel_key[hi_];
-                if ((a < b) == desc) {
-                    sel_key[lo] = b; sel_key[hi_] = a;
-                    const float fa = sel_val[lo]; sel_val[lo] = sel_val[hi_]; sel_val[hi_] = fa;
+            if (st == 64) {                                                     // partner = the lane's other pair (size == 128: descending throughout)
+                if (k2[0] < k2[1]) {
+                    const unsigned long long tk = k2[0]; k2[0] = k2[1]; k2[1] = tk;
+                    const float tv = v2[0]; v2[0] = v2[1]; v2[1] = tv;
+                }
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int p_ = sl * 64 + lane;
+                    const unsigned long long ok = shfl64(k2[sl], st);
+                    const float ov = __shfl_xor(v2[sl], st);
+                    const bool desc = (p_ & size) == 0, first = (p_ & st) == 0;       // first: this element is the lower index of the pair
+                    const bool take_max = desc == first;
+                    if (take_max ? ok > k2[sl] : ok < k2[sl]) { k2[sl] = ok; v2[sl] = ov; }
                 }
             }
-            __syncthreads();
         }
-    // The reference's filter (LP:417-446) in pick order.  r06: one thread per pick -- its thing flag and mask score fetched in parallel, its output
-    // slot = the number of kept picks in front of it (128 flags in LDS) -- instead of thread 0 walking the <= 128 picks behind two dependent
-    // global loads each (most of this kernel's 73 us, profiles/r05_kernel_stats.txt).  Same triples in the same order.
-    __shared__ int keep_s[128];
-    int lab = 0, qq = 0;
-    float sc = 0.f;
-    if (tid < 128) {
-        bool keep = false;
-        if (tid < kk) {
-            const int idx = TOPK_IDX_MAX - (int)(sel_key[tid] & (unsigned long long)TOPK_IDX_MAX);
-            lab = idx % C;
-            qq = idx / C;
-            keep = !is_thing || is_thing[lab];
-            sc = sel_val[tid] * (mask_score ? mask_score[qq] : 1.f);
-        }
-        keep_s[tid] = keep ? 1 : 0;
     }
-    __syncthreads();
-    if (tid < 128) {
-        int pos = 0;
-        for (int j = 0; j < tid; ++j) pos += keep_s[j];
-        if (keep_s[tid]) {
-            out_score[pos] = sc;
-            out_class[pos] = lab;
-            out_query[pos] = qq;
-        }
-        if (tid == 127) count[0] = pos + keep_s[127];
+    int lab[2], qq[2];
+    bool keep[2];
+    float sc[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int r = sl * 64 + lane;
+        const int idx = TOPK_IDX_MAX - (int)(k2[sl] & (unsigned long long)TOPK_IDX_MAX);
+        lab[sl] = idx % C;
+        qq[sl] = idx / C;
+        keep[sl] = r < kk && (!is_thing || is_thing[r < kk ? lab[sl] : 0]);
+        sc[sl] = v2[sl] * ((mask_score && r < kk) ? mask_score[qq[sl]] : 1.f);
     }
+    const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int n0 = __builtin_popcountll(b0);
+    const int pos[2] = {__builtin_popcountll(b0 & below), n0 + __builtin_popcountll(b1 & below)};
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+        if (keep[sl]) {
+            out_score[pos[sl]] = sc[sl];
+            out_class[pos[sl]] = lab[sl];
+            out_query[pos[sl]] = qq[sl];
+        }
+    if (lane == 0) count[0] = n0 + __builtin_popcountll(b1);
 }
 
 extern "C" int psalm_topk_select(const float* vals, int Q, int C, int stride, int k, const int* is_thing, const float* mask_score,

@@ -723,8 +723,7 @@ extern "C" int psalm_postprocess(const psalm_post_desc* d, const psalm_post_io* 
     auto zero_topk = [&]() -> int {
         int r;
         if ((r = psalm_memset_zero(io->scores, (long)Q * 4, stream))) return r;
-        if ((r = psalm_memset_zero(cl, (long)Q * 4, stream))) return r;
-        return psalm_memset_zero(qq, (long)Q * 4, stream);
+        return psalm_memset_zero(cl, (lo.qq - lo.cl) + (long)Q * 4, stream);          // class and query vectors: adjacent in the workspace, one fill
     };
     if (task == PSALM_POST_SEMANTIC) {                                                  // on the padded-size masks, post-processed AFTER inference (LP:301,1437-1440)
         PSALM_CHECK_ARG(io->sem_seg && Kpad == 128, "psalm_postprocess: sem_seg buffer; Q in (64, 128]");
