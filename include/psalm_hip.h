@@ -29,7 +29,8 @@ const char* psalm_last_error(void);
  * 5: process-wide policy getenv()s replaced by nothing (PSALM_ATTN_PAIR, PSALM_SEM_ORDER, PSALM_MSDA_LINEAR are gone).
  * 6: psalm_gemm_x3_set_products, psalm_fuse_masks, the stage-level psalm_phi_forward (r05); psalm_causal_attention_f32_workspace grew by one
  *    byte per 32-key tile.
- * 7: psalm_set_tuning / psalm_get_tuning, psalm_layernorm_chain, psalm_gemm_f32_pair, psalm_postprocess* (r06). */
+ * 7: psalm_set_tuning / psalm_get_tuning, psalm_layernorm_chain, psalm_gemm_f32_pair, psalm_postprocess*, psalm_predictor_kv + the kv_ready argument of
+ *    psalm_predictor_forward (r06). */
 #define PSALM_ABI_VERSION 7
 int psalm_abi_version(void);
 const char* psalm_backend(void); /* "hip-gfx950" */
@@ -523,10 +524,16 @@ typedef struct psalm_pr_desc {
     const psalm_pr_layer* layers;                                   /* HOST array */
 } psalm_pr_desc;
 long psalm_predictor_forward_workspace(const psalm_pr_desc* d, const int* hw_levels_host, int H2, int W2, int n_extra_rows);
+/* kv_ready != 0: the level K / V projections and the mask-feature split are in `workspace` already -- psalm_predictor_kv wrote them, with the same descriptor /
+ * geometry / n_extra_rows (= n_reg) and the SAME workspace; it needs nothing from the LLM, so a caller can issue it on another stream behind the pixel decoder
+ * while the LLM runs (psalm_amd/model.py does) and join before this call. */
+int psalm_predictor_kv(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
+                       const float* mask_features, int H2, int W2, int n_extra_rows, void* workspace, long workspace_bytes, void* gemm_workspace,
+                       long gemm_workspace_bytes, void* stream);
 int psalm_predictor_forward(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
                             const float* mask_features, int H2, int W2, const float* seg_query, const float* class_emb, int n_cls, const float* seg_emb,
                             int n_seg, const float* region_emb, int n_reg, float* pred_masks, float* cls_logits, float* seg_logits, float* region_logits,
-                            void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, void* stream);
+                            void* workspace, long workspace_bytes, void* gemm_workspace, long gemm_workspace_bytes, int kv_ready, void* stream);
 
 
 /* psalm_postprocess: llava_phi.py:1401-1466 for ONE image from native code -- the mask logits up-sampled to the padded image size (LP:1401-1406),

@@ -511,11 +511,49 @@ extern "C" long psalm_predictor_forward_workspace(const psalm_pr_desc* d, const 
     if (pr_check(d) != 0 || !hw_levels_host || H2 <= 0 || W2 <= 0) return -1;
     return pr_layout(d, hw_levels_host, H2, W2, n_extra_rows).total;
 }
+// The part of psalm_predictor_forward that needs nothing from the LLM: the K / V projections of the three levels (every decoder layer of a level in one
+// GEMM) and the split of the mask features -- into the SAME workspace the forward call is then given with kv_ready = 1.  r06: model.py issues it on
+// the side stream right behind the pixel decoder, beside the LLM (~0.2 ms of launches leave the critical path: 6 adds, 7 splits, 6 GEMMs); the
+// workspace prefix it writes (PrLayout kin .. mfinv) does not depend on the region count.
+static int predictor_kv_impl(const psalm_pr_desc* d, const PrLayout& lo, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
+                             const float* mask_features, int H2, int W2, char* ws, void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    const int D = d->D, nl = d->num_layers, nlev = d->num_levels, HW2 = H2 * W2, MD = d->mask_dim;
+    float* kin = (float*)(ws + lo.kin); float* vin = (float*)(ws + lo.vin);
+    void* sp = ws + lo.sp; float* spinv = (float*)(ws + lo.spinv);
+    const int KpD = c64(D), KpM = c64(MD);
+    int rc;
+#define PR(call) do { rc = (call); if (rc) return rc; } while (0)
+    // ---- K / V of the three levels: (level tokens + position + level embedding) . Wk^T, (level tokens + level embedding) . Wv^T, every decoder layer of the level in one GEMM
+    for (int l = 0; l < nlev; ++l) {
+        const int hw = hw_levels_host[2 * l] * hw_levels_host[2 * l + 1];
+        const int N = ((nl - l + nlev - 1) / nlev) * D;
+        float* Kl = (float*)(ws + lo.K[l]); float* Vl = (float*)(ws + lo.V[l]);
+        PR(psalm_add_bcast(ms_host[l], PSALM_F32, prpos_host[l], PSALM_F32, kin, PSALM_F32, hw, D, hw, stream));
+        PR(psalm_add_bcast(ms_host[l], PSALM_F32, d->level_embed + (long)l * D, PSALM_F32, vin, PSALM_F32, hw, D, 1, stream));
+        PR(psalm_split_f16(kin, D, sp, 2L * KpD, spinv, hw, D, stream));
+        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_k_w[l], 2L * KpD, d->lvl_k_ws[l], KpD, d->lvl_k_b[l], nullptr, 0, Kl, N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+        PR(psalm_split_f16(vin, D, sp, 2L * KpD, spinv, hw, D, stream));
+        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_v_w[l], 2L * KpD, d->lvl_v_ws[l], KpD, d->lvl_v_b[l], nullptr, 0, Vl, N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
+    }
+    // the mask features as the W operand of the 1 + num_layers mask GEMMs: split once when they are large (PSALM._wop: > 4096 rows), else exact fp32
+    if (HW2 > 4096) PR(psalm_split_f16(mask_features, MD, ws + lo.mfp, 2L * KpM, (float*)(ws + lo.mfinv), HW2, MD, stream));
+#undef PR
+    return 0;
+}
+extern "C" int psalm_predictor_kv(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
+                                  const float* mask_features, int H2, int W2, int n_extra_rows, void* workspace, long workspace_bytes,
+                                  void* gemm_workspace, long gemm_workspace_bytes, void* stream) {
+    if (pr_check(d) != 0) return -1;
+    PSALM_CHECK_ARG(ms_host && hw_levels_host && prpos_host && mask_features && workspace, "psalm_predictor_kv: null argument");
+    const PrLayout lo = pr_layout(d, hw_levels_host, H2, W2, std::max(n_extra_rows, 0));
+    PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_predictor_kv: workspace of psalm_predictor_forward_workspace() bytes, 256-byte aligned");
+    return predictor_kv_impl(d, lo, ms_host, hw_levels_host, prpos_host, mask_features, H2, W2, (char*)workspace, gemm_workspace, gemm_workspace_bytes, stream);
+}
 extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* const* ms_host, const int* hw_levels_host, const float* const* prpos_host,
                                        const float* mask_features, int H2, int W2, const float* seg_query, const float* class_emb, int n_cls,
                                        const float* seg_emb, int n_seg, const float* region_emb, int n_reg, float* pred_masks, float* cls_logits,
                                        float* seg_logits, float* region_logits, void* workspace, long workspace_bytes, void* gemm_workspace,
-                                       long gemm_workspace_bytes, void* stream) {
+                                       long gemm_workspace_bytes, int kv_ready, void* stream) {
     if (pr_check(d) != 0) return -1;
     PSALM_CHECK_ARG(ms_host && hw_levels_host && prpos_host && mask_features && seg_query && pred_masks && workspace, "psalm_predictor_forward: null argument");
     const int D = d->D, Q = d->Q, nh = d->heads, nl = d->num_layers, nlev = d->num_levels, HW2 = H2 * W2, MD = d->mask_dim, F = d->ffn;
@@ -523,8 +561,6 @@ extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* cons
     PSALM_CHECK_ARG(workspace_bytes >= lo.total && (uintptr_t)workspace % 256 == 0, "psalm_predictor_forward: workspace of psalm_predictor_forward_workspace() bytes, 256-byte aligned");
     char* ws = (char*)workspace;
     const float eps = 1e-5f;
-    float* kin = (float*)(ws + lo.kin); float* vin = (float*)(ws + lo.vin);
-    void* sp = ws + lo.sp; float* spinv = (float*)(ws + lo.spinv);
     float* Kl[3]; float* Vl[3];
     for (int l = 0; l < 3; ++l) { Kl[l] = (float*)(ws + lo.K[l]); Vl[l] = (float*)(ws + lo.V[l]); }
     void* mfp = ws + lo.mfp; float* mfinv = (float*)(ws + lo.mfinv);
@@ -546,23 +582,12 @@ extern "C" int psalm_predictor_forward(const psalm_pr_desc* d, const float* cons
     auto ln = [&](const float* x, const float* g_, const float* b_, float* y, int rows) -> int {
         return psalm_layernorm3(x, PSALM_F32, D, y, PSALM_F32, D, nullptr, 0, nullptr, 0, nullptr, 0, g_, b_, rows, D, eps, stream);
     };
-    const int KpD = c64(D), KpM = c64(MD);
-    // ---- K / V of the three levels: (level tokens + position + level embedding) . Wk^T, (level tokens + level embedding) . Wv^T, every decoder layer of the level in one GEMM
+    const int KpM = c64(MD);
+    // ---- K / V of the three levels + the split of the mask features: here, or already in the workspace (psalm_predictor_kv)
     int nl_l[3] = {0, 0, 0};
-    for (int l = 0; l < nlev; ++l) {
-        const int hw = hw_levels_host[2 * l] * hw_levels_host[2 * l + 1];
-        nl_l[l] = (nl - l + nlev - 1) / nlev;
-        const int N = nl_l[l] * D;
-        PR(psalm_add_bcast(ms_host[l], PSALM_F32, prpos_host[l], PSALM_F32, kin, PSALM_F32, hw, D, hw, stream));
-        PR(psalm_add_bcast(ms_host[l], PSALM_F32, d->level_embed + (long)l * D, PSALM_F32, vin, PSALM_F32, hw, D, 1, stream));
-        PR(psalm_split_f16(kin, D, sp, 2L * KpD, spinv, hw, D, stream));
-        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_k_w[l], 2L * KpD, d->lvl_k_ws[l], KpD, d->lvl_k_b[l], nullptr, 0, Kl[l], N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
-        PR(psalm_split_f16(vin, D, sp, 2L * KpD, spinv, hw, D, stream));
-        PR(psalm_gemm_x3(sp, 2L * KpD, spinv, d->lvl_v_w[l], 2L * KpD, d->lvl_v_ws[l], KpD, d->lvl_v_b[l], nullptr, 0, Vl[l], N, hw, N, 0, 0, gemm_workspace, gemm_workspace_bytes, stream));
-    }
-    // the mask features as the W operand of the 1 + num_layers mask GEMMs: split once when they are large (PSALM._wop: > 4096 rows), else exact fp32
+    for (int l = 0; l < nlev; ++l) nl_l[l] = (nl - l + nlev - 1) / nlev;
+    if (!kv_ready) PR(predictor_kv_impl(d, lo, ms_host, hw_levels_host, prpos_host, mask_features, H2, W2, ws, gemm_workspace, gemm_workspace_bytes, stream));
     const bool mf_split = HW2 > 4096;
-    if (mf_split) PR(psalm_split_f16(mask_features, MD, mfp, 2L * KpM, mfinv, HW2, MD, stream));
     // (fused LayerNorm chain / paired projections: D % 8 == 0, the skinny GEMM's M <= 192; PSALM_TUNE_DECODER_FUSE switches them off)
     const bool fuse = D % 8 == 0 && D <= 2048 && Q <= 192 && psalm_get_tuning(PSALM_TUNE_DECODER_FUSE) != 0;
     auto mask_head = [&](const float* out_, bool have_dec = false) -> int {   // decoder_norm -> mask_embed MLP -> (Q, H2*W2) mask logits; `dec` stays for the class heads

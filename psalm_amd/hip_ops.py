@@ -650,7 +650,25 @@ class Ops:
         d._keep = (layers, w)
         return d
 
-    def predictor_forward(self, desc, ms, shapes, prpos, mf, mf_size, seg_query, class_emb=None, seg_emb=None, region_emb=None):
+    def predictor_kv(self, desc, ms, shapes, prpos, mf, mf_size, n_reg=0, slot=0):
+        """The LLM-independent front of the masked-attention decoder (psalm_predictor_kv: level K / V projections + mask-feature split) into a workspace
+        that `predictor_forward(..., kv=<the returned handle>)` then continues in.  `slot`: which of the caller's images this is (each keeps its own
+        workspace until its predictor call)."""
+        H2, W2 = mf_size
+        hw = (c_int * (2 * len(shapes)))(*[int(v) for s_ in shapes for v in s_])
+        self.lib.psalm_predictor_forward_workspace.restype = c_long
+        nbytes = self.lib.psalm_predictor_forward_workspace(ctypes.byref(desc), hw, H2, W2, int(n_reg))
+        if nbytes < 0:
+            raise PsalmHipError(f"psalm_predictor_forward_workspace: {self.lib.psalm_last_error().decode()}")
+        ws = self._stage_ws(f"predictor{slot}", nbytes + 256)
+        off = (-ws.data_ptr()) % 256
+        VP = c_void_p * len(shapes)
+        rc = self.lib.psalm_predictor_kv(ctypes.byref(desc), VP(*[t.data_ptr() for t in ms]), hw, VP(*[t.data_ptr() for t in prpos]), self._p(mf), H2, W2, int(n_reg),
+                                         c_void_p(ws.data_ptr() + off), c_long(nbytes), self._p(self._gemm_ws()), c_long(self.GEMM_WS_BYTES), self._stream())
+        self._check(rc, "psalm_predictor_kv")
+        return (ws, off, nbytes, int(n_reg))
+
+    def predictor_forward(self, desc, ms, shapes, prpos, mf, mf_size, seg_query, class_emb=None, seg_emb=None, region_emb=None, kv=None):
         """The masked-attention decoder of ONE image as ONE native call.  ms / prpos: per-level (h*w, D) float32 tensors; mf (H2*W2, mask_dim);
         seg_query (Q, D); *_emb (n, D) float32 or None.  Returns (pred_masks (Q, H2*W2), cls_logits | None, seg_logits | None, region_logits | None)."""
         H2, W2 = mf_size
@@ -664,8 +682,13 @@ class Ops:
         nbytes = self.lib.psalm_predictor_forward_workspace(ctypes.byref(desc), hw, H2, W2, n_reg)
         if nbytes < 0:
             raise PsalmHipError(f"psalm_predictor_forward_workspace: {self.lib.psalm_last_error().decode()}")
-        ws = self._stage_ws("predictor", nbytes + 256)
-        off = (-ws.data_ptr()) % 256
+        if kv is not None:
+            ws, off, kv_bytes, kv_reg = kv
+            if kv_bytes != nbytes or kv_reg != n_reg:
+                raise PsalmHipError("predictor_forward: the K / V workspace was prepared for another geometry / region count")
+        else:
+            ws = self._stage_ws("predictor", nbytes + 256)
+            off = (-ws.data_ptr()) % 256
         masks = self.empty(Q, H2 * W2, dtype=torch.float32)
         cls = self.empty(Q, class_emb.shape[0], dtype=torch.float32) if class_emb is not None else None
         seg = self.empty(Q, seg_emb.shape[0], dtype=torch.float32) if seg_emb is not None else None
@@ -675,7 +698,7 @@ class Ops:
                                               self._p(seg_query), self._p(class_emb), int(class_emb.shape[0]) if class_emb is not None else 0, self._p(seg_emb),
                                               int(seg_emb.shape[0]) if seg_emb is not None else 0, self._p(region_emb), n_reg, self._p(masks), self._p(cls),
                                               self._p(seg), self._p(reg), c_void_p(ws.data_ptr() + off), c_long(nbytes), self._p(self._gemm_ws()),
-                                              c_long(self.GEMM_WS_BYTES), self._stream())
+                                              c_long(self.GEMM_WS_BYTES), 1 if kv is not None else 0, self._stream())
         self._check(rc, "psalm_predictor_forward")
         return masks, cls, seg, reg
 

@@ -997,9 +997,41 @@ class PSALM:
         return mf, ms, shapes, (H2, W2)
 
     # ======================================================================================= predictor (one image)
-    def predictor(self, ms, shapes, mf, mf_size, seg_query, SEG_emb=None, class_emb=None, region_emb=None):
+    def _predictor_native_ok(self, mf):
+        """the part of the native-predictor condition that is known before the LLM has run (psalm_predictor_kv / psalm_predictor_forward, csrc/stages.hip)"""
+        o, cfg = self.ops, self.cfg
+        D, nh, Q, nlev = cfg.md_hidden, cfg.md_heads, cfg.md_queries, cfg.md_levels
+        return (self.c_stages and self.x3 and Q <= 128 and D == 32 * nh and D % 8 == 0 and nlev <= 3 and cfg.md_mask_dim % 8 == 0 and cfg.md_dim_ff % 8 == 0
+                and getattr(o.lib, "records", None) is None and mf.dtype == torch.float32)
+
+    def _predictor_desc(self, shapes):
+        o, w, cfg = self.ops, self.w, self.cfg
+        dkey = ("pr_desc",)                            # stage-level native call (csrc/stages.hip): ~200 launches from ONE ctypes call
+        if dkey not in self._cache:
+            self._cache[dkey] = o.pr_desc(w, cfg.md_hidden, cfg.md_heads, cfg.md_queries, cfg.md_dec_layers, cfg.md_levels, cfg.md_dim_ff, cfg.md_mask_dim)
+        prpos = []
+        for l in range(cfg.md_levels):
+            h, w_ = shapes[l]
+            key = ("prpos", l, h, w_)
+            if key not in self._cache:
+                self._cache[key] = (self._pos_embed(h, w_) + w["pr.level_embed"][l][None]).contiguous()
+            prpos.append(self._cache[key])
+        return self._cache[dkey], prpos
+
+    def predictor_kv(self, ms, shapes, mf, mf_size, n_reg=0, slot=0):
+        """The LLM-independent front of `predictor` for one image -- the level K / V projections and the mask-feature split -- as its own native call
+        (psalm_predictor_kv), so that it can run on the side stream behind the pixel decoder, beside the LLM.  Returns a handle for `predictor(kv=...)`, or
+        None when the op-by-op path will run."""
+        if not self._predictor_native_ok(mf):
+            return None
+        desc, prpos = self._predictor_desc(shapes)
+        cont = lambda t: t if t.is_contiguous() else t.contiguous()       # noqa: E731
+        ms_c, mf_c = [cont(t) for t in ms], cont(mf)
+        return (self.ops.predictor_kv(desc, ms_c, shapes, prpos, mf_c, mf_size, n_reg, slot), ms_c, mf_c)
+
+    def predictor(self, ms, shapes, mf, mf_size, seg_query, SEG_emb=None, class_emb=None, region_emb=None, kv=None):
         """mask2former_transformer_decoder.py:596-693 (+ heads :695-762) for ONE image.
-        seg_query (Q, D) fp32; *_emb (n, D) in the GEMM-weight dtype."""
+        seg_query (Q, D) fp32; *_emb (n, D) in the GEMM-weight dtype.  kv: `predictor_kv`'s handle (the K / V front already issued)."""
         o, w, cfg = self.ops, self.w, self.cfg
         D, nh, Q = cfg.md_hidden, cfg.md_heads, cfg.md_queries
         nl, nlev = cfg.md_dec_layers, cfg.md_levels
@@ -1008,22 +1040,17 @@ class PSALM:
         # bf16 mode: attention on the matrix cores (split-KV kernel).  It takes V transposed, which the value projection
         # produces directly by swapping the GEMM operands (V^T = W_v . X^T, bias along rows).
         mfma = self.adt == torch.bfloat16 and all((h * w_) % 8 == 0 for h, w_ in shapes)
-        if (self.c_stages and self.x3 and Q <= 128 and D == 32 * nh and D % 8 == 0 and nlev <= 3 and cfg.md_mask_dim % 8 == 0 and cfg.md_dim_ff % 8 == 0
-                and getattr(o.lib, "records", None) is None and seg_query.dtype == torch.float32 and mf.dtype == torch.float32
+        if (self._predictor_native_ok(mf) and seg_query.dtype == torch.float32
                 and all(e is None or (e.dtype == torch.float32 and e.data_ptr() % 16 == 0) for e in (SEG_emb, class_emb, region_emb))):
-            dkey = ("pr_desc",)                        # stage-level native call (csrc/stages.hip): ~200 launches from ONE ctypes call
-            if dkey not in self._cache:
-                self._cache[dkey] = o.pr_desc(w, D, nh, Q, nl, nlev, cfg.md_dim_ff, cfg.md_mask_dim)
-            prpos = []
-            for l in range(nlev):
-                h, w_ = shapes[l]
-                key = ("prpos", l, h, w_)
-                if key not in self._cache:
-                    self._cache[key] = (self._pos_embed(h, w_) + w["pr.level_embed"][l][None]).contiguous()
-                prpos.append(self._cache[key])
+            desc, prpos = self._predictor_desc(shapes)
             cont = lambda t: t if t is None or t.is_contiguous() else t.contiguous()       # noqa: E731
-            masks, cls_l, seg_l, reg_l = o.predictor_forward(self._cache[dkey], [cont(t) for t in ms], shapes, prpos, cont(mf), mf_size, cont(seg_query),
-                                                             cont(class_emb), cont(SEG_emb), cont(region_emb))
+            n_reg = int(region_emb.shape[0]) if region_emb is not None else 0
+            if kv is not None and kv[0][3] == n_reg:
+                handle, ms_c, mf_c = kv
+            else:
+                handle, ms_c, mf_c = None, [cont(t) for t in ms], cont(mf)
+            masks, cls_l, seg_l, reg_l = o.predictor_forward(desc, ms_c, shapes, prpos, mf_c, mf_size, cont(seg_query),
+                                                             cont(class_emb), cont(SEG_emb), cont(region_emb), kv=handle)
             return {"pred_masks": masks.view(Q, H2, W2), "pred_class_name_logits": cls_l, "pred_SEG_logits": seg_l, "pred_region_logits": reg_l}
         Kl, Vl = [], []
         for l in range(nlev):
@@ -1243,6 +1270,9 @@ class PSALM:
             with torch.cuda.stream(side):
                 for b in range(B):
                     pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])
+                    mf_, ms_, shapes_, mfs_ = pd_out[b]
+                    # r06: the predictor's K / V front needs nothing from the LLM either: on the side stream too (~0.2 ms of launches off the critical path)
+                    pd_out[b] = pd_out[b] + (self.predictor_kv(ms_, shapes_, mf_, mfs_, n_regions[b] if n_regions else 0, slot=b),)
         embeds = o.gather_rows([w["embed"], img_tok, w["seg_query"], region_feats], dv["sid"], dv["srow"], cfg.hidden_size,
                                out_dtype=torch.float32)
         hidden = self.llm(embeds, dv["kmask"].view(B, L), B, L)
@@ -1278,13 +1308,15 @@ class PSALM:
                 # `side.wait_stream(main)` -- ordered already; this makes it hold without that argument.)
                 for po in pd_out:
                     if po is not None:
-                        for t in [po[0]] + list(po[1]):
+                        for t in [po[0]] + list(po[1]) + ([po[4][0][0]] if len(po) > 4 and po[4] is not None else []):
                             if torch.is_tensor(t):
                                 t.record_stream(torch.cuda.current_stream())
         for b in range(B):
             if pd_out[b] is None:
                 pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])
-            mf, ms, shapes, mf_size = pd_out[b]
+                mf_, ms_, shapes_, mfs_ = pd_out[b]
+                pd_out[b] = pd_out[b] + (self.predictor_kv(ms_, shapes_, mf_, mfs_, n_regions[b] if n_regions else 0, slot=b),)
+            mf, ms, shapes, mf_size, kv = pd_out[b]
             nc = meta["n_cls"][b]
             ce = cls_emb[c0:c0 + nc] if cls_emb is not None else None
             c0 += nc
@@ -1293,7 +1325,7 @@ class PSALM:
             if reg_emb is not None:
                 re = reg_emb[r0:r0 + n_regions[b]]
                 r0 += n_regions[b]
-            r = self.predictor(ms, shapes, mf, mf_size, seg_q[b * Q:(b + 1) * Q], se, ce, re)
+            r = self.predictor(ms, shapes, mf, mf_size, seg_q[b * Q:(b + 1) * Q], se, ce, re, kv=kv)
             if stages is not None:
                 stages.setdefault("mask_features", []).append(mf)
                 stages.setdefault("multi_scale_features", []).append(ms)
