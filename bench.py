@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--breakdown", default=None, help="write the per-kernel time breakdown JSON here")
     ap.add_argument("--gemm-policy", default="", help="comma-separated psalm_gemm_set_tile_policy codes applied before the first call (kernel A/B runs)")
     ap.add_argument("--tuning", default="", help="comma-separated key=value pairs for psalm_set_tuning (PSALM_TUNE_* of include/psalm_hip.h; kernel A/B runs)")
+    ap.add_argument("--set", default="", help="comma-separated attr=int pairs set on the PSALM object before the first call (A/B switches such as kv_side=0)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still run init_process_group('nccl'), the weight broadcast, the checksum all-reduce and the barriers (RCCL dry run on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (for kernel traces / PMC passes: per-kernel durations undisturbed)")
@@ -226,6 +227,9 @@ def main():
         model.ops.gemm_tile_policy(code)
     for kv in [c for c in args.tuning.split(",") if c]:
         model.ops.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    for kv in [c for c in getattr(args, "set").split(",") if c]:
+        assert hasattr(model, kv.split("=")[0]), kv
+        setattr(model, kv.split("=")[0], type(getattr(model, kv.split("=")[0]))(int(kv.split("=")[1])))
     # Results are consumed (here: dropped) before the next step, as the reference's eval loop does (evaluator.process right after
     # eval_seg): hand out the graph's own output buffers instead of a private ~1 GB copy per image (see PSALM.graph_outputs).
     model.graph_outputs = "alias"

@@ -155,6 +155,7 @@ class PSALM:
         # call into the library instead of one ctypes call each -- same launches, same order, same bits (tests/test_6_model_emu.py); off while
         # bench.py's per-launch events are being recorded (they attribute time per op-level call).
         self.c_stages = True
+        self.kv_side = True        # r06: the predictor's K / V front on the side stream beside the LLM (False: at the start of the predictor call, as r05; A/B switch)
         self.graph_tail = False
         self.graph_stats = {"calls": 0, "replays": 0, "eager": 0, "captures": 0}
         self.use_graphs = use_graphs                  # capture each input signature's launch sequence into a hipGraph
@@ -1272,7 +1273,7 @@ class PSALM:
                     pd_out[b] = self.pixel_decoder([(tok[b * h * w_:(b + 1) * h * w_], h, w_) for tok, h, w_ in feats])
                     mf_, ms_, shapes_, mfs_ = pd_out[b]
                     # r06: the predictor's K / V front needs nothing from the LLM either: on the side stream too (~0.2 ms of launches off the critical path)
-                    pd_out[b] = pd_out[b] + (self.predictor_kv(ms_, shapes_, mf_, mfs_, n_regions[b] if n_regions else 0, slot=b),)
+                    pd_out[b] = pd_out[b] + ((self.predictor_kv(ms_, shapes_, mf_, mfs_, n_regions[b] if n_regions else 0, slot=b) if self.kv_side else None),)
         embeds = o.gather_rows([w["embed"], img_tok, w["seg_query"], region_feats], dv["sid"], dv["srow"], cfg.hidden_size,
                                out_dtype=torch.float32)
         hidden = self.llm(embeds, dv["kmask"].view(B, L), B, L)
