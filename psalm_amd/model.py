@@ -319,6 +319,12 @@ class PSALM:
     def _prepare_weights(self, sd):
         cfg, w = self.cfg, self.w
         W, Fp = self._W, self._F
+        # (the stage descriptors and captured graphs hold raw device pointers into `w`: a second preparation replaces those tensors, so whatever was
+        #  derived from the old ones goes -- ADVICE r05; broadcast_weights writes IN PLACE and keeps them valid)
+        for k in [k for k in getattr(self, "_cache", {}) if isinstance(k, tuple) and k and isinstance(k[0], str) and k[0].endswith("_desc")]:
+            del self._cache[k]
+        if getattr(self, "_graphs", None):
+            self._graphs.clear()
 
         def lin(dst, src, bias=True, small=False, pair=False):
             wt, bs = sd[src + ".weight"], (sd[src + ".bias"] if bias and (src + ".bias") in sd else None)
