@@ -44,11 +44,14 @@ const char* psalm_backend(void); /* "hip-gfx950" */
  *   PSALM_TUNE_GEMM_MID         1 (default): mid-size split-f16 GEMMs take the 64 x 64 wave-tile kernel where the selection prefers it; 0: r05 kernels
  *   PSALM_TUNE_DECODER_FUSE     1 (default): psalm_predictor_forward issues the query rows' LayerNorm chains / paired projections as single launches
  *                               (psalm_layernorm_chain, psalm_gemm_f32_pair); 0: the r05 launch sequence
- *   4..7                        unused */
+ *   PSALM_TUNE_ROW_GROUPS       1 (default): the LayerNorm-fused row kernels (psalm_layernorm_split, psalm_swin_window_gather_split,
+ *                               psalm_swin_window_merge_ln_split) put 4 / 2 rows of <= 128 / 256 columns on one wavefront; 0: one row per wavefront
+ *   5..7                        unused */
 #define PSALM_TUNE_GEMM_XCD_KSPLIT 0
 #define PSALM_TUNE_ATTN_XCD_HEADS 1
 #define PSALM_TUNE_GEMM_MID 2
 #define PSALM_TUNE_DECODER_FUSE 3
+#define PSALM_TUNE_ROW_GROUPS 4
 #define PSALM_TUNE_COUNT 8
 int psalm_set_tuning(int key, int value);
 int psalm_get_tuning(int key);

@@ -14,7 +14,7 @@ extern "C" void psalm_set_error(const char* msg) {
 extern "C" const char* psalm_last_error() { return g_err; }
 // Process-wide tuning switches (psalm_hip.h: PSALM_TUNE_*).  Atomic words: a host thread that flips one while another thread launches makes that
 // thread's NEXT launch see the old or the new value, never a torn one; every switch selects between forms with identical results.
-static std::atomic<int> g_tuning[PSALM_TUNE_COUNT] = {{1}, {1}, {1}, {1}, {0}, {0}, {0}, {0}};
+static std::atomic<int> g_tuning[PSALM_TUNE_COUNT] = {{1}, {1}, {1}, {1}, {1}, {0}, {0}, {0}};
 extern "C" int psalm_set_tuning(int key, int value) {
     if (key < 0 || key >= PSALM_TUNE_COUNT) { psalm_set_error("psalm_set_tuning: unknown key"); return -1; }
     g_tuning[key].store(value, std::memory_order_relaxed);

@@ -69,6 +69,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ... over aligned groups of LPR = 16 / 32 / 64 lanes (a row per group in the row kernels that put several short rows on one wavefront).  The
+// butterfly runs from LPR / 2 down: a row that occupies the first LPR lanes of a 64-lane wave_sum / wave_max (zeros elsewhere) gets the same
+// additions in the same order, i.e. the same bits.
+template <int LPR> __device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int LPR> __device__ __forceinline__ float seg_max(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): the LDS destination is the WAVE-UNIFORM
 // `lds_wave_base` + lane*16 (hardware adds the lane offset; the base goes through M0), the global source is per lane.
 // Completion is tracked by vmcnt; a following __syncthreads() drains it.
@@ -93,11 +107,14 @@ __device__ __forceinline__ void psalm_glds16(const void* g, void* lds_wave_base)
 #define PSALM_RAW_BARRIER() __syncthreads()
 #define PSALM_SCHED_FENCE() do { } while (0)
 #define PSALM_OPAQUE_VGPR(x) do { } while (0)
+#define PSALM_OPAQUE_SGPR(x) do { } while (0)
 __device__ __forceinline__ float psalm_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float psalm_exp2(float x) { return exp2f(x); }
 #else
 // makes an int look freshly defined to the optimiser (keeps loop-invariant LDS fragment reads from being hoisted into registers)
 #define PSALM_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+// the same for a wave-uniform int: what is derived from it is recomputed where it is used instead of being hoisted out of a loop into (spilled) SGPRs
+#define PSALM_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
 #define PSALM_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PSALM_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define PSALM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)       // no instruction is scheduled across this point
@@ -184,6 +201,7 @@ extern "C" int psalm_get_tuning(int key);          // api.hip; keys: PSALM_TUNE_
 #define PSALM_TUNE_ATTN_XCD_HEADS 1
 #define PSALM_TUNE_GEMM_MID 2
 #define PSALM_TUNE_DECODER_FUSE 3
+#define PSALM_TUNE_ROW_GROUPS 4
 #define PSALM_TUNE_COUNT 8
 #endif
 

@@ -399,6 +399,11 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
                                                                              int C, long HW, int ntiles, int contig) {
     constexpr int PITCH = KP + 4, CT = 5, NI = KP / 4, KS = KP / 16, KS1 = (KS + 1) / 2;
     constexpr float SC = 8192.0f;
+#ifdef PSALM_SEM_ABL                                          // (tools/experiments/r06_semantic_ablate.py: what the pass costs without ...)
+    constexpr int ABL = PSALM_SEM_ABL;                        // 1: the stores  2: the matrix instructions  4: the sigmoids  8: the loads  16: the split
+#else
+    constexpr int ABL = 0;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned short Ph[CT * 32 * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Pl[CT * 32 * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Sh[2][64 * PITCH];
@@ -427,15 +432,25 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
     const int iters = (ntiles + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x);
     float num[NI], den[NI], m[NI], sg[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; }
+    for (int i = 0; i < NI; ++i) { num[i] = 0.f; den[i] = 0.f; sg[i] = 0.f; }
+    // r06: the wave's query slots beyond Q (Q = 100: 12 of wave 3's 28) are skipped by wave-uniform branches -- as per-query select masks they were 28
+    // SGPR pairs; with the 28 load and 48 store row offsets (loop invariants the compiler hoists) the loop body carried ~560 v_readlane / v_writelane
+    // instructions of SGPR spills per tile in a kernel that is bound by VALU issue.  The row offsets are now derived inside the loop from an
+    // opaque copy of the wave's first query / class tile (a few dozen SALU instructions per tile).
+    const int nvq = __builtin_amdgcn_readfirstlane(max(0, min(NI, Q - qb)));
     // tile order: strided (all CUs walk neighbouring 256-byte pieces of every row at the same time) or, contig != 0, one contiguous
     // pixel range per block (experiment: PSALM_SEM_ORDER=1)
     auto tile_of = [&](int it) { return contig ? (long)blockIdx.x * (2 * iters) + 2 * it + grp : (long)blockIdx.x + (long)gridDim.x * (2 * it + grp); };
     auto request = [&](int it) {                              // unconditional clamped loads: NI in flight per lane
         const long t = min(tile_of(it), (long)ntiles - 1);
         const unsigned voff = (unsigned)min(t * 64 + lane, HW - 1) * 4u;
+        int qb_ = qb;
+        PSALM_OPAQUE_SGPR(qb_);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) m[i] = psalm_buf_load_f32_s(mrsrc, voff, (unsigned)min(qb + i, Q - 1) * row_bytes);   // row offset: SGPR
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (ABL & 8) m[i] = 0.001f * (float)(lane + i);
+            else m[i] = psalm_buf_load_f32_s(mrsrc, voff, (unsigned)min(qb_ + i, Q - 1) * row_bytes);   // row offset: SGPR
+        }
     };
     request(0);
     // 48 dropped stores behind the first request: the loop's wait for a tile's logits then sees the SAME instruction stream behind them on
@@ -453,14 +468,15 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
         float xm = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const float x = v ? m[i] : 0.f;
-            const bool vq = qb + i < Q;
-            const float sv = sigmoidf_(x);
-            sg[i] = vq ? sv : 0.f;
-            if (vq) xm = fmaxf(xm, m[i]);
-            const bool pos = vq && x > 0.f;
-            num[i] += pos ? sv : 0.f;
-            den[i] += pos ? 1.f : 0.f;
+            if (i < nvq) {                                        // (wave-uniform; sg[i] of the other slots stays 0)
+                const float x = v ? m[i] : 0.f;
+                const float sv = (ABL & 4) ? 0.5f + 0.125f * x : sigmoidf_(x);
+                sg[i] = sv;
+                xm = fmaxf(xm, m[i]);
+                const bool pos = x > 0.f;
+                num[i] += pos ? sv : 0.f;
+                den[i] += pos ? 1.f : 0.f;
+            }
         }
         pmax[grp][w][lane] = xm;
         if (it + 1 < iters) request(it + 1);
@@ -480,6 +496,7 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
             unsigned short* sl = &Sl[grp][lane * PITCH + qb];
 #pragma unroll
             for (int i = 0; i < NI; i += 4) {
+                if constexpr (ABL & 16) break;
                 unsigned hw[4], lw[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -511,7 +528,7 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
                 const pp_f16x8 bh = frag(&Sh[grp][(32 * ps + n) * PITCH + ko]), bl = frag(&Sl[grp][(32 * ps + n) * PITCH + ko]);
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    if (u < nu) {
+                    if (u < nu && !(ABL & 2)) {
                         const pp_f16x8 ah = frag(&Ph[(32 * (u0 + u) + n) * PITCH + ko]), al = frag(&Pl[(32 * (u0 + u) + n) * PITCH + ko]);
                         acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
                         acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
@@ -528,13 +545,16 @@ __global__ void __launch_bounds__(512, 1) semantic_from_masks_x3_pair_kernel(con
             const bool pv = live && p0 + 32 * ps + n < HW;
             // lane part of the address: the pixel inside a class row + this half-wave's 4 rows; the class row of (u, r) is wave-uniform
             const unsigned pix = pv ? (unsigned)(p0 + 32 * ps + n) * 4u + (unsigned)(4 * hi) * row_bytes : PSALM_BUF_OOB;
+            int u0_ = u0;
+            PSALM_OPAQUE_SGPR(u0_);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cb = 32 * (u0 + u) + (r & 3) + 8 * (r >> 2);
+                    const int cb = 32 * (u0_ + u) + (r & 3) + 8 * (r >> 2);
                     const bool ok = u < nu && cb + 4 * hi < C;
-                    psalm_buf_store_f32_s(acc[u][r] * oinv, orsrc, ok ? pix : PSALM_BUF_OOB, (unsigned)min(cb, C - 1) * row_bytes);
+                    if constexpr (!(ABL & 1)) psalm_buf_store_f32_s(acc[u][r] * oinv, orsrc, ok ? pix : PSALM_BUF_OOB, (unsigned)min(cb, C - 1) * row_bytes);
+                    else if (acc[u][r] * oinv == 123.456f && ok) psalm_buf_store_f32_s(1.f, orsrc, pix, 0u);     // (keeps the accumulators alive)
                 }
         }
         PSALM_RAW_BARRIER();

@@ -246,41 +246,45 @@ extern "C" int psalm_layernorm(const void* x, int x_dtype, long ldx, void* y, in
 // them ([hi (Kp) | lo (Kp)] f16 + per-row power-of-two scale): the separate split pass (read 8 B + write 4 B per element and one launch
 // per GEMM) disappears for LayerNorm-fed projections -- Phi's [k|v|q|fc1] input, the pixel decoder's value / offset / FFN inputs.
 // One wavefront per row, row in registers (C % 8 == 0, C <= 2048).
+// LPR: lanes per row (r06; see swin_window_merge_ln_kernel): 32 puts two rows of C <= 256 on a wavefront (the pixel decoder's 21504 x 256 rows), 16 four of
+// C <= 128; same bits as one row per wavefront.
+template <int LPR>
 __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C,
                                                               float eps, unsigned short* __restrict__ s1, float* __restrict__ inv1,
                                                               const float* __restrict__ add, long add_rows, unsigned short* __restrict__ s2,
                                                               float* __restrict__ inv2, int Kp) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int RPW = 64 / LPR, NI = LPR == 64 ? 4 : 1;
+    const int lane = (threadIdx.x & 63) % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (threadIdx.x & 63) / LPR;
     if (row >= rows) return;
     const float* xr = x + row * ldx;
-    float v[4][8];
+    float v[NI][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < C) {
             ld8(xr + c, v[i]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[i][k];
         }
     }
-    const float mean = wave_sum(s) / C;
+    const float mean = seg_sum<LPR>(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < C) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float rstd = rsqrtf(seg_sum<LPR>(q) / C + eps);
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < C) {
             float g8[8], b8[8];
             ld8(gamma + c, g8);
@@ -297,16 +301,16 @@ __global__ void __launch_bounds__(256) layernorm_split_kernel(const float* __res
         }
     }
     float sc1, iv1, sc2 = 1.f, iv2 = 1.f;
-    split_scale(wave_max(a1), sc1, iv1);
-    if (s2) split_scale(wave_max(a2), sc2, iv2);
+    split_scale(seg_max<LPR>(a1), sc1, iv1);
+    if (s2) split_scale(seg_max<LPR>(a2), sc2, iv2);
     if (lane == 0) {
         if (s1) inv1[row] = iv1;
         if (s2) inv2[row] = iv2;
     }
     const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < Kp) {
             const bool in = c < C;
             if (s1) emit_split8(in ? v[i] : zero8, sc1, s1 + row * 2L * Kp + c, s1 + row * 2L * Kp + Kp + c);
@@ -336,8 +340,11 @@ extern "C" int psalm_layernorm_split(const float* x, long ldx, float* y, long ld
                     "psalm_layernorm_split: 16-byte aligned rows; split2 needs the `add` table");
     PSALM_CHECK_ARG((!split1 || inv1) && (!split2 || inv2) && (split1 || split2 || y), "psalm_layernorm_split: outputs / scale arrays missing");
     const int Kp = (C + 63) / 64 * 64;
-    hipLaunchKernelGGL(layernorm_split_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, rows, C, eps,
-                       (unsigned short*)split1, inv1, add, add_rows, (unsigned short*)split2, inv2, Kp);
+#define LNS_LAUNCH(LPR_) hipLaunchKernelGGL((layernorm_split_kernel<LPR_>), dim3(cdiv(rows, 4 * (64 / LPR_))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, \
+                                            gamma, beta, rows, C, eps, (unsigned short*)split1, inv1, add, add_rows, (unsigned short*)split2, inv2, Kp)
+    const int lpr = !psalm_get_tuning(PSALM_TUNE_ROW_GROUPS) ? 64 : (C <= 128 ? 16 : (C <= 256 ? 32 : 64));
+    if (lpr == 16) LNS_LAUNCH(16); else if (lpr == 32) LNS_LAUNCH(32); else LNS_LAUNCH(64);
+#undef LNS_LAUNCH
     PSALM_LAUNCH_END("psalm_layernorm_split");
 }
 
@@ -421,28 +428,32 @@ extern "C" int psalm_swin_window_merge(const void* win, int win_dtype, const voi
 
 // ... the same fused with norm2 (swin_trans.py:250-251): x_new = shortcut + merged is written once (fp32 stream) and its
 // LayerNorm (the MLP's input) comes out of the same registers.  C % 8 == 0, C <= 2048.
-template <typename TW, typename TH>
+// LPR (r06): lanes per row.  64: one row per wavefront, up to four 8-column chunks per lane (C <= 2048).  16 / 32: a row of C <= 128 / 256 columns on
+// a quarter / half of the wavefront, 4 / 2 rows per wavefront -- the stage-1 / stage-2 rows of Swin (65536 x 128, 16384 x 256) left 48 / 32 lanes of every
+// wavefront idle; same lane <-> column map inside a row and the same reduction order (seg_sum), so the same bits.
+template <typename TW, typename TH, int LPR = 64>
 __global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __restrict__ win, const float* __restrict__ shortcut,
                                                                    float* __restrict__ out_x, TH* __restrict__ out_h,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    int B, int H, int W, int C, int ws, int shift, float eps,
                                                                    unsigned short* __restrict__ h_split, float* __restrict__ h_inv, int Kp) {
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR, NI = LPR == 64 ? 4 : 1;
+    const int lane = (threadIdx.x & 63) % LPR;                    // lane inside the row's group
     const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws, N = ws * ws;
     const int Hp = nWh * ws, Wp = nWw * ws;
     const long rows = (long)B * H * W;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
+    const long r = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (threadIdx.x & 63) / LPR;
+    if (r >= rows) return;                                        // (a whole group: shuffles stay inside groups)
     const int xx = (int)(r % W);
     const int y = (int)((r / W) % H);
     const int b = (int)(r / ((long)W * H));
     const int yp = (y - shift + Hp) % Hp, xp = (xx - shift + Wp) % Wp;
     const long wr = (((long)b * nWh + yp / ws) * nWw + xp / ws) * N + (yp % ws) * ws + (xp % ws);
-    float v[4][8];
+    float v[NI][8];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < C) {
             float a[8];
             ld8(shortcut + r * C + c, v[i]);
@@ -452,20 +463,20 @@ __global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __r
             st8(out_x + r * C + c, v[i]);
         }
     }
-    const float mean = wave_sum(sum) / C;
+    const float mean = seg_sum<LPR>(sum) / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if ((i * 64 + lane) * 8 < C) {
+    for (int i = 0; i < NI; ++i)
+        if ((i * LPR + lane) * 8 < C) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
         }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float rstd = rsqrtf(seg_sum<LPR>(q) / C + eps);
     if (h_split) {                                               // f16x3: norm2's result leaves as the fc1 GEMM's split-f16 A operand
         float amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (i * 64 + lane) * 8;
+        for (int i = 0; i < NI; ++i) {
+            const int c = (i * LPR + lane) * 8;
             if (c < C) {
                 float g8[8], b8[8];
                 ld8(gamma + c, g8);
@@ -475,19 +486,19 @@ __global__ void __launch_bounds__(256) swin_window_merge_ln_kernel(const TW* __r
             }
         }
         float sc, inv;
-        split_scale(wave_max(amax), sc, inv);
+        split_scale(seg_max<LPR>(amax), sc, inv);
         if (lane == 0) h_inv[r] = inv;
         const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (i * 64 + lane) * 8;
+        for (int i = 0; i < NI; ++i) {
+            const int c = (i * LPR + lane) * 8;
             if (c < Kp) emit_split8(c < C ? v[i] : zero8, sc, h_split + r * 2L * Kp + c, h_split + r * 2L * Kp + Kp + c);
         }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < C) {
             float g8[8], b8[8], o8[8];
             ld8(gamma + c, g8);
@@ -522,19 +533,24 @@ extern "C" int psalm_swin_window_merge_ln_split(const float* win, const float* s
     const long rows = (long)B * H * W;
     if (rows == 0) return 0;
     PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048 && h_split && h_inv, "psalm_swin_window_merge_ln_split: C % 8 == 0, C <= 2048, outputs required");
-    hipLaunchKernelGGL((swin_window_merge_ln_kernel<float, float>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, win, shortcut, out_x,
-                       (float*)nullptr, gamma, beta, B, H, W, C, ws, shift, eps, (unsigned short*)h_split, h_inv, (C + 63) / 64 * 64);
+#define MLN_LAUNCH(LPR_) hipLaunchKernelGGL((swin_window_merge_ln_kernel<float, float, LPR_>), dim3(cdiv(rows, 4 * (64 / LPR_))), dim3(256), 0, (hipStream_t)stream, \
+                                            win, shortcut, out_x, (float*)nullptr, gamma, beta, B, H, W, C, ws, shift, eps, (unsigned short*)h_split, h_inv, (C + 63) / 64 * 64)
+    const int lpr = !psalm_get_tuning(PSALM_TUNE_ROW_GROUPS) ? 64 : (C <= 128 ? 16 : (C <= 256 ? 32 : 64));
+    if (lpr == 16) MLN_LAUNCH(16); else if (lpr == 32) MLN_LAUNCH(32); else MLN_LAUNCH(64);
+#undef MLN_LAUNCH
     PSALM_LAUNCH_END("psalm_swin_window_merge_ln_split");
 }
 
+template <int LPR>                                            // lanes per row: see swin_window_merge_ln_kernel
 __global__ void __launch_bounds__(256) swin_window_gather_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, float* __restrict__ inv_out,
                                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H,
                                                                        int W, int C, int ws, int shift, float eps, int Kp) {
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR, NI = LPR == 64 ? 4 : 1;
+    const int lane = (threadIdx.x & 63) % LPR;
     const int nWh = (H + ws - 1) / ws, nWw = (W + ws - 1) / ws, N = ws * ws;
     const int Hp = nWh * ws, Wp = nWw * ws;
     const long rows = (long)B * nWh * nWw * N;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long r = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (threadIdx.x & 63) / LPR;
     if (r >= rows) return;
     const int tok = (int)(r % N);
     long t = r / N;
@@ -543,34 +559,34 @@ __global__ void __launch_bounds__(256) swin_window_gather_split_kernel(const flo
     const int wh = (int)(t % nWh);
     const int b = (int)(t / nWh);
     const int y = (wh * ws + tok / ws + shift) % Hp, xx = (ww * ws + tok % ws + shift) % Wp;
-    const bool live = y < H && xx < W;                            // (wave-uniform: one row per wavefront)
-    float v[4][8];
+    const bool live = y < H && xx < W;                            // (uniform over the row's lanes)
+    float v[NI][8];
     float sc = 1.f, inv = 1.f;
     if (live) {
         const float* xr = x + (((long)b * H + y) * W + xx) * C;
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (i * 64 + lane) * 8;
+        for (int i = 0; i < NI; ++i) {
+            const int c = (i * LPR + lane) * 8;
             if (c < C) {
                 ld8(xr + c, v[i]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s += v[i][k];
             }
         }
-        const float mean = wave_sum(s) / C;
+        const float mean = seg_sum<LPR>(s) / C;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if ((i * 64 + lane) * 8 < C) {
+        for (int i = 0; i < NI; ++i)
+            if ((i * LPR + lane) * 8 < C) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
             }
-        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        const float rstd = rsqrtf(seg_sum<LPR>(q) / C + eps);
         float amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (i * 64 + lane) * 8;
+        for (int i = 0; i < NI; ++i) {
+            const int c = (i * LPR + lane) * 8;
             if (c < C) {
                 float g8[8], b8[8];
                 ld8(gamma + c, g8);
@@ -579,13 +595,13 @@ __global__ void __launch_bounds__(256) swin_window_gather_split_kernel(const flo
                 for (int k = 0; k < 8; ++k) { v[i][k] = (v[i][k] - mean) * rstd * g8[k] + b8[k]; amax = fmaxf(amax, fabsf(v[i][k])); }
             }
         }
-        split_scale(wave_max(amax), sc, inv);
+        split_scale(seg_max<LPR>(amax), sc, inv);
     }
     if (lane == 0) inv_out[r] = inv;
     const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (i * 64 + lane) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int c = (i * LPR + lane) * 8;
         if (c < Kp) emit_split8((live && c < C) ? v[i] : zero8, sc, out + r * 2L * Kp + c, out + r * 2L * Kp + Kp + c);
     }
 }
@@ -594,8 +610,11 @@ extern "C" int psalm_swin_window_gather_split(const float* x, void* out, float* 
     const long rows = (long)B * ((H + ws - 1) / ws) * ((W + ws - 1) / ws) * ws * ws;
     if (rows == 0) return 0;
     PSALM_CHECK_ARG(C % 8 == 0 && C <= 2048 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_swin_window_gather_split: C % 8 == 0, C <= 2048, aligned");
-    hipLaunchKernelGGL(swin_window_gather_split_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, inv_out,
-                       gamma, beta, B, H, W, C, ws, shift, eps, (C + 63) / 64 * 64);
+#define WGS_LAUNCH(LPR_) hipLaunchKernelGGL((swin_window_gather_split_kernel<LPR_>), dim3(cdiv(rows, 4 * (64 / LPR_))), dim3(256), 0, (hipStream_t)stream, x, \
+                                            (unsigned short*)out, inv_out, gamma, beta, B, H, W, C, ws, shift, eps, (C + 63) / 64 * 64)
+    const int lpr = !psalm_get_tuning(PSALM_TUNE_ROW_GROUPS) ? 64 : (C <= 128 ? 16 : (C <= 256 ? 32 : 64));
+    if (lpr == 16) WGS_LAUNCH(16); else if (lpr == 32) WGS_LAUNCH(32); else WGS_LAUNCH(64);
+#undef WGS_LAUNCH
     PSALM_LAUNCH_END("psalm_swin_window_gather_split");
 }
 

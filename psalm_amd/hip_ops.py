@@ -781,7 +781,7 @@ class Ops:
         operands, a third of the matrix work -- the reduced-precision LLM side mode, not at the parity bar).  See psalm_gemm_x3_set_products."""
         self._check(self.lib.psalm_gemm_x3_set_products(int(n)), "psalm_gemm_x3_set_products")
 
-    TUNE_GEMM_XCD_KSPLIT, TUNE_ATTN_XCD_HEADS, TUNE_GEMM_MID, TUNE_DECODER_FUSE = 0, 1, 2, 3      # PSALM_TUNE_* of include/psalm_hip.h
+    TUNE_GEMM_XCD_KSPLIT, TUNE_ATTN_XCD_HEADS, TUNE_GEMM_MID, TUNE_DECODER_FUSE, TUNE_ROW_GROUPS = 0, 1, 2, 3, 4      # PSALM_TUNE_* of include/psalm_hip.h
 
     def set_tuning(self, key: int, value: int):
         """psalm_set_tuning: process-wide atomic switches between kernel forms with identical results (A/B runs, tests)."""

@@ -719,3 +719,33 @@ def test_segment_mean_vector_path_is_the_scalar_sum_in_the_same_order(ops, C):
             acc = acc + x[int(rows[i])]
         want[s_] = acc * (torch.tensor(1.0) / (i1 - i0) if i1 > i0 else 0.0)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,C,shift", [(1, 13, 11, 128, 6), (1, 25, 14, 256, 0), (1, 7, 9, 96, 6), (1, 12, 12, 136, 0)])
+def test_row_kernels_several_rows_per_wavefront_same_bits(ops, B, H, W, C, shift):
+    """r06 (PSALM_TUNE_ROW_GROUPS): rows of <= 128 / 256 columns share a wavefront four / two at a time in psalm_layernorm_split,
+    psalm_swin_window_gather_split and psalm_swin_window_merge_ln_split -- same lane <-> column map inside a row, same reduction order: every word
+    equals the one-row-per-wavefront form's, on row counts that leave the last wavefront partly empty and with padded (zero) window tokens."""
+    ws = 12
+    g = torch.Generator().manual_seed(B * H * W + C)
+    d = ops.device
+    x = (torch.randn(B * H * W, C, generator=g) * 2 + 0.5).to(d)
+    ga, be = torch.randn(C, generator=g).to(d), torch.randn(C, generator=g).to(d)
+    add = torch.randn(5, C, generator=g).to(d)
+    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    win = torch.randn(B * nW * ws * ws, C, generator=g).to(d)
+    res = []
+    try:
+        for groups in (0, 1):
+            ops.set_tuning(ops.TUNE_ROW_GROUPS, groups)
+            y, s1, s2 = ops.layernorm_split(x, ga, be, 1e-5, want_y=True, add=add)
+            a = ops.swin_window_gather_split(x, ga, be, B, H, W, ws, shift)
+            x1, h1 = ops.swin_window_merge_ln_split(win, x, ga, be, B, H, W, ws, shift)
+            res.append([y, s1.t, s1.inv_scale, s2.t, s2.inv_scale, a.t, a.inv_scale, x1, h1.t, h1.inv_scale])
+    finally:
+        ops.set_tuning(ops.TUNE_ROW_GROUPS, 1)
+    for p, q in zip(*res):
+        p, q = p.cpu(), q.cpu()
+        if p.dtype == torch.float16:
+            p, q = p.view(torch.int16), q.view(torch.int16)
+        assert torch.equal(p, q)
