@@ -340,10 +340,15 @@ extern "C" int psalm_region_pool(const float* tokens, const int* img_of_region, 
 // (msdeformattn.py:248-254) that matrix is 604 MB written, read twice by the split and written again (2.4 GB of traffic); here the
 // 67 MB NHWC input is read (9x, from L2) and the 604 MB split operand written once.  One wavefront per output pixel, two passes over
 // its k*k taps (row maximum, then conversion); C % 8 == 0.
+// WPR = 4 (r06): all four wavefronts of the block share ONE output pixel (row maximum through LDS) -- for the few, long rows of the projector's
+// convolutions (256 output pixels x K = 9216 / 18432: one wavefront per row left 192 compute units idle and walked 36 + 36 dependent iterations;
+// 33 -> 11 us per call on the serial path between the vision tower and the LLM).  The maximum is exact in any order: same words.
+template <int WPR>
 __global__ void __launch_bounds__(256) im2col_split_f16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, float* __restrict__ inv_scale,
                                                                int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int K, int Kp) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = WPR == 1 ? (threadIdx.x & 63) : threadIdx.x;          // position among the row's lanes
+    constexpr int STEP = 512 * WPR;                                         // K elements per pass of the row's lanes
+    const long row = WPR == 1 ? (long)blockIdx.x * 4 + (threadIdx.x >> 6) : (long)blockIdx.x;
     if (row >= (long)B * Ho * Wo) return;
     const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((long)Wo * Ho));
     const float* xb = x + (long)b * H * W * C;
@@ -358,13 +363,20 @@ __global__ void __launch_bounds__(256) im2col_split_f16_kernel(const float* __re
         }
     };
     float amax = 0.f;
-    for (int e = lane * 8; e < K; e += 512) {
+    for (int e = lane * 8; e < K; e += STEP) {
         float v[8];
         load(e, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
     }
     amax = wave_max(amax);
+    if constexpr (WPR > 1) {
+        __shared__ float wmax[WPR];
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) amax = fmaxf(amax, wmax[w]);
+    }
     int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
     int se = 13 - ex;
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
@@ -373,7 +385,7 @@ __global__ void __launch_bounds__(256) im2col_split_f16_kernel(const float* __re
     const float inv = zero ? 1.f : __builtin_bit_cast(float, (unsigned)(127 - se) << 23);
     if (lane == 0) inv_scale[row] = inv;
     unsigned short* orow = out + row * 2L * Kp;
-    for (int e = lane * 8; e < Kp; e += 512) {
+    for (int e = lane * 8; e < Kp; e += STEP) {
         float v[8];
         load(e, v);
         unsigned hw[4], lw[4];
@@ -399,8 +411,12 @@ extern "C" int psalm_im2col_split_f16(const float* x, void* out, float* inv_scal
     if (rows <= 0) return 0;
     PSALM_CHECK_ARG(C > 0 && C % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "psalm_im2col_split_f16: C % 8 == 0, 16-byte aligned buffers");
     const int K = k * k * C, Kp = (K + 63) / 64 * 64;
-    hipLaunchKernelGGL(im2col_split_f16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out,
-                       inv_scale, B, H, W, C, k, stride, pad, Ho, Wo, K, Kp);
+    if (rows <= 2048 && K >= 2048 && psalm_get_tuning(PSALM_TUNE_ROW_GROUPS))      // few long rows: a block per row
+        hipLaunchKernelGGL((im2col_split_f16_kernel<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, inv_scale, B, H, W, C, k,
+                           stride, pad, Ho, Wo, K, Kp);
+    else
+        hipLaunchKernelGGL((im2col_split_f16_kernel<1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, inv_scale, B, H,
+                           W, C, k, stride, pad, Ho, Wo, K, Kp);
     PSALM_LAUNCH_END("psalm_im2col_split_f16");
 }
 

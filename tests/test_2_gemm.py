@@ -622,7 +622,8 @@ def test_gemm_f32_skinny_exact(ops, M, N, K, cd, has_res, act):
     assert (got - want).abs().max().item() <= tol
 
 
-@pytest.mark.parametrize("B,H,W,C,k,s,p", [(2, 9, 7, 8, 3, 1, 1), (1, 10, 12, 16, 3, 2, 1), (2, 8, 8, 24, 1, 2, 0), (1, 6, 5, 256, 3, 1, 1)])
+@pytest.mark.parametrize("B,H,W,C,k,s,p", [(2, 9, 7, 8, 3, 1, 1), (1, 10, 12, 16, 3, 2, 1), (2, 8, 8, 24, 1, 2, 0), (1, 6, 5, 256, 3, 1, 1),
+                                             (1, 5, 4, 264, 3, 2, 1)])      # the last two: few long rows -- a block per row (r06), ragged K padding
 def test_im2col_split_equals_im2col_then_split(ops, B, H, W, C, k, s, p):
     """psalm_im2col_split_f16 == psalm_im2col_nhwc followed by psalm_split_f16, bit for bit (hi, lo, scales, zero padding)."""
     g = torch.Generator().manual_seed(H * W + C)

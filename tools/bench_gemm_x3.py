@@ -63,6 +63,12 @@ def main():
         shapes = [(M, N, K, so) for (M, N, K) in shapes if M > 192 for so in ((False, True) if (M, N, K) in MID_SO else (False,))]
     else:
         shapes = [(M, N, K, False) for (M, N, K) in shapes]
+    if "--shapes" in sys.argv:                                 # --shapes "256,2048,18432;256,2048,9216": only these (fp32 output)
+        i = sys.argv.index("--shapes")
+        shapes = [tuple(int(v) for v in t.split(",")) + (False,) for t in sys.argv[i + 1].split(";")]
+        del sys.argv[i:i + 2]
+        if ring:
+            POLICIES = POLICIES + [("auto_default", [0]), ("t128", [128]), ("t64_slice64", [64, 3301]), ("t128_slice64", [128, 3301]), ("t256", [256])]
     for M, N, K, so_out in shapes:
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda")
