@@ -45,7 +45,9 @@ const char* psalm_backend(void); /* "hip-gfx950" */
  *   PSALM_TUNE_DECODER_FUSE     1 (default): psalm_predictor_forward issues the query rows' LayerNorm chains / paired projections as single launches
  *                               (psalm_layernorm_chain, psalm_gemm_f32_pair); 0: the r05 launch sequence
  *   PSALM_TUNE_ROW_GROUPS       1 (default): the LayerNorm-fused row kernels (psalm_layernorm_split, psalm_swin_window_gather_split,
- *                               psalm_swin_window_merge_ln_split) put 4 / 2 rows of <= 128 / 256 columns on one wavefront; 0: one row per wavefront
+ *                               psalm_swin_window_merge_ln_split) put 4 / 2 rows of <= 128 / 256 columns on one wavefront, psalm_patch_merge_ln keeps
+ *                               an fp32 row of 512 / 1024 / 2048 values in registers, psalm_im2col_split_f16 gives few long rows a block each;
+ *                               0: the r01-r05 forms (one row per wavefront)
  *   5..7                        unused */
 #define PSALM_TUNE_GEMM_XCD_KSPLIT 0
 #define PSALM_TUNE_ATTN_XCD_HEADS 1

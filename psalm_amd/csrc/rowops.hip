@@ -646,10 +646,50 @@ __global__ void __launch_bounds__(256) patch_merge_ln_kernel(const TI* __restric
     for (int c = lane; c < C4; c += 64) stf(o + c, (get(c) - mean) * rstd * gamma[c] + beta[c]);
 }
 
+// fp32 -> fp32 form for 4C = 64 NJ (r06): the row (<= 2048 values) is read ONCE into registers -- the kernel above re-reads it for the variance and for
+// the output and pays an integer division per element for the (quadrant, channel) of a column: 35 us for the 16384 x 512 rows of Swin stage 1 -> 2 (1.7 TB/s).
+// Lane <-> column map (column lane + 64 j), summation order and expressions are the kernel above's: same words.
+template <int NJ>
+__global__ void __launch_bounds__(256) patch_merge_ln_regs_kernel(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int B, int H, int W, float eps) {
+    constexpr int C4 = 64 * NJ, C = C4 / 4;
+    const int lane = threadIdx.x & 63;
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const long rows = (long)B * H2 * W2;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int x2 = (int)(r % W2), y2 = (int)((r / W2) % H2), b = (int)(r / ((long)W2 * H2));
+    float val[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int blk = (64 * j) / C, c = (64 * j) % C + lane;           // (compile-time quadrant: C % 64 == 0)
+        const int y = 2 * y2 + (blk & 1), xx = 2 * x2 + (blk >> 1);
+        val[j] = (y < H && xx < W) ? x[(((long)b * H + y) * W + xx) * C + c] : 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += val[j];
+    const float mean = wave_sum(s) / C4;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const float d = val[j] - mean; v += d * d; }
+    const float rstd = rsqrtf(wave_sum(v) / C4 + eps);
+    float* o = out + r * C4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) o[lane + 64 * j] = (val[j] - mean) * rstd * gamma[lane + 64 * j] + beta[lane + 64 * j];
+}
+
 extern "C" int psalm_patch_merge_ln(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,
                                     const float* beta, int B, int H, int W, int C, float eps, void* stream) {
     const long rows = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
     if (rows == 0) return 0;
+    if (x_dtype == PSALM_F32 && out_dtype == PSALM_F32 && (C == 128 || C == 256 || C == 512) && psalm_get_tuning(PSALM_TUNE_ROW_GROUPS)) {
+#define PML_LAUNCH(NJ_) hipLaunchKernelGGL((patch_merge_ln_regs_kernel<NJ_>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, \
+                                           gamma, beta, B, H, W, eps)
+        if (C == 128) PML_LAUNCH(8); else if (C == 256) PML_LAUNCH(16); else PML_LAUNCH(32);
+#undef PML_LAUNCH
+        PSALM_LAUNCH_END("psalm_patch_merge_ln");
+    }
     PSALM_DISPATCH(x_dtype, TI, PSALM_DISPATCH(out_dtype, TO, {
         hipLaunchKernelGGL((patch_merge_ln_kernel<TI, TO>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                            (const TI*)x, (TO*)out, gamma, beta, B, H, W, C, eps);

@@ -749,3 +749,26 @@ def test_row_kernels_several_rows_per_wavefront_same_bits(ops, B, H, W, C, shift
         if p.dtype == torch.float16:
             p, q = p.view(torch.int16), q.view(torch.int16)
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 7, 9, 128), (2, 6, 6, 256), (1, 3, 5, 512)])
+def test_patch_merge_ln_row_in_registers_same_bits(ops, B, H, W, C):
+    """r06: psalm_patch_merge_ln on fp32 rows of 4C = 512 / 1024 / 2048 values reads the row once into registers (no per-element division, no re-reads);
+    lane <-> column map, summation order and expressions are the generic kernel's: every word equal (odd H / W: zero-padded quadrants), and the
+    LayerNorm of the 2 x 2 gather-concat to fp32 round-off."""
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
+    ga, be = 1 + 0.1 * torch.randn(4 * C, generator=g), 0.1 * torch.randn(4 * C, generator=g)
+    d = ops.device
+    outs = []
+    try:
+        for v in (0, 1):
+            ops.set_tuning(ops.TUNE_ROW_GROUPS, v)
+            outs.append(ops.patch_merge_ln(x.view(-1, C).to(d), ga.to(d), be.to(d), B, H, W).cpu())
+    finally:
+        ops.set_tuning(ops.TUNE_ROW_GROUPS, 1)
+    assert torch.equal(outs[0], outs[1])
+    xx = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xx[:, 0::2, 0::2], xx[:, 1::2, 0::2], xx[:, 0::2, 1::2], xx[:, 1::2, 1::2]], -1)
+    want = F.layer_norm(cat.reshape(-1, 4 * C), (4 * C,), ga, be, 1e-5)
+    assert (outs[1] - want).abs().max() <= 1e-5 * want.abs().max()
