@@ -640,10 +640,12 @@ __global__ void __launch_bounds__(256) patch_merge_ln_kernel(const TI* __restric
     for (int c = lane; c < C4; c += 64) s += get(c);
     const float mean = wave_sum(s) / C4;
     float v = 0.f;
-    for (int c = lane; c < C4; c += 64) { const float d = get(c) - mean; v += d * d; }
+    // (fused multiply-adds written out -- the form hipcc compiled this loop to since r01 -- so that the register-resident form below and the host build
+    //  round alike)
+    for (int c = lane; c < C4; c += 64) { const float d = get(c) - mean; v = fmaf(d, d, v); }
     const float rstd = rsqrtf(wave_sum(v) / C4 + eps);
     TO* o = out + r * C4;
-    for (int c = lane; c < C4; c += 64) stf(o + c, (get(c) - mean) * rstd * gamma[c] + beta[c]);
+    for (int c = lane; c < C4; c += 64) stf(o + c, fmaf((get(c) - mean) * rstd, gamma[c], beta[c]));
 }
 
 // fp32 -> fp32 form for 4C = 64 NJ (r06): the row (<= 2048 values) is read ONCE into registers -- the kernel above re-reads it for the variance and for
@@ -672,11 +674,13 @@ __global__ void __launch_bounds__(256) patch_merge_ln_regs_kernel(const float* _
     const float mean = wave_sum(s) / C4;
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { const float d = val[j] - mean; v += d * d; }
+    for (int j = 0; j < NJ; ++j) { const float d = val[j] - mean; v = fmaf(d, d, v); }
     const float rstd = rsqrtf(wave_sum(v) / C4 + eps);
     float* o = out + r * C4;
+    // (the fused multiply-adds are WRITTEN OUT, as the generic kernel compiles them: left to the compiler, the unrolled NJ = 16 form squared 4 of its 16
+    //  differences with a packed multiply + add -- two roundings -- and the output moved by an ulp on the MI355X; the host build cannot see this)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) o[lane + 64 * j] = (val[j] - mean) * rstd * gamma[lane + 64 * j] + beta[lane + 64 * j];
+    for (int j = 0; j < NJ; ++j) o[lane + 64 * j] = fmaf((val[j] - mean) * rstd, gamma[lane + 64 * j], beta[lane + 64 * j]);
 }
 
 extern "C" int psalm_patch_merge_ln(const void* x, int x_dtype, void* out, int out_dtype, const float* gamma,
